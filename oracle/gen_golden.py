@@ -1,0 +1,364 @@
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator.
+
+Runs ONLY in the build container: imports the real reference from
+/root/reference (absent third-party deps replaced by MagicMock modules, the
+recipe of SURVEY.md Appendix A), loads the name-keyed synthetic weights of
+`oracle.svg_oracle.make_weights`, runs the reference hot path on the synthetic
+inputs of `robot_aware_control_amd.synthetic` and writes small `.npz` fixtures
+to tests/golden/.  The reference itself never travels; only these vectors do.
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/oracle/gen_golden.py
+"""
+import argparse
+import importlib.abc
+import importlib.machinery
+import importlib.util
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# our own modules are loaded by path so that the name `src` stays the reference's
+orc = _load("svg_oracle", os.path.join(REPO, "oracle", "svg_oracle.py"))
+syn = _load("rac_synthetic", os.path.join(REPO, "robot_aware_control_amd", "synthetic.py"))
+
+MISSING = {"skimage", "torchvision", "h5py", "imageio", "wandb", "colorlog", "ipdb", "cv2", "mujoco_py", "gym",
+           "rospy", "actionlib", "eef_control", "cv_bridge", "sensor_msgs", "pupil_apriltags", "mujoco", "glfw",
+           "franka_ik_service", "sklearn"}
+
+
+class _StubFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    def find_spec(self, name, path, target=None):
+        if name.split(".")[0] in MISSING:
+            return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+    def create_module(self, spec):
+        m = MagicMock(name=spec.name)
+        m.__path__, m.__spec__, m.__name__ = [], spec, spec.name
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
+sys.meta_path.insert(0, _StubFinder())
+sys.path.insert(0, REF)
+torch.set_num_threads(8)
+
+# ---- eps injection: Tensor.normal_() pops from this queue when it is non-empty ----
+_EPS = []
+_orig_normal = torch.Tensor.normal_
+
+
+def _normal_patch(self, mean=0.0, std=1.0, *, generator=None):
+    if _EPS:
+        e = _EPS.pop(0)
+        assert tuple(e.shape) == tuple(self.shape), (e.shape, self.shape)
+        self.copy_(e)
+        return self
+    return _orig_normal(self, mean, std, generator=generator)
+
+
+torch.Tensor.normal_ = _normal_patch
+
+from src.prediction.models.dynamics import SVGConvModel  # noqa: E402
+import src.prediction.losses as ref_losses  # noqa: E402
+from src.utils.state import DemoGoalState, State  # noqa: E402
+
+FLAGSETS = {
+    "vanilla": dict(model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
+                    reconstruction_loss="l1"),
+    "ra": dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=True,
+               reconstruction_loss="dontcare_l1"),
+}
+
+
+def ns_for(cfg: "orc.Cfg", **extra):
+    d = dict(cfg.__dict__)
+    d.update(device=torch.device("cpu"), debug_cem=False, log_dir="/tmp/rac_golden", img_cost_threshold=None,
+             img_cost_world_norm=True, experiment="train_robonet", robot_joint_dim=5, multiview=False,
+             load_movement_info=False, scheduled_sampling=False, model="svg", optimizer="adam")
+    d.update(extra)
+    return argparse.Namespace(**d)
+
+
+def ref_model(cfg, sd, train=False):
+    m = SVGConvModel(ns_for(cfg))
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    m.train(train)
+    return m
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KB)")
+
+
+def step_inputs(cfg, data, i):
+    """The argument packing of trainer.py:352-404 for time index i (ground-truth token)."""
+    x, m, s, a = data["images"], data["masks"], data["states"], data["actions"]
+    x_j, x_i, m_j, m_i = x[i - 1], x[i], m[i - 1], m[i]
+    if "dontcare" in cfg.reconstruction_loss or cfg.black_robot_input:
+        x_j, x_i = orc.zero_robot_region(m_j, x_j), orc.zero_robot_region(m_i, x_i)
+    m_in = torch.cat([m_j, m_i], 1) if cfg.model_use_future_mask else m_j
+    m_next = m_i.repeat(1, 2, 1, 1) if cfg.model_use_future_mask else m_i
+    return x_j, m_in, s[i - 1], a[i - 1], x_i, m_next, s[i]
+
+
+def gen_forward():
+    """F2: SVGConvModel.forward, eval + train mode, two consecutive steps."""
+    for tag, flags in FLAGSETS.items():
+        cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, **flags)
+        sd = orc.make_weights(cfg, seed=7)
+        data = syn.synth_video(seed=3, T=3, B=2)
+        eps = syn.synth_eps(seed=5, steps=2, B=2, z=16, h=8, w=8)
+        for mode in ("eval", "train"):
+            m = ref_model(cfg, sd, train=(mode == "train"))
+            m.init_hidden(2)
+            out = {}
+            with torch.no_grad():
+                # step 1: posterior path (next frame given), eps injected prior-then-posterior
+                x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1)
+                _EPS.extend([eps[0][0], eps[0][1]])
+                o = m(x_j, m_in, r, None, a, x_i, m_next, r_i, None, None)
+                assert not _EPS
+                for nm, v in zip(("x_pred", "skip", "mu", "logvar", "mu_p", "logvar_p"), o):
+                    if nm == "skip":
+                        for k, sk in enumerate(v):
+                            out[f"s1_skip{k}_sum"] = sk.double().sum()
+                            out[f"s1_skip{k}_abs"] = sk.double().abs().sum()
+                        out["s1_skip3"] = v[3]
+                    else:
+                        out[f"s1_{nm}"] = v
+                # step 2: prior only, sample_mean (the CEM call form, trajectory_sampler.py:148)
+                x_j, m_in, r, a, _, _, _ = step_inputs(cfg, data, 2)
+                _EPS.extend([eps[1][0]])
+                o = m.forward(x_j, m_in, r, None, a, sample_mean=True)
+                assert not _EPS
+                out["s2_x_pred"], out["s2_mu_p"], out["s2_logvar_p"] = o[0], o[4], o[5]
+                assert o[2] is None and o[3] is None
+            if mode == "train":
+                st = m.state_dict()
+                for k in ("encoder.c1.0.main.1", "encoder.c4.2.main.1", "decoder.upc5.0.main.1"):
+                    out[k + ".running_mean"] = st[k + ".running_mean"].clone()
+                    out[k + ".running_var"] = st[k + ".running_var"]
+                    out[k + ".num_batches_tracked"] = st[k + ".num_batches_tracked"]
+            save(f"fwd_{mode}_{tag}", **out)
+
+
+def gen_shape_pin():
+    """F6: 48x64 input -> 6x8 latent."""
+    cfg = orc.Cfg(g_dim=32, z_dim=8, batch_size=1, image_height=48, image_width=64, **FLAGSETS["vanilla"])
+    sd = orc.make_weights(cfg, seed=2)
+    m = ref_model(cfg, sd)
+    m.init_hidden(1)
+    data = syn.synth_video(seed=4, T=2, B=1, H=48, W=64)
+    with torch.no_grad():
+        o = m.forward(data["images"][0], None, None, None, data["actions"][0], sample_mean=True)
+    _EPS.clear()
+    save("fwd_48x64", x_pred=o[0], mu_p=o[4])
+
+
+def gen_losses():
+    """F3: loss values and input gradients."""
+    g = np.random.Generator(np.random.Philox(key=[11, 0]))
+    pred = torch.from_numpy(g.random((3, 3, 16, 16), dtype=np.float32)).requires_grad_(True)
+    target = torch.from_numpy(g.random((3, 3, 16, 16), dtype=np.float32))
+    mask = torch.from_numpy((g.random((3, 1, 16, 16), dtype=np.float32) < 0.3).astype(np.float32))
+    bw = torch.tensor([1.0, 2.5, 0.5])
+    out = {"pred": pred.detach(), "target": target, "mask": mask, "bw": bw}
+
+    def rec(name, fn):
+        pred.grad = None
+        v = fn()
+        v.backward()
+        out[name], out[name + "_grad"] = v.detach(), pred.grad.clone()
+
+    rec("l1", lambda: ref_losses.l1_criterion(pred, target))
+    rec("l1_bw", lambda: ref_losses.l1_criterion(pred, target, bw))
+    rec("mse", lambda: ref_losses.mse_criterion(pred, target))
+    rec("dc_l1_w0", lambda: ref_losses.dontcare_l1_criterion(pred, target, mask, 0))
+    rec("dc_l1_w05", lambda: ref_losses.dontcare_l1_criterion(pred, target, mask, 0.5))
+    rec("dc_l1_w0_bw", lambda: ref_losses.dontcare_l1_criterion(pred, target, mask, 0, bw))
+    rec("dc_mse_w05", lambda: ref_losses.dontcare_mse_criterion(pred, target, mask, 0.5))
+    with torch.no_grad():
+        out["robot_mse"] = ref_losses.robot_mse_criterion(pred, target, mask)
+        out["world_mse"] = ref_losses.world_mse_criterion(pred, target, mask)
+    mu1, lv1, mu2, lv2 = [torch.from_numpy(g.standard_normal((3, 4, 8, 8), dtype=np.float32) * np.float32(0.7))
+                          .requires_grad_(True) for _ in range(4)]
+    kl = ref_losses.kl_criterion(mu1, lv1, mu2, lv2, 3)
+    kl.backward()
+    out.update(kl=kl.detach(), mu1=mu1.detach(), lv1=lv1.detach(), mu2=mu2.detach(), lv2=lv2.detach(),
+               kl_gmu1=mu1.grad, kl_glv1=lv1.grad, kl_gmu2=mu2.grad, kl_glv2=lv2.grad)
+    # CEM costs
+    cost_cfg = argparse.Namespace(robot_cost_weight=0, world_cost_weight=1, reward_type="dense",
+                                  img_cost_threshold=None, img_cost_world_norm=True)
+    curr = torch.from_numpy(g.random((4, 3, 16, 16), dtype=np.float32))
+    goal = torch.from_numpy(g.random((3, 16, 16), dtype=np.float32))
+    cm = torch.from_numpy((g.random((4, 1, 16, 16), dtype=np.float32) < 0.3))
+    gm = torch.from_numpy((g.random((1, 16, 16), dtype=np.float32) < 0.3))
+    out.update(c_curr=curr, c_goal=goal, c_cmask=cm, c_gmask=gm)
+    out["cost_l2"] = ref_losses.RobotWorldCost(cost_cfg)(State(img=curr), State(img=goal))
+    cost_cfg.reward_type = "dontcare"
+    out["cost_dontcare"] = ref_losses.RobotWorldCost(cost_cfg)(State(img=curr, mask=cm), State(img=goal, mask=gm))
+    save("losses", **out)
+
+
+def gen_train():
+    """F4: PredictionTrainer._train_step x3 at cfg1 (+ one scheduled-sampling run)."""
+    from src.prediction.trainer import PredictionTrainer
+    for tag, flags in FLAGSETS.items():
+        for sched in ((False,) if tag == "vanilla" else (False, True)):
+            cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, **flags)
+            sd = orc.make_weights(cfg, seed=1, randomize_bn_stats=False)
+            ns = ns_for(cfg, wandb=False, jobname="g", wandb_project="x", wandb_entity="x", wandb_group=None,
+                        wandb_job_type=None, img_augmentation=False, seed=0, scheduled_sampling=sched,
+                        scheduled_sampling_k=4000, learned_robot_model=False)
+            tr = PredictionTrainer(ns)
+            tr.model.load_state_dict({k: v.clone() for k, v in sd.items()})
+            tr.model.train()
+            tr._step = 0
+            flips = [False, True, False]  # consumed once per step at i == 2
+            if sched:
+                tr._use_true_token = lambda: flips.pop(0)
+            out = {"flips": np.array([False, True, False])}
+            for step in range(3):
+                data = syn.synth_video(seed=20 + step, T=3, B=2)
+                eps = syn.synth_eps(seed=40 + step, steps=2, B=2, z=16, h=8, w=8)
+                for e in eps:
+                    _EPS.extend(e)
+                losses = tr._train_step(data)
+                assert not _EPS
+                for k, v in losses.items():
+                    out[f"step{step}_{k}"] = v
+                st = tr.model.state_dict()
+                keys = [k for k, _, kind in orc.param_spec(cfg) if kind != "bn_nbt"]
+                out[f"step{step}_norms"] = np.array([st[k].double().norm().item() for k in keys])
+                if step == 0:
+                    grads = dict(tr.model.named_parameters())
+                    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+                    out["step0_grad_norms"] = np.array([grads[k].grad.double().norm().item() for k in pk])
+                    out["step0_grad_slice_enc"] = grads["encoder.c1.0.main.0.weight"].grad.clone()
+                    out["step0_grad_slice_lstm"] = grads["prior.lstm.1.gates.weight"].grad[:4, :8].clone()
+                out[f"step{step}_nbt_enc"] = st["encoder.c1.0.main.1.num_batches_tracked"].clone()
+                out[f"step{step}_rm_enc"] = st["encoder.c1.1.main.1.running_mean"].clone()
+                out[f"step{step}_rv_enc"] = st["encoder.c1.1.main.1.running_var"].clone()
+                out[f"step{step}_rm_dec"] = st["decoder.upc4.1.main.1.running_mean"].clone()
+                out[f"step{step}_w_slice"] = st["frame_predictor.lstm.0.gates.weight"][:2, :3].clone()
+            save(f"train_cfg1_{tag}" + ("_sched" if sched else ""), **out)
+
+
+CEM_GAIN = 200.0
+CEM_SEED = {"vanilla": 5, "ra": 4}
+
+
+class _FakeRobotModel:
+    def __init__(self, states, masks):
+        self.states, self.masks = states, masks
+
+    def predict_batch(self, start_data, thick=True):
+        return self.states.clone(), self.masks.clone()
+
+
+def gen_cem():
+    """F5: generate_model_rollouts + get_action traces, action-amplified weights."""
+    from src.cem.cem import CEMPolicy
+    for tag, flags in FLAGSETS.items():
+        ra = tag == "ra"
+        cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=5, sample_mean=True,
+                      reward_type="dontcare" if ra else "dense", topk=3, **flags)
+        sd = orc.make_weights(cfg, seed=9, action_gain=CEM_GAIN)
+        model = ref_model(cfg, sd)
+        off = dict(model_use_mask=False, model_use_robot_state=False, black_robot_input=False,
+                   reward_type="dense", reconstruction_loss="l1")
+        N, T = 12, 4
+        prob = syn.synth_cem_problem(seed=CEM_SEED[tag], N=N + 1, T=T, with_robot=ra, goal_blend=0.15)
+        pol = CEMPolicy(ns_for(cfg, **off), model, horizon=T + 1, opt_iter=2, action_candidates=N, topk=3,
+                        init_std=0.03)
+        ns_on = ns_for(cfg)
+        pol.cfg = pol.traj_sampler.cfg = ns_on
+        pol.traj_sampler.cost = ref_losses.RobotWorldCost(ns_on)
+        start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+        goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+        out = {}
+        # (a) plain rollouts with an opt_traj appended as candidate N+1 (trajectory_sampler.py:62-68)
+        if ra:
+            pol.traj_sampler.robot_model = _FakeRobotModel(prob["states"], prob["masks"])
+        acts = prob["actions"][:N]
+        opt_traj = prob["actions"][N, :, :2].clone()
+        ro = pol.traj_sampler.generate_model_rollouts(acts.clone(), start, goal, opt_traj=opt_traj)
+        out["ro_sum_cost"], out["ro_optimal_sum_cost"] = ro["sum_cost"], ro["optimal_sum_cost"]
+        srt = np.sort(ro["sum_cost"])[::-1]
+        out["ro_gap_k"] = (srt[2] - srt[3]) / abs(srt[2])
+        # (b) get_action trace: record what Normal.sample consumed and every refit
+        if ra:
+            pol.traj_sampler.robot_model = _FakeRobotModel(prob["states"][:, :N], prob["masks"][:, :N])
+        trace = []
+        orig = pol._get_rollouts
+
+        def spy(act_seq, start_, goal_, opt_traj=None, plot=False):
+            r = orig(act_seq, start_, goal_, opt_traj, plot)
+            trace.append((act_seq.clone(), r["sum_cost"].copy()))
+            return r
+
+        pol._get_rollouts = spy
+        # Normal.sample == torch.normal(mean, std) == randn(shape) * std + mean on the global generator;
+        # the model's own eps draws (lstm.py:278) interleave with it, so record the N(0,1) draws here.
+        noise = []
+        orig_normal = torch.normal
+
+        def rec_normal(mean_, std_, *a, **k):
+            n = torch.randn(mean_.shape)
+            noise.append(n.clone())
+            return n.mul_(std_).add_(mean_)
+
+        torch.manual_seed(123)
+        torch.normal = rec_normal
+        try:
+            mean = pol.get_action(start, goal, 0, 0)
+        finally:
+            torch.normal = orig_normal
+        assert len(noise) == 2
+        out["ga_mean"] = mean
+        for i, (a, c) in enumerate(trace):
+            out[f"ga_act{i}"], out[f"ga_cost{i}"], out[f"ga_noise{i}"] = a[:, :, :2], c, noise[i]
+        # self-check: the oracle's reconstruction of Normal.sample from randn
+        o_mean, o_trace = orc.cem_get_action(
+            sd, cfg, prob["start_img"], prob["goal_imgs"], prob["goal_masks"], T + 1, 2, N, 3, 0.03, noise,
+            states=prob["states"][:, :N] if ra else None, masks=prob["masks"][:, :N] if ra else None)
+        for i in range(2):
+            assert np.array_equal(o_trace[i]["act_seq"], trace[i][0][:, :, :2].numpy()), "Normal.sample != mean+std*randn"
+        print(tag, "oracle-vs-ref get_action max|dmean|", np.abs(o_mean - mean).max(), "gap", out["ro_gap_k"])
+        save(f"cem_{tag}", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem"]
+    if "forward" in which:
+        gen_forward()
+    if "shape" in which:
+        gen_shape_pin()
+    if "losses" in which:
+        gen_losses()
+    if "train" in which:
+        gen_train()
+    if "cem" in which:
+        gen_cem()
