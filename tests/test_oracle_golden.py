@@ -142,7 +142,8 @@ def test_train_steps(golden_dir, name, tag, sched):
         close(ts.sd["encoder.c1.1.main.1.running_mean"], g[f"step{step}_rm_enc"], rtol=1e-5, atol=1e-7)
         close(ts.sd["encoder.c1.1.main.1.running_var"], g[f"step{step}_rv_enc"], rtol=1e-5)
         close(ts.sd["decoder.upc4.1.main.1.running_mean"], g[f"step{step}_rm_dec"], rtol=1e-5, atol=1e-7)
-        close(ts.sd["frame_predictor.lstm.0.gates.weight"].detach()[:2, :3], g[f"step{step}_w_slice"], rtol=1e-5, atol=1e-8)
+        close(ts.sd["frame_predictor.lstm.0.gates.weight"].detach()[:2, :3], g[f"step{step}_w_slice"], rtol=1e-5,
+              atol=5e-6)  # Adam's first steps move every weight by ~lr*sign(g): tiny grads make 5% of lr the noise floor
 
 
 @pytest.mark.parametrize("tag", ["vanilla", "ra"])
