@@ -132,7 +132,7 @@ def test_train_steps(golden_dir, name, tag, sched):
         for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
             close(losses[k], g[f"step{step}_{k}"], rtol=2e-5)
         norms = np.array([ts.sd[k].detach().double().norm().item() for k in keys])
-        close(norms, g[f"step{step}_norms"], rtol=1e-5)
+        close(norms, g[f"step{step}_norms"], rtol=1e-4)
         if step == 0:
             pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
             gn = np.array([ts.sd[k].grad.double().norm().item() for k in pk])
