@@ -1,0 +1,195 @@
+/*
+ * librac_hip.so -- C ABI of the MI355X (gfx950) hot path of robot_aware_control:
+ * the conv-SVG dynamics model (train step + frozen rollouts) and the CEM cost tail.
+ *
+ * The reference has no FFI layer: the path sits behind Python/PyTorch operators
+ * (SURVEY.md section 8b).  Each entry point below replaces the ATen operator(s)
+ * the reference calls at the cited file:line (paths relative to the reference root).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer to caller-owned memory; the library never
+ *     allocates, frees or synchronises; kernels are launched on `stream`
+ *     (a hipStream_t passed as void*).
+ *   - activations are fp32 NHWC ("channels last": [B][H][W][C]); conv weights are
+ *     fp32 [Cout][kh][kw][Cin] (the channels_last memory of a (Cout,Cin,kh,kw)
+ *     tensor); frames at the model boundary are NCHW planes as the reference
+ *     dataloader produces them (src/dataset/robonet/robonet_dataset.py:434-451).
+ *   - return value 0 on success, negative RAC_E* otherwise; rac_last_error()
+ *     returns a thread-local message for the last failure.
+ */
+#ifndef RAC_HIP_H
+#define RAC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAC_OK 0
+#define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
+#define RAC_ELAUNCH (-2)  /* hipLaunch failed */
+
+#define RAC_ABI_VERSION 1
+
+int rac_version(void);
+const char* rac_device_arch(void); /* "gfx950" */
+const char* rac_last_error(void);
+
+/* ------------------------------------------------------------------------ *
+ * Implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * stride 1, "same" padding (pad = ksize/2), ksize odd.
+ * ------------------------------------------------------------------------ */
+enum {
+  RAC_CONV_FWD = 0,   /* out[p][co] = sum_{tap,ci} in[p+tap][ci] * w[co][tap][ci]          */
+  RAC_CONV_DGRAD = 1, /* out[p][ci] = sum_{tap,co} in[p-tap][co] * w[co][tap][ci]          */
+  RAC_CONV_WGRAD = 2  /* dw[co][tap][ci] += sum_p dy[p][co] * x[p+tap][ci]                 */
+};
+enum { RAC_ACT_NONE = 0, RAC_ACT_LEAKY02 = 1, RAC_ACT_SIGMOID = 2 };
+
+typedef struct rac_conv_args {
+  int32_t mode;       /* RAC_CONV_* */
+  int32_t B, H, W;    /* batch and spatial size (input == output) */
+  int32_t ksize;      /* 3 or 5 */
+  int32_t Cin;        /* weight inner dim  (channels of the conv input)  */
+  int32_t Cout;       /* weight outer dim  (channels of the conv output) */
+  int32_t act;        /* RAC_ACT_*  (FWD / DGRAD epilogue) */
+  int32_t split_k;    /* >=1.  FWD/DGRAD: slab s written at out + s*slab_stride (no epilogue);
+                         WGRAD: partial sums combined with float atomics */
+  int32_t accumulate; /* WGRAD: 1 -> dw += result (dw holds a valid gradient), 0 -> dw = result */
+  int32_t a_split;    /* A-side virtual concat: channels [0,a_split) come from a0, the rest from a1.
+                         FWD: the conv input (Cin = a_split + rest); DGRAD: unused (0).
+                         WGRAD: the saved conv input x. 0 or == channel count -> single source */
+  int32_t o_split;    /* DGRAD: output channels [0,o_split) go to out0, the rest to out1 (0 -> single) */
+  int64_t slab_stride;/* elements between split-K slabs (FWD/DGRAD with split_k > 1) */
+  const float* a0;    /* FWD: input NHWC (first a_split channels); DGRAD: dy NHWC [.,Cout]; WGRAD: x part 0 */
+  const float* a1;    /* second source of the virtual concat, or NULL */
+  const float* w;     /* FWD/DGRAD: weights [Cout][k][k][Cin]; WGRAD: dy NHWC [.,Cout] */
+  float* out0;        /* FWD: [.,Cout]; DGRAD: [.,Cin or o_split]; WGRAD: dw [Cout][k][k][Cin] */
+  float* out1;        /* DGRAD second destination or NULL */
+  const float* bias;  /* [N] added first, or NULL */
+  const float* scale; /* [N] v = v*scale + shift (folded eval BatchNorm), or NULL */
+  const float* shift;
+  double* stats;      /* [2][N] fp64 sum / sum of squares of the raw conv output (train BatchNorm), or NULL */
+} rac_conv_args;
+
+/* Replaces aten::conv2d / conv_transpose2d and their backward on the hot path:
+ *   src/prediction/models/vgg_64.py:8-18 (vgg_layer), :218-220 (ConvTranspose2d head),
+ *   src/prediction/models/lstm.py:129-149 (ConvLSTMCell gates), :273-274 (mu/logvar heads),
+ *   src/prediction/models/dynamics.py:496-513 (input convs). */
+int rac_conv2d(const rac_conv_args* a, void* stream);
+
+
+/* ------------------------------------------------------------------------ *
+ * BatchNorm2d (training statistics) + LeakyReLU(0.2)
+ *   src/prediction/models/vgg_64.py:12-14 (nn.BatchNorm2d, nn.LeakyReLU(0.2))
+ * ------------------------------------------------------------------------ */
+/* stats = fp64 [2][C] (sum, sum of squares over `count` = B*H*W values, from rac_conv2d).
+ * Writes mean/invstd (biased variance, eps), scale = gamma*invstd, shift = beta - mean*scale,
+ * and applies the running-stat momentum update `n_updates` times (the reference encodes the
+ * same frame twice per train step: dynamics.py:584,619). */
+int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int32_t n_updates, float* scale, float* shift,
+                    float* mean, float* invstd, int32_t C, void* stream);
+/* y[m][c] = act(x[m][c]*scale[c] + shift[c]) */
+int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
+                   int32_t C, void* stream);
+/* sums = fp64 [2][C]: sum dz, sum dz*xhat  with z = x*scale+shift, dz = dy*(z>0?1:0.2), xhat=(x-mean)*invstd.
+ * `sums` must be zero on entry. */
+int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, double* sums, int64_t M, int32_t C, void* stream);
+/* dx = scale*(dz - sum_dz/M - xhat*sum_dzx/M); dgamma += sum_dzx; dbeta += sum_dz */
+int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
+                     int32_t C, void* stream);
+
+/* MaxPool2d(2,2) / nearest x2 upsample on NHWC maps: vgg_64.py:120,126-128 / :221,235-240 */
+int rac_maxpool2_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int rac_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                     void* stream);
+int rac_upsample2_fwd(const float* x, float* y, int32_t B, int32_t h, int32_t w, int32_t C, void* stream);
+int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t w, int32_t C, void* stream);
+
+/* out[b][p][:] = [v0[b] | v1[b] | v2[b] | m0[b][p] | m1[b][p]]   (dynamics.py:591-607,634-640:
+ * action / robot-state tiling + channel concat in front of the three input convs) */
+int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
+                    const float* m0, int32_t c0, const float* m1, int32_t c1, float* out, int32_t B, int32_t HW,
+                    void* stream);
+/* dst[m][0:n] = src[m][off:off+n]  (row strides Csrc / n) */
+int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t n, float* dst, int64_t M, void* stream);
+/* out[c] += sum_m x[m][c]   (bias gradients) */
+int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream);
+
+/* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
+int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
+                    int64_t n, int32_t N, void* stream);
+/* stats[c] += sum_m x[m][c]; stats[C+c] += sum_m x[m][c]^2  (fp64; BatchNorm statistics after a split-K combine) */
+int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream);
+/* dx = dy * act'(.) expressed through the activation OUTPUT y (sigmoid: y(1-y); leaky: y>0 ? 1 : 0.2) */
+int rac_act_bwd(const float* dy, const float* y, int32_t act, float* dx, int64_t n, void* stream);
+
+/* ConvLSTM cell pointwise part (lstm.py:136-149); gate order i, f, o, g.
+ * pre = sum_s slabs[s] + bias;  c = sig(f)*c_prev + sig(i)*tanh(g);  h = sig(o)*tanh(c).
+ * act_out (nullable) receives the four activated gates [M][4g] for the backward pass. */
+int rac_lstm_cell_fwd(const float* gate_slabs, int32_t n_slabs, int64_t slab_stride, const float* bias,
+                      const float* c_prev, float* h_out, float* c_out, float* act_out, int64_t M, int32_t g,
+                      void* stream);
+/* dgates[M][4g] (pre-activation grads), dc_prev[M][g]; dc_next may be NULL (zero). */
+int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev,
+                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, void* stream);
+
+/* z = eps*exp(0.5*logvar) + mu (lstm.py:276-279); dlogvar = dz*eps*0.5*exp(0.5*logvar) */
+int rac_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
+int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------ *
+ * Frame-level elementwise ops (NCHW planes at the model boundary)
+ * ------------------------------------------------------------------------ */
+/* packed[b][p][:] = [img[b][0..2][p] * (zmask ? 1-zmask[b][p] : 1) | mask[b][0..Cm-1][p]]
+ * = zero_robot_region (src/utils/image.py:5-19) + cat([img, mask]) (dynamics.py:578-582), NCHW -> NHWC */
+int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, float* packed, int32_t B,
+                   int32_t HW, void* stream);
+/* dimg[b][c][p] = dpacked[b][p][c] * (zmask ? 1-zmask : 1), c < 3 */
+int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,
+                    void* stream);
+/* out = img * (1 - mask)   (also its own backward) */
+int rac_zero_region(const float* img, const float* mask, float* out, int32_t B, int32_t HW, void* stream);
+/* out[b][c][p] = (1-m)*prev[b][c][p] + m*x4[b][p][c],  m = x4[b][p][3]   (trainer.py:406-407) */
+int rac_composite_fwd(const float* x4, const float* prev, float* out, int32_t B, int32_t HW, void* stream);
+int rac_composite_bwd(const float* dout, const float* x4, const float* prev, float* dx4, float* dprev, int32_t B,
+                      int32_t HW, void* stream);
+
+/* Reconstruction losses + logging metrics in one pass (losses.py:11-78, trainer.py:149-161,426-452).
+ * kind: 0 mse, 1 l1, 2 dontcare_mse, 3 dontcare_l1.  out[0] = loss, out[1] = robot_mse, out[2] = world_mse
+ * (out[1..2] only when mask != NULL).  per_sample = workspace fp32 [B][8]. */
+enum { RAC_LOSS_MSE = 0, RAC_LOSS_L1 = 1, RAC_LOSS_DONTCARE_MSE = 2, RAC_LOSS_DONTCARE_L1 = 3 };
+int rac_recon_loss_fwd(int32_t kind, const float* pred, const float* target, const float* mask, float robot_weight,
+                       const float* batch_weight, float* per_sample, float* out, int32_t B, int32_t HW, void* stream);
+/* dpred = gout[0] * dloss/dpred ; per_sample from the forward call */
+int rac_recon_loss_bwd(int32_t kind, const float* pred, const float* target, const float* mask, float robot_weight,
+                       const float* batch_weight, const float* per_sample, const float* gout, float* dpred, int32_t B,
+                       int32_t HW, void* stream);
+/* kl_criterion (losses.py:97-106): out[0] = sum(...) / bs ; partial = workspace fp64 [1] (zeroed by the call) */
+int rac_kl_fwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, int64_t n, int32_t bs,
+               double* partial, float* out, void* stream);
+int rac_kl_bwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, const float* gout, int64_t n,
+               int32_t bs, float* dmu1, float* dlv1, float* dmu2, float* dlv2, void* stream);
+
+/* CEM step tail (trajectory_sampler.py:149-169 + losses.py:224-263), fused:
+ *   next = (1-m)*curr + m*rgb; next *= (1-next_mask) if next_mask;
+ *   cost = -sqrt(sum (255*(next-goal))^2) [dontcare: robot|goal-mask pixels dropped, / #world pixels]
+ *   sum_cost[n] += weight * (double)(float)cost      (fp64 accumulate, kept on the device)
+ * kind: 0 ImgL2Cost, 1 ImgDontcareCost.  cost_mask = thick robot mask of the next step (dontcare only). */
+int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask, const float* goal_img,
+                      const float* cost_mask, const uint8_t* goal_mask, int32_t kind, float weight, int32_t add_cost,
+                      float* next_out, double* sum_cost, int32_t N, int32_t HW, void* stream);
+
+/* torch.optim.Adam step (trainer.py:109-110,461), fused over one flat buffer. step >= 1. */
+int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAC_HIP_H */

@@ -1,0 +1,109 @@
+"""ctypes binding of librac_hip.so (the C ABI declared in include/rac_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a
+call fails, this module raises.  Tensors cross the boundary as raw device
+pointers (`tensor.data_ptr()`), the stream as `torch.cuda.current_stream().cuda_stream`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librac_hip.so")
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvArgs(C.Structure):
+    """struct rac_conv_args (include/rac_hip.h)."""
+    _fields_ = [
+        ("mode", i32), ("B", i32), ("H", i32), ("W", i32), ("ksize", i32), ("Cin", i32), ("Cout", i32),
+        ("act", i32), ("split_k", i32), ("accumulate", i32), ("a_split", i32), ("o_split", i32),
+        ("slab_stride", i64),
+        ("a0", vp), ("a1", vp), ("w", vp), ("out0", vp), ("out1", vp),
+        ("bias", vp), ("scale", vp), ("shift", vp), ("stats", vp),
+    ]
+
+
+# name -> argtypes (return type is always int unless listed in _RET)
+_SIGS = {
+    "rac_conv2d": [C.POINTER(ConvArgs), vp],
+    "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, vp],
+    "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, vp],
+    "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, vp],
+    "rac_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
+    "rac_upsample2_fwd": [vp, vp, i32, i32, i32, i32, vp],
+    "rac_upsample2_bwd": [vp, vp, i32, i32, i32, i32, vp],
+    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp],
+    "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
+    "rac_colsum_acc": [vp, vp, i64, i32, vp],
+    "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp],
+    "rac_col_stats": [vp, vp, i64, i32, vp],
+    "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
+    "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_reparam_fwd": [vp, vp, vp, vp, i64, vp],
+    "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
+    "rac_pack_input": [vp, vp, vp, i32, vp, i32, i32, vp],
+    "rac_unpack_grad": [vp, i32, vp, vp, i32, i32, vp],
+    "rac_zero_region": [vp, vp, vp, i32, i32, vp],
+    "rac_composite_fwd": [vp, vp, vp, i32, i32, vp],
+    "rac_composite_bwd": [vp, vp, vp, vp, vp, i32, i32, vp],
+    "rac_recon_loss_fwd": [i32, vp, vp, vp, f32, vp, vp, vp, i32, i32, vp],
+    "rac_recon_loss_bwd": [i32, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp],
+    "rac_kl_fwd": [vp, vp, vp, vp, i64, i32, vp, vp, vp],
+    "rac_kl_bwd": [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
+    "rac_cem_step_tail": [vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, i32, vp],
+    "rac_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
+    "rac_version": [],
+    "rac_device_arch": [],
+    "rac_last_error": [],
+}
+_RET = {"rac_device_arch": C.c_char_p, "rac_last_error": C.c_char_p}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+class RacError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen librac_hip.so and type every export; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RacError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       f"or `make -C robot_aware_control_amd/csrc` (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RET.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t) -> int | None:
+    """Device pointer of a tensor (None passes NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RacError(f"{name} failed ({rc}): {lib.rac_last_error().decode()}")

@@ -1,0 +1,379 @@
+// Frame-level kernels at the model boundary (NCHW planes <-> NHWC maps):
+// input packing with robot-region zeroing, mask compositing, the reconstruction
+// losses (+ logging metrics) and the fused CEM step tail with fp64 cost sums.
+// All of them stream 3-5 planes of H*W floats per frame: HBM-bound.
+#include "rac_common.h"
+
+namespace rac {
+
+static inline int grid_for(long work_items) {
+  long b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+__global__ void pack_input_kernel(const float* img, const float* zmask, const float* mask, int Cm, float* packed,
+                                  int B, int HW) {
+  const int C = 3 + Cm;
+  const long n = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW;
+    int p = (int)(i - b * HW);
+    const bool zero = zmask && zmask[i] != 0.f;
+    float* o = packed + i * C;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float v = img[(b * 3 + c) * HW + p];
+      o[c] = zero ? v * 0.f : v;
+    }
+    for (int c = 0; c < Cm; ++c) o[3 + c] = mask[(b * Cm + c) * HW + p];
+  }
+}
+
+__global__ void unpack_grad_kernel(const float* dpacked, int C, const float* zmask, float* dimg, int B, int HW) {
+  const long n = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW;
+    int p = (int)(i - b * HW);
+    const bool zero = zmask && zmask[i] != 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dimg[(b * 3 + c) * HW + p] = zero ? 0.f : dpacked[i * C + c];
+  }
+}
+
+__global__ void zero_region_kernel(const float* img, const float* mask, float* out, int B, int HW) {
+  const long n = (long)B * 3 * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long bc = i / HW;
+    int p = (int)(i - bc * HW);
+    long b = bc / 3;
+    float v = img[i];
+    out[i] = (mask[b * HW + p] != 0.f) ? v * 0.f : v;
+  }
+}
+
+__global__ void composite_fwd_kernel(const f32x4* x4, const float* prev, float* out, int B, int HW) {
+  const long n = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW;
+    int p = (int)(i - b * HW);
+    f32x4 v = x4[i];
+    const float m = v.w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      long o = (b * 3 + c) * HW + p;
+      out[o] = (1.f - m) * prev[o] + m * v[c];
+    }
+  }
+}
+
+__global__ void composite_bwd_kernel(const float* dout, const f32x4* x4, const float* prev, f32x4* dx4, float* dprev,
+                                     int B, int HW) {
+  const long n = (long)B * HW;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long b = i / HW;
+    int p = (int)(i - b * HW);
+    f32x4 v = x4[i], d;
+    const float m = v.w;
+    float dm = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      long o = (b * 3 + c) * HW + p;
+      float g = dout[o];
+      d[c] = g * m;
+      dm += g * (v[c] - prev[o]);
+      if (dprev) dprev[o] = g * (1.f - m);
+    }
+    d.w = dm;
+    dx4[i] = d;
+  }
+}
+
+// ---- reconstruction losses --------------------------------------------------
+// per_sample[b][0..7]: 0 main sum, 1 #world values (3 per unmasked pixel), 2 sum robot d^2, 3 #robot values,
+//                      4 sum world d^2
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) sh[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) t += sh[k];
+  return t;
+}
+
+__global__ void recon_loss_sample_kernel(int kind, const float* pred, const float* target, const float* mask,
+                                         float rw, float* per_sample, int HW) {
+  __shared__ float sh[16];
+  const int b = blockIdx.x;
+  const long base = (long)b * 3 * HW;
+  float s_main = 0.f, s_world_n = 0.f, s_rob2 = 0.f, s_rob_n = 0.f, s_world2 = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const bool rob = mask && mask[(long)b * HW + p] != 0.f;
+    if (mask) {
+      if (rob) s_rob_n += 3.f; else s_world_n += 3.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float d = target[base + (long)c * HW + p] - pred[base + (long)c * HW + p];
+      if (mask) {
+        if (rob) s_rob2 += d * d; else s_world2 += d * d;
+      }
+      float dm = d;
+      if ((kind == RAC_LOSS_DONTCARE_L1 || kind == RAC_LOSS_DONTCARE_MSE) && rob) dm = d * rw;
+      s_main += (kind == RAC_LOSS_L1 || kind == RAC_LOSS_DONTCARE_L1) ? fabsf(dm) : dm * dm;
+    }
+  }
+  float t0 = block_sum(s_main, sh), t1 = block_sum(s_world_n, sh), t2 = block_sum(s_rob2, sh),
+        t3 = block_sum(s_rob_n, sh), t4 = block_sum(s_world2, sh);
+  if (threadIdx.x == 0) {
+    float* o = per_sample + b * 8;
+    o[0] = t0, o[1] = t1, o[2] = t2, o[3] = t3, o[4] = t4;
+  }
+}
+
+__global__ void recon_loss_final_kernel(int kind, const float* per_sample, const float* bw, bool has_mask, float* out,
+                                        int B, int HW) {
+  __shared__ float sh[16];
+  float a = 0.f, r = 0.f, w = 0.f;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const float* s = per_sample + b * 8;
+    float wt = bw ? bw[b] : 1.f;
+    if (kind == RAC_LOSS_DONTCARE_L1 || kind == RAC_LOSS_DONTCARE_MSE)
+      a += wt * s[0] / (s[1] + 1.f);
+    else if (kind == RAC_LOSS_L1)
+      a += wt * (s[0] / (3.f * HW));
+    else
+      a += s[0] / (3.f * HW);
+    if (has_mask) {
+      r += s[2] / (s[3] + 1.f);
+      w += s[4] / (s[1] + 1.f);
+    }
+  }
+  float ta = block_sum(a, sh), tr = block_sum(r, sh), tw = block_sum(w, sh);
+  if (threadIdx.x == 0) {
+    out[0] = ta / B;
+    out[1] = tr / B;
+    out[2] = tw / B;
+  }
+}
+
+__global__ void recon_loss_bwd_kernel(int kind, const float* pred, const float* target, const float* mask, float rw,
+                                      const float* bw, const float* per_sample, const float* gout, float* dpred,
+                                      int B, int HW) {
+  const long n = (long)B * 3 * HW;
+  const float g = gout[0];
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long bc = i / HW;
+    int p = (int)(i - bc * HW);
+    int b = (int)(bc / 3);
+    float d = target[i] - pred[i];
+    float wt = bw ? bw[b] : 1.f;
+    float coef, dm = d, inner = 1.f;
+    if (kind == RAC_LOSS_DONTCARE_L1 || kind == RAC_LOSS_DONTCARE_MSE) {
+      coef = wt / ((per_sample[b * 8 + 1] + 1.f) * B);
+      if (mask[(long)b * HW + p] != 0.f) {
+        dm = d * rw;
+        inner = rw;
+      }
+    } else {
+      coef = ((kind == RAC_LOSS_L1) ? wt : 1.f) / (3.f * HW * B);
+    }
+    float dd;  // d loss_elem / d dm
+    if (kind == RAC_LOSS_L1 || kind == RAC_LOSS_DONTCARE_L1)
+      dd = (dm > 0.f) ? 1.f : ((dm < 0.f) ? -1.f : 0.f);
+    else
+      dd = 2.f * dm;
+    dpred[i] = -g * coef * dd * inner;
+  }
+}
+
+// ---- KL ---------------------------------------------------------------------
+__global__ void kl_fwd_kernel(const float* mu1, const float* lv1, const float* mu2, const float* lv2, long n,
+                              double* partial) {
+  __shared__ float sh[16];
+  float a = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s1 = expf(0.5f * lv1[i]), s2 = expf(0.5f * lv2[i]);
+    float dmu = mu1[i] - mu2[i];
+    a += logf(s2 / s1) + (expf(lv1[i]) + dmu * dmu) / (2.f * expf(lv2[i])) - 0.5f;
+  }
+  float t = block_sum(a, sh);
+  if (threadIdx.x == 0) atomicAdd(partial, (double)t);
+}
+__global__ void kl_final_kernel(const double* partial, int bs, float* out) { out[0] = (float)(partial[0] / bs); }
+
+__global__ void kl_bwd_kernel(const float* mu1, const float* lv1, const float* mu2, const float* lv2,
+                              const float* gout, long n, int bs, float* dmu1, float* dlv1, float* dmu2, float* dlv2) {
+  const float g = gout[0] / bs;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float e1 = expf(lv1[i]), e2 = expf(lv2[i]);
+    float dmu = mu1[i] - mu2[i];
+    float q = (e1 + dmu * dmu) / (2.f * e2);
+    dmu1[i] = g * dmu / e2;
+    dmu2[i] = -g * dmu / e2;
+    dlv1[i] = g * (-0.5f + e1 / (2.f * e2));
+    dlv2[i] = g * (0.5f - q);
+  }
+}
+
+// ---- CEM step tail ------------------------------------------------------------
+__global__ void cem_step_tail_kernel(const f32x4* x4, const float* curr, const float* next_mask, const float* goal,
+                                     const float* cost_mask, const unsigned char* goal_mask, int kind, float weight,
+                                     int add_cost, float* next_out, double* sum_cost, int HW) {
+  __shared__ double shd[16];
+  const int b = blockIdx.x;
+  const long base = (long)b * 3 * HW;
+  double acc = 0.0;
+  float nworld = 0.f;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    f32x4 v = x4[(long)b * HW + p];
+    const float m = v.w;
+    const bool zero = next_mask && next_mask[(long)b * HW + p] != 0.f;
+    bool drop = false;
+    if (kind == 1) {
+      drop = (cost_mask && cost_mask[(long)b * HW + p] != 0.f) || (goal_mask && goal_mask[p] != 0);
+      if (!drop) nworld += 1.f;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      long o = base + (long)c * HW + p;
+      float nx = (1.f - m) * curr[o] + m * v[c];
+      if (zero) nx = nx * 0.f;
+      next_out[o] = nx;
+      float d = 255.f * (nx - goal[(long)c * HW + p]);
+      float sq = d * d;
+      if (!drop) acc += (double)sq;
+    }
+  }
+  if (!add_cost) return;
+  // block reduce (fp64)
+  acc = wave_sum_d(acc);
+  nworld = wave_sum(nworld);
+  __shared__ float shn[16];
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) {
+    shd[w] = acc;
+    shn[w] = nworld;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    float nw = 0.f;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+      t += shd[k];
+      nw += shn[k];
+    }
+    float dist = sqrtf((float)t);
+    if (kind == 1) dist = dist / nw;
+    sum_cost[b] += (double)(weight * (-dist));
+  }
+}
+
+}  // namespace rac
+
+using namespace rac;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, float* packed, int32_t B,
+                   int32_t HW, void* stream) {
+  RAC_REQUIRE(img && packed && B > 0 && HW > 0 && Cm >= 0 && (Cm == 0 || mask), "rac_pack_input: bad args");
+  hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), img, zmask, mask, Cm,
+                     packed, B, HW);
+  return check_launch("rac_pack_input");
+}
+
+int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,
+                    void* stream) {
+  RAC_REQUIRE(dpacked && dimg && C >= 3 && B > 0 && HW > 0, "rac_unpack_grad: bad args");
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), dpacked, C, zmask,
+                     dimg, B, HW);
+  return check_launch("rac_unpack_grad");
+}
+
+int rac_zero_region(const float* img, const float* mask, float* out, int32_t B, int32_t HW, void* stream) {
+  RAC_REQUIRE(img && mask && out && B > 0 && HW > 0, "rac_zero_region: bad args");
+  hipLaunchKernelGGL(zero_region_kernel, dim3(grid_for((long)B * 3 * HW)), dim3(256), 0, ST(stream), img, mask, out, B,
+                     HW);
+  return check_launch("rac_zero_region");
+}
+
+int rac_composite_fwd(const float* x4, const float* prev, float* out, int32_t B, int32_t HW, void* stream) {
+  RAC_REQUIRE(x4 && prev && out && B > 0 && HW > 0 && aligned16(x4), "rac_composite_fwd: bad args");
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), (const f32x4*)x4,
+                     prev, out, B, HW);
+  return check_launch("rac_composite_fwd");
+}
+
+int rac_composite_bwd(const float* dout, const float* x4, const float* prev, float* dx4, float* dprev, int32_t B,
+                      int32_t HW, void* stream) {
+  RAC_REQUIRE(dout && x4 && prev && dx4 && B > 0 && HW > 0 && aligned16(x4) && aligned16(dx4),
+              "rac_composite_bwd: bad args");
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), dout,
+                     (const f32x4*)x4, prev, (f32x4*)dx4, dprev, B, HW);
+  return check_launch("rac_composite_bwd");
+}
+
+int rac_recon_loss_fwd(int32_t kind, const float* pred, const float* target, const float* mask, float robot_weight,
+                       const float* batch_weight, float* per_sample, float* out, int32_t B, int32_t HW, void* stream) {
+  RAC_REQUIRE(kind >= 0 && kind <= 3 && pred && target && per_sample && out && B > 0 && HW > 0,
+              "rac_recon_loss_fwd: bad args");
+  RAC_REQUIRE(!((kind == RAC_LOSS_DONTCARE_L1 || kind == RAC_LOSS_DONTCARE_MSE) && !mask),
+              "rac_recon_loss_fwd: dontcare loss needs a mask");
+  hipLaunchKernelGGL(recon_loss_sample_kernel, dim3(B), dim3(256), 0, ST(stream), kind, pred, target, mask,
+                     robot_weight, per_sample, HW);
+  hipLaunchKernelGGL(recon_loss_final_kernel, dim3(1), dim3(256), 0, ST(stream), kind, per_sample, batch_weight,
+                     mask != nullptr, out, B, HW);
+  return check_launch("rac_recon_loss_fwd");
+}
+
+int rac_recon_loss_bwd(int32_t kind, const float* pred, const float* target, const float* mask, float robot_weight,
+                       const float* batch_weight, const float* per_sample, const float* gout, float* dpred, int32_t B,
+                       int32_t HW, void* stream) {
+  RAC_REQUIRE(kind >= 0 && kind <= 3 && pred && target && per_sample && gout && dpred && B > 0 && HW > 0,
+              "rac_recon_loss_bwd: bad args");
+  RAC_REQUIRE(!((kind == RAC_LOSS_DONTCARE_L1 || kind == RAC_LOSS_DONTCARE_MSE) && !mask),
+              "rac_recon_loss_bwd: dontcare loss needs a mask");
+  hipLaunchKernelGGL(recon_loss_bwd_kernel, dim3(grid_for((long)B * 3 * HW)), dim3(256), 0, ST(stream), kind, pred,
+                     target, mask, robot_weight, batch_weight, per_sample, gout, dpred, B, HW);
+  return check_launch("rac_recon_loss_bwd");
+}
+
+int rac_kl_fwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, int64_t n, int32_t bs,
+               double* partial, float* out, void* stream) {
+  RAC_REQUIRE(mu1 && lv1 && mu2 && lv2 && partial && out && n > 0 && bs > 0, "rac_kl_fwd: bad args");
+  hipError_t e = hipMemsetAsync(partial, 0, sizeof(double), ST(stream));
+  if (e != hipSuccess) {
+    set_error("rac_kl_fwd: memset: %s", hipGetErrorString(e));
+    return RAC_ELAUNCH;
+  }
+  long nb = (n + 255) / 256;
+  if (nb > 256) nb = 256;
+  hipLaunchKernelGGL(kl_fwd_kernel, dim3((int)nb), dim3(256), 0, ST(stream), mu1, lv1, mu2, lv2, (long)n, partial);
+  hipLaunchKernelGGL(kl_final_kernel, dim3(1), dim3(1), 0, ST(stream), partial, bs, out);
+  return check_launch("rac_kl_fwd");
+}
+
+int rac_kl_bwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, const float* gout, int64_t n,
+               int32_t bs, float* dmu1, float* dlv1, float* dmu2, float* dlv2, void* stream) {
+  RAC_REQUIRE(mu1 && lv1 && mu2 && lv2 && gout && dmu1 && dlv1 && dmu2 && dlv2 && n > 0 && bs > 0,
+              "rac_kl_bwd: bad args");
+  hipLaunchKernelGGL(kl_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), mu1, lv1, mu2, lv2, gout, (long)n, bs,
+                     dmu1, dlv1, dmu2, dlv2);
+  return check_launch("rac_kl_bwd");
+}
+
+int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask, const float* goal_img,
+                      const float* cost_mask, const uint8_t* goal_mask, int32_t kind, float weight, int32_t add_cost,
+                      float* next_out, double* sum_cost, int32_t N, int32_t HW, void* stream) {
+  RAC_REQUIRE(x4 && curr && goal_img && next_out && sum_cost && N > 0 && HW > 0 && aligned16(x4),
+              "rac_cem_step_tail: bad args");
+  RAC_REQUIRE(kind == 0 || kind == 1, "rac_cem_step_tail: kind must be 0 (l2) or 1 (dontcare)");
+  hipLaunchKernelGGL(cem_step_tail_kernel, dim3(N), dim3(256), 0, ST(stream), (const f32x4*)x4, curr, next_mask,
+                     goal_img, cost_mask, goal_mask, kind, weight, add_cost, next_out, sum_cost, HW);
+  return check_launch("rac_cem_step_tail");
+}
+
+}  // extern "C"

@@ -1,0 +1,611 @@
+// HBM-bound kernels around the convolutions: BatchNorm statistics / apply /
+// backward, pooling, upsampling, tiling, ConvLSTM gate math, reparameterisation,
+// bias gradients and the fused Adam step.  fp32 NHWC maps ([M = B*H*W][C]).
+// Elementwise kernels move 16 B per lane when C % 4 == 0 and grid-stride over
+// at most 2048 workgroups (256 CUs x 8).
+#include "rac_common.h"
+
+namespace rac {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int grid_for(long work_items) {
+  long b = (work_items + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+// ------------------------------------------------------------------ BatchNorm
+__global__ void bn_finalize_kernel(const double* stats, long count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, float momentum, float eps, int n_updates, float* scale,
+                                   float* shift, float* mean_o, float* invstd_o, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = stats[c] / (double)count;
+  double var = stats[C + c] / (double)count - mean * mean;
+  if (var < 0) var = 0;
+  float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  float meanf = (float)mean;
+  float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  mean_o[c] = meanf;
+  invstd_o[c] = invstd;
+  if (rmean) {
+    float unbiased = (float)(count > 1 ? var * (double)count / (double)(count - 1) : var);
+    float rm = rmean[c], rv = rvar[c];
+    for (int i = 0; i < n_updates; ++i) {
+      rm = (1.f - momentum) * rm + momentum * meanf;
+      rv = (1.f - momentum) * rv + momentum * unbiased;
+    }
+    rmean[c] = rm;
+    rvar[c] = rv;
+  }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  if (act == RAC_ACT_LEAKY02) return v > 0.f ? v : 0.2f * v;
+  if (act == RAC_ACT_SIGMOID) return sigmoid_acc(v);
+  return v;
+}
+
+__global__ void affine_act_kernel4(const f32x4* x, const f32x4* scale, const f32x4* shift, int act, f32x4* y, long n4,
+                                   int C4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C4);
+    f32x4 v = x[i], s = scale[c], t = shift[c], o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] * s[e] + t[e], act);
+    y[i] = o;
+  }
+}
+__global__ void affine_act_kernel1(const float* x, const float* scale, const float* shift, int act, float* y, long n,
+                                   int C) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    y[i] = act_apply(x[i] * scale[c] + shift[c], act);
+  }
+}
+
+// Per-channel reductions over M rows: block = 256 threads = (256/TC) row-lanes x TC channel-lanes,
+// TC = min(C,64) channels per block column group; partials combined through LDS then fp64 atomics.
+__global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, double* sums, long M, int C,
+                                     int rows_per_block) {
+  __shared__ float s1[256], s2[256];
+  const int TC = C < 64 ? C : 64;
+  const int RL = 256 / TC;
+  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, M);
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int c = c0 + cl;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C && rl < RL) {
+      const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+      for (long r = r_begin + rl; r < r_end; r += RL) {
+        float xv = x[r * C + c];
+        float z = xv * sc + sh;
+        float dz = dy[r * C + c] * (z > 0.f ? 1.f : 0.2f);
+        a1 += dz;
+        a2 += dz * ((xv - mu) * is);
+      }
+    }
+    s1[threadIdx.x] = a1;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < RL; ++k) {
+        t1 += s1[k * TC + threadIdx.x];
+        t2 += s2[k * TC + threadIdx.x];
+      }
+      atomicAdd(sums + c0 + threadIdx.x, (double)t1);
+      atomicAdd(sums + C + c0 + threadIdx.x, (double)t2);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float* scale, const float* shift,
+                                    const float* mean, const float* invstd, const double* sums, float* dx,
+                                    float* dgamma, float* dbeta, long M, int C) {
+  const long n = M * C;
+  const double invM = 1.0 / (double)M;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    float xv = x[i], sc = scale[c];
+    float z = xv * sc + shift[c];
+    float dz = dy[i] * (z > 0.f ? 1.f : 0.2f);
+    float xh = (xv - mean[c]) * invstd[c];
+    float m1 = (float)(sums[c] * invM), m2 = (float)(sums[C + c] * invM);
+    dx[i] = sc * (dz - m1 - xh * m2);
+  }
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dgamma[c] += (float)sums[C + c];
+      dbeta[c] += (float)sums[c];
+    }
+  }
+}
+
+// ------------------------------------------------------------ pool / upsample
+template <typename T>
+__global__ void maxpool2_fwd_kernel(const T* x, T* y, int B, int H, int W, int Cv) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = (long)B * Ho * Wo * Cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cv);
+    long q = i / Cv;
+    int xo = (int)(q % Wo);
+    long q2 = q / Wo;
+    int yo = (int)(q2 % Ho);
+    int b = (int)(q2 / Ho);
+    const T* p = x + (((long)b * H + 2 * yo) * W + 2 * xo) * Cv + c;
+    T v00 = p[0], v01 = p[Cv], v10 = p[(long)W * Cv], v11 = p[(long)W * Cv + Cv], o;
+    if constexpr (sizeof(T) == 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(fmaxf(v00[e], v01[e]), fmaxf(v10[e], v11[e]));
+    } else {
+      o = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+    }
+    y[i] = o;
+  }
+}
+
+// gradient goes to the first maximum in scan order (ATen max_pool2d_with_indices semantics)
+__global__ void maxpool2_bwd_kernel(const float* x, const float* dy, float* dx, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2;
+  const long n = (long)B * Ho * Wo * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long q = i / C;
+    int xo = (int)(q % Wo);
+    long q2 = q / Wo;
+    int yo = (int)(q2 % Ho);
+    int b = (int)(q2 / Ho);
+    long base = (((long)b * H + 2 * yo) * W + 2 * xo) * C + c;
+    long off[4] = {0, (long)C, (long)W * C, (long)W * C + C};
+    float best = x[base];
+    int arg = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      float v = x[base + off[k]];
+      if (v > best || (v != v && best == best)) {
+        best = v;
+        arg = k;
+      }
+    }
+    float g = dy[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dx[base + off[k]] = (k == arg) ? g : 0.f;
+  }
+}
+
+template <typename T>
+__global__ void upsample2_fwd_kernel(const T* x, T* y, int B, int h, int w, int Cv) {
+  const long n = (long)B * (2 * h) * (2 * w) * Cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cv);
+    long q = i / Cv;
+    int xo = (int)(q % (2 * w));
+    long q2 = q / (2 * w);
+    int yo = (int)(q2 % (2 * h));
+    int b = (int)(q2 / (2 * h));
+    y[i] = x[(((long)b * h + yo / 2) * w + xo / 2) * Cv + c];
+  }
+}
+template <typename T>
+__global__ void upsample2_bwd_kernel(const T* dy, T* dx, int B, int h, int w, int Cv) {
+  const long n = (long)B * h * w * Cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Cv);
+    long q = i / Cv;
+    int xi = (int)(q % w);
+    long q2 = q / w;
+    int yi = (int)(q2 % h);
+    int b = (int)(q2 / h);
+    const T* p = dy + (((long)b * 2 * h + 2 * yi) * (2 * w) + 2 * xi) * Cv + c;
+    dx[i] = (p[0] + p[Cv]) + (p[(long)2 * w * Cv] + p[(long)2 * w * Cv + Cv]);
+  }
+}
+
+// ------------------------------------------------------------ tiling / slices
+__global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1, const float* v2, int n2,
+                               const float* m0, int c0, const float* m1, int c1, float* out, int B, int HW) {
+  const int Ct = n0 + n1 + n2 + c0 + c1;
+  const long n = (long)B * HW * Ct;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    int c = (int)(i % Ct);
+    long q = i / Ct;  // b*HW + p
+    int b = (int)(q / HW);
+    float v;
+    if (c < n0)
+      v = v0[b * n0 + c];
+    else if (c < n0 + n1)
+      v = v1[b * n1 + (c - n0)];
+    else if (c < n0 + n1 + n2)
+      v = v2[b * n2 + (c - n0 - n1)];
+    else if (c < n0 + n1 + n2 + c0)
+      v = m0[q * c0 + (c - n0 - n1 - n2)];
+    else
+      v = m1[q * c1 + (c - n0 - n1 - n2 - c0)];
+    out[i] = v;
+  }
+}
+
+__global__ void slice_channels_kernel(const float* src, int Csrc, int off, int nc, float* dst, long M) {
+  const long n = M * nc;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / nc;
+    int c = (int)(i - m * nc);
+    dst[i] = src[m * Csrc + off + c];
+  }
+}
+
+__global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int rows_per_block) {
+  __shared__ float s1[256];
+  const int TC = C < 64 ? C : 64;
+  const int RL = 256 / TC;
+  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, M);
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int c = c0 + cl;
+    float a = 0.f;
+    if (c < C && rl < RL)
+      for (long r = r_begin + rl; r < r_end; r += RL) a += x[r * C + c];
+    s1[threadIdx.x] = a;
+    __syncthreads();
+    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
+      float t = 0.f;
+      for (int k = 0; k < RL; ++k) t += s1[k * TC + threadIdx.x];
+      atomicAdd(out + c0 + threadIdx.x, t);
+    }
+    __syncthreads();
+  }
+}
+
+
+__global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out,
+                                   long n, int N) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float a = bias ? bias[i % N] : 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + i];
+    out[i] = a;
+  }
+}
+
+__global__ void col_stats_kernel(const float* x, double* stats, long M, int C, int rows_per_block) {
+  __shared__ float s1[256], s2[256];
+  const int TC = C < 64 ? C : 64;
+  const int RL = 256 / TC;
+  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, M);
+  for (int c0 = 0; c0 < C; c0 += TC) {
+    const int c = c0 + cl;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C && rl < RL)
+      for (long r = r_begin + rl; r < r_end; r += RL) {
+        float v = x[r * C + c];
+        a1 += v;
+        a2 += v * v;
+      }
+    s1[threadIdx.x] = a1;
+    s2[threadIdx.x] = a2;
+    __syncthreads();
+    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
+      float t1 = 0.f, t2 = 0.f;
+      for (int k = 0; k < RL; ++k) {
+        t1 += s1[k * TC + threadIdx.x];
+        t2 += s2[k * TC + threadIdx.x];
+      }
+      atomicAdd(stats + c0 + threadIdx.x, (double)t1);
+      atomicAdd(stats + C + c0 + threadIdx.x, (double)t2);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void act_bwd_kernel(const float* dy, const float* y, int act, float* dx, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float yv = y[i], g = dy[i];
+    if (act == RAC_ACT_SIGMOID)
+      g *= yv * (1.f - yv);
+    else if (act == RAC_ACT_LEAKY02)
+      g *= (yv > 0.f ? 1.f : 0.2f);
+    dx[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------- ConvLSTM
+__global__ void lstm_cell_fwd_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias,
+                                     const float* c_prev, float* h_out, float* c_out, float* act_out, long M, int g) {
+  const long n = M * g;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / g;
+    int c = (int)(i - m * g);
+    const float* row = slabs + m * 4 * g + c;
+    float pi = bias[c], pf = bias[g + c], po = bias[2 * g + c], pg = bias[3 * g + c];
+    for (int s = 0; s < n_slabs; ++s) {
+      const float* r = row + s * slab_stride;
+      pi += r[0];
+      pf += r[g];
+      po += r[2 * g];
+      pg += r[3 * g];
+    }
+    float gi = sigmoid_acc(pi), gf = sigmoid_acc(pf), go = sigmoid_acc(po), gg = tanhf(pg);
+    float cn = gf * c_prev[i] + gi * gg;
+    c_out[i] = cn;
+    h_out[i] = go * tanhf(cn);
+    if (act_out) {
+      float* a = act_out + m * 4 * g + c;
+      a[0] = gi;
+      a[g] = gf;
+      a[2 * g] = go;
+      a[3 * g] = gg;
+    }
+  }
+}
+
+__global__ void lstm_cell_bwd_kernel(const float* dh, const float* dc_next, const float* act, const float* c_prev,
+                                     const float* c_new, float* dgates, float* dc_prev, long M, int g) {
+  const long n = M * g;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / g;
+    int c = (int)(i - m * g);
+    const float* a = act + m * 4 * g + c;
+    float gi = a[0], gf = a[g], go = a[2 * g], gg = a[3 * g];
+    float tc = tanhf(c_new[i]);
+    float dhv = dh ? dh[i] : 0.f;
+    float dc = dhv * go * (1.f - tc * tc) + (dc_next ? dc_next[i] : 0.f);
+    float* d = dgates + m * 4 * g + c;
+    d[0] = dc * gg * gi * (1.f - gi);
+    d[g] = dc * c_prev[i] * gf * (1.f - gf);
+    d[2 * g] = dhv * tc * go * (1.f - go);
+    d[3 * g] = dc * gi * (1.f - gg * gg);
+    dc_prev[i] = dc * gf;
+  }
+}
+
+__global__ void reparam_fwd_kernel(const float* mu, const float* lv, const float* eps, float* z, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    z[i] = eps[i] * expf(0.5f * lv[i]) + mu[i];
+}
+__global__ void reparam_bwd_kernel(const float* dz, const float* lv, const float* eps, float* dlv, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    dlv[i] = dz[i] * eps[i] * (0.5f * expf(0.5f * lv[i]));
+}
+
+// ----------------------------------------------------------------------- Adam
+__global__ void adam_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v, long n4, float* pt, const float* gt,
+                            float* mt, float* vt, int tail, float b1, float b2, float eps, float step_size,
+                            float inv_sqrt_bc2) {
+  auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+    mm = b1 * mm + (1.f - b1) * gg;
+    vv = b2 * vv + (1.f - b2) * gg * gg;
+    float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+    pp -= step_size * (mm / denom);
+  };
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 P = p[i], G = g[i], Mv = m[i], V = v[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float pe = P[e], me = Mv[e], ve = V[e];
+      upd(pe, G[e], me, ve);
+      P[e] = pe, Mv[e] = me, V[e] = ve;
+    }
+    p[i] = P;
+    m[i] = Mv;
+    v[i] = V;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < tail) upd(pt[threadIdx.x], gt[threadIdx.x], mt[threadIdx.x], vt[threadIdx.x]);
+}
+
+}  // namespace rac
+
+using namespace rac;
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+extern "C" {
+
+int rac_version(void) { return RAC_ABI_VERSION; }
+const char* rac_device_arch(void) { return "gfx950"; }
+const char* rac_last_error(void) { return g_err; }
+
+int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int32_t n_updates, float* scale, float* shift,
+                    float* mean, float* invstd, int32_t C, void* stream) {
+  RAC_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0,
+              "rac_bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), stats, (long)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, n_updates, scale, shift, mean, invstd, C);
+  return check_launch("rac_bn_finalize");
+}
+
+int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
+                   int32_t C, void* stream) {
+  RAC_REQUIRE(x && scale && shift && y && M > 0 && C > 0, "rac_affine_act: bad args");
+  long n = (long)M * C;
+  if (C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift)) {
+    hipLaunchKernelGGL(affine_act_kernel4, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)x,
+                       (const f32x4*)scale, (const f32x4*)shift, act, (f32x4*)y, n / 4, C / 4);
+  } else {
+    hipLaunchKernelGGL(affine_act_kernel1, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, scale, shift, act, y, n, C);
+  }
+  return check_launch("rac_affine_act");
+}
+
+static int rows_per_block_for(long M, int* nblocks) {
+  long nb = M / 64;
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  int rpb = (int)((M + nb - 1) / nb);
+  *nblocks = (int)((M + rpb - 1) / rpb);
+  return rpb;
+}
+
+int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                      const float* invstd, double* sums, int64_t M, int32_t C, void* stream) {
+  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0, "rac_bn_bwd_reduce: bad args");
+  int nb;
+  int rpb = rows_per_block_for(M, &nb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), dy, x, scale, shift, mean, invstd, sums,
+                     (long)M, C, rpb);
+  return check_launch("rac_bn_bwd_reduce");
+}
+
+int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
+                     int32_t C, void* stream) {
+  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && M > 0 && C > 0, "rac_bn_bwd_apply: bad args");
+  RAC_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rac_bn_bwd_apply: dgamma/dbeta must come together");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, ST(stream), dy, x, scale, shift,
+                     mean, invstd, sums, dx, dgamma, dbeta, (long)M, C);
+  return check_launch("rac_bn_bwd_apply");
+}
+
+int rac_maxpool2_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  RAC_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, "rac_maxpool2_fwd: bad args");
+  long n = (long)B * (H / 2) * (W / 2) * C;
+  if (C % 4 == 0 && aligned16(x) && aligned16(y))
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<f32x4>, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)x,
+                       (f32x4*)y, B, H, W, C / 4);
+  else
+    hipLaunchKernelGGL(maxpool2_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, y, B, H, W, C);
+  return check_launch("rac_maxpool2_fwd");
+}
+
+int rac_maxpool2_bwd(const float* x, const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C,
+                     void* stream) {
+  RAC_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0,
+              "rac_maxpool2_bwd: bad args");
+  long n = (long)B * (H / 2) * (W / 2) * C;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, dy, dx, B, H, W, C);
+  return check_launch("rac_maxpool2_bwd");
+}
+
+int rac_upsample2_fwd(const float* x, float* y, int32_t B, int32_t h, int32_t w, int32_t C, void* stream) {
+  RAC_REQUIRE(x && y && B > 0 && h > 0 && w > 0 && C > 0, "rac_upsample2_fwd: bad args");
+  long n = (long)B * 4 * h * w * C;
+  if (C % 4 == 0 && aligned16(x) && aligned16(y))
+    hipLaunchKernelGGL(upsample2_fwd_kernel<f32x4>, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)x,
+                       (f32x4*)y, B, h, w, C / 4);
+  else
+    hipLaunchKernelGGL(upsample2_fwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, y, B, h, w, C);
+  return check_launch("rac_upsample2_fwd");
+}
+
+int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t w, int32_t C, void* stream) {
+  RAC_REQUIRE(dy && dx && B > 0 && h > 0 && w > 0 && C > 0, "rac_upsample2_bwd: bad args");
+  long n = (long)B * h * w * C;
+  if (C % 4 == 0 && aligned16(dy) && aligned16(dx))
+    hipLaunchKernelGGL(upsample2_bwd_kernel<f32x4>, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)dy,
+                       (f32x4*)dx, B, h, w, C / 4);
+  else
+    hipLaunchKernelGGL(upsample2_bwd_kernel<float>, dim3(grid_for(n)), dim3(256), 0, ST(stream), dy, dx, B, h, w, C);
+  return check_launch("rac_upsample2_bwd");
+}
+
+int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
+                    const float* m0, int32_t c0, const float* m1, int32_t c1, float* out, int32_t B, int32_t HW,
+                    void* stream) {
+  RAC_REQUIRE(out && B > 0 && HW > 0, "rac_tilecat_fwd: bad args");
+  RAC_REQUIRE((n0 == 0 || v0) && (n1 == 0 || v1) && (n2 == 0 || v2) && (c0 == 0 || m0) && (c1 == 0 || m1),
+              "rac_tilecat_fwd: null source with non-zero width");
+  long n = (long)B * HW * (n0 + n1 + n2 + c0 + c1);
+  RAC_REQUIRE(n > 0, "rac_tilecat_fwd: empty");
+  hipLaunchKernelGGL(tilecat_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1,
+                     c1, out, B, HW);
+  return check_launch("rac_tilecat_fwd");
+}
+
+int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, float* dst, int64_t M, void* stream) {
+  RAC_REQUIRE(src && dst && M > 0 && nc > 0 && off >= 0 && off + nc <= Csrc, "rac_slice_channels: bad args");
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for((long)M * nc)), dim3(256), 0, ST(stream), src, Csrc, off, nc,
+                     dst, (long)M);
+  return check_launch("rac_slice_channels");
+}
+
+int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
+  RAC_REQUIRE(x && out && M > 0 && C > 0, "rac_colsum_acc: bad args");
+  int nb;
+  int rpb = rows_per_block_for(M, &nb);
+  hipLaunchKernelGGL(colsum_acc_kernel, dim3(nb), dim3(256), 0, ST(stream), x, out, (long)M, C, rpb);
+  return check_launch("rac_colsum_acc");
+}
+
+int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
+                    int64_t n, int32_t N, void* stream) {
+  RAC_REQUIRE(slabs && out && n_slabs >= 1 && n > 0 && N > 0, "rac_slab_reduce: bad args");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), slabs, n_slabs,
+                     (long)slab_stride, bias, out, (long)n, N);
+  return check_launch("rac_slab_reduce");
+}
+
+int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream) {
+  RAC_REQUIRE(x && stats && M > 0 && C > 0, "rac_col_stats: bad args");
+  int nb;
+  int rpb = rows_per_block_for(M, &nb);
+  hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(256), 0, ST(stream), x, stats, (long)M, C, rpb);
+  return check_launch("rac_col_stats");
+}
+
+int rac_act_bwd(const float* dy, const float* y, int32_t act, float* dx, int64_t n, void* stream) {
+  RAC_REQUIRE(dy && y && dx && n > 0, "rac_act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dy, y, act, dx, (long)n);
+  return check_launch("rac_act_bwd");
+}
+
+int rac_lstm_cell_fwd(const float* gate_slabs, int32_t n_slabs, int64_t slab_stride, const float* bias,
+                      const float* c_prev, float* h_out, float* c_out, float* act_out, int64_t M, int32_t g,
+                      void* stream) {
+  RAC_REQUIRE(gate_slabs && bias && c_prev && h_out && c_out && M > 0 && g > 0 && n_slabs >= 1,
+              "rac_lstm_cell_fwd: bad args");
+  hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), gate_slabs, n_slabs,
+                     (long)slab_stride, bias, c_prev, h_out, c_out, act_out, (long)M, g);
+  return check_launch("rac_lstm_cell_fwd");
+}
+
+int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev,
+                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, void* stream) {
+  RAC_REQUIRE(act && c_prev && c_new && dgates && dc_prev && M > 0 && g > 0, "rac_lstm_cell_bwd: bad args");
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), dh, dc_next, act,
+                     c_prev, c_new, dgates, dc_prev, (long)M, g);
+  return check_launch("rac_lstm_cell_bwd");
+}
+
+int rac_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream) {
+  RAC_REQUIRE(mu && logvar && eps && z && n > 0, "rac_reparam_fwd: bad args");
+  hipLaunchKernelGGL(reparam_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), mu, logvar, eps, z, (long)n);
+  return check_launch("rac_reparam_fwd");
+}
+int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, int64_t n, void* stream) {
+  RAC_REQUIRE(dz && logvar && eps && dlogvar && n > 0, "rac_reparam_bwd: bad args");
+  hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dz, logvar, eps, dlogvar,
+                     (long)n);
+  return check_launch("rac_reparam_bwd");
+}
+
+int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int32_t step, void* stream) {
+  RAC_REQUIRE(p && g && m && v && n > 0 && step >= 1, "rac_adam_step: bad args");
+  RAC_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "rac_adam_step: buffers must be 16-B aligned");
+  double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  float step_size = (float)((double)lr / bc1);
+  float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  long n4 = n / 4;
+  int tail = (int)(n - n4 * 4);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, ST(stream), (f32x4*)p,
+                     (const f32x4*)g, (f32x4*)m, (f32x4*)v, n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail,
+                     beta1, beta2, eps, step_size, inv_sqrt_bc2);
+  return check_launch("rac_adam_step");
+}
+
+}  // extern "C"

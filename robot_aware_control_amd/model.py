@@ -1,0 +1,366 @@
+"""SVGConvModel on librac_hip.so -- drop-in for the reference
+`src.prediction.models.dynamics.SVGConvModel` (reference dynamics.py:457-644):
+same constructor (`SVGConvModel(config)`), `init_hidden`, 12-argument `forward`,
+and `state_dict()` keys / shapes, so reference checkpoints load unchanged.
+
+Differences that are deliberate and invisible to callers:
+  * feature maps live in HBM as NHWC; tensors handed back to the caller are
+    logical NCHW views of them (channels_last strides);
+  * all parameters are views into ONE flat fp32 buffer (and their gradients into
+    another): the fused Adam step and the DDP all-reduce work on flat memory;
+    conv weights are stored [Cout][k][k][Cin];
+  * in a train step the reference encodes the *current* frame twice
+    (dynamics.py:584 and :619 -- the posterior never sees the next frame).  Both
+    passes produce identical activations, so the encoder runs once; BatchNorm
+    running stats receive the two momentum updates and the gradient of both uses
+    of `h` flows through the single pass.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE
+
+ENC_PLAN = (("c1", (None, 64, 64)), ("c2", (64, 128, 128)), ("c3", (128, 256, 256, 256)),
+            ("c4", (256, 512, 512, None)))
+DEC_PLAN = (("upc2", (None, 512, 512, 256)), ("upc3", (512, 256, 256, 128)), ("upc4", (256, 128, 64)),
+            ("upc5", (128, 64)))
+
+
+def _cl_weight(cout: int, cin: int, k: int) -> nn.Parameter:
+    """(cout, cin, k, k) parameter with [cout][k][k][cin] memory."""
+    mem = torch.empty(cout, k, k, cin)
+    return nn.Parameter(mem.permute(0, 3, 1, 2))
+
+
+class _Conv(nn.Module):
+    """Parameter holder named like nn.Conv2d / nn.ConvTranspose2d (`weight`, `bias`)."""
+
+    def __init__(self, cin, cout, k, bias=True, transposed=False):
+        super().__init__()
+        self.ksize = k
+        # ConvTranspose2d stores (cin, cout, k, k)
+        self.weight = _cl_weight(cin, cout, k) if transposed else _cl_weight(cout, cin, k)
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+
+
+class _BatchNorm(nn.Module):
+    """Holder with nn.BatchNorm2d's parameter / buffer names."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.empty(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.zeros((), dtype=torch.long))
+        self.pending_updates = 0  # folded into num_batches_tracked lazily (state_dict time)
+
+
+class _VggLayer(nn.Module):
+    """vgg_layer (vgg_64.py:8-18): `main.0` conv (no bias), `main.1` batch norm; LeakyReLU has no state."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.main = nn.ModuleList([_Conv(cin, cout, 3, bias=False), _BatchNorm(cout)])
+        self._folded = None
+
+    def forward(self, x0, x1=None, n_updates=1):
+        conv, bn = self.main[0], self.main[1]
+        if self.training:
+            bn.pending_updates += n_updates
+            folded = None
+        else:
+            if self._folded is None:  # eval: BatchNorm folded into the conv epilogue
+                with torch.no_grad():
+                    scale = bn.weight / torch.sqrt(bn.running_var + ops.BN_EPS)
+                    self._folded = (scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+            folded = self._folded
+        return ops.VggLayer.apply(x0, x1, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                  self.training, n_updates, folded)
+
+
+class _Encoder(nn.Module):
+    """ConvEncoder (vgg_64.py:87-129)."""
+
+    def __init__(self, dim, nc):
+        super().__init__()
+        for name, chans in ENC_PLAN:
+            chans = [nc if (c is None and i == 0) else (dim if c is None else c) for i, c in enumerate(chans)]
+            setattr(self, name, nn.ModuleList([_VggLayer(chans[i], chans[i + 1]) for i in range(len(chans) - 1)]))
+
+    def forward(self, x, n_updates=1):
+        skips = []
+        for i, name in enumerate(("c1", "c2", "c3", "c4")):
+            if i:
+                x = ops.MaxPool2.apply(x)
+            for layer in getattr(self, name):
+                x = layer(x, None, n_updates)
+            skips.append(x)
+        return x, skips
+
+
+class _Decoder(nn.Module):
+    """ConvDecoder (vgg_64.py:196-241); the skip concat is virtual (second conv source)."""
+
+    def __init__(self, dim, nc):
+        super().__init__()
+        for name, chans in DEC_PLAN[:-1]:
+            chans = [dim if c is None else c for c in chans]
+            setattr(self, name, nn.ModuleList([_VggLayer(chans[i], chans[i + 1]) for i in range(len(chans) - 1)]))
+        self.upc5 = nn.ModuleList([_VggLayer(128, 64), _Conv(64, nc, 3, bias=True, transposed=True)])
+
+    def forward(self, vec, skip):
+        d = vec
+        for layer in self.upc2:
+            d = layer(d)
+        for name, sk in (("upc3", skip[2]), ("upc4", skip[1])):
+            up = ops.Upsample2.apply(d)
+            layers = getattr(self, name)
+            d = layers[0](up, sk)
+            for layer in list(layers)[1:]:
+                d = layer(d)
+        up = ops.Upsample2.apply(d)
+        d = self.upc5[0](up, skip[0])
+        head = self.upc5[1]
+        return ops.ConvTHead.apply(d, head.weight, head.bias)
+
+
+class _LstmCell(nn.Module):
+    def __init__(self, g, k):
+        super().__init__()
+        self.gates = _Conv(2 * g, 4 * g, k)
+
+
+class _ConvLSTM(nn.Module):
+    """ConvLSTM (lstm.py:201-257): layer 0 is 5x5, layer 1 is 3x3; state lives in `self.hidden`."""
+
+    def __init__(self, config, g):
+        super().__init__()
+        if getattr(config, "lstm_group_norm", False):
+            raise NotImplementedError("--lstm_group_norm True (NormConvLSTMCell, lstm.py:151-198) is not built yet")
+        self.hid_ch = g
+        self.lstm = nn.ModuleList([_LstmCell(g, 5), _LstmCell(g, 3)])
+        self.batch_size = config.batch_size
+        self._hw = (config.image_height // 8, config.image_width // 8)
+        self.hidden = None
+
+    def init_hidden(self, batch_size=None):
+        b = self.batch_size if batch_size is None else batch_size
+        dev = self.lstm[0].gates.weight.device
+        h, w = self._hw
+        return [(torch.zeros(b, h, w, self.hid_ch, device=dev), torch.zeros(b, h, w, self.hid_ch, device=dev))
+                for _ in self.lstm]
+
+    def forward(self, x):
+        for i, cell in enumerate(self.lstm):
+            h_prev, c_prev = self.hidden[i]
+            self.hidden[i] = ops.LstmCell.apply(x, h_prev, c_prev, cell.gates.weight, cell.gates.bias)
+            x = self.hidden[i][0]
+        return x
+
+
+class _GaussianConvLSTM(_ConvLSTM):
+    """GaussianConvLSTM (lstm.py:260-286)."""
+
+    def __init__(self, config, g, z):
+        super().__init__(config, g)
+        self.mu_net = _Conv(g, z, 3)
+        self.logvar_net = _Conv(g, z, 3)
+
+    def forward(self, x, eps_fn, need_z=True):
+        h = super().forward(x)
+        mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE)
+        logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE)
+        z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
+        return z, mu, logvar
+
+
+class SVGConvModel(nn.Module):
+    """Conv SVG LSTM predictor (reference dynamics.py:457-644) on hand-written gfx950 kernels."""
+
+    def __init__(self, config):
+        super().__init__()
+        self._config = cf = config
+        self._device = config.device
+        self._image_width = cf.image_width
+        self._image_height = cf.image_height
+        self.eps_source = None  # optional callable(shape_bzhw) -> N(0,1) tensor; tests inject the reference's draws
+        self._flat = self._flat_grad = None
+        if cf.image_width not in (64, 128):  # dynamics.py:470-473
+            raise ValueError
+        enc_c = cf.channels
+        if cf.model_use_mask:
+            enc_c += 1 + (1 if cf.model_use_future_mask else 0)
+        if getattr(cf, "model_use_heatmap", False):
+            enc_c += 1 + (1 if getattr(cf, "model_use_future_heatmap", False) else 0)
+        g, z, A, R = cf.g_dim, cf.z_dim, cf.action_dim, cf.robot_dim
+        use_r, use_rn = cf.model_use_robot_state, cf.model_use_future_robot_state
+        extra = (R if use_r else 0) + (R if use_rn else 0)
+        self.encoder = _Encoder(g, enc_c)
+        self.frame_pred_input_conv = _Conv(g + A + z + extra, g, 3)
+        self.frame_predictor = _ConvLSTM(cf, g)
+        self.posterior_input_conv = _Conv(g + (R if use_r else 0), g, 3)
+        self.prior_input_conv = _Conv(g + A + extra, g, 3)
+        self.posterior = _GaussianConvLSTM(cf, g, z)
+        self.prior = _GaussianConvLSTM(cf, g, z)
+        self.decoder = _Decoder(g, cf.channels + 1)
+        self.reset_parameters()
+        self.to(self._device)
+
+    # ------------------------------------------------------------------ params
+    def reset_parameters(self):
+        """init_weights (base.py:26-36): conv W ~ N(0, 0.02), b = 0; BatchNorm gamma ~ N(1, 0.02), beta = 0."""
+        with torch.no_grad():
+            for m in self.modules():
+                if isinstance(m, _Conv):
+                    m.weight.normal_(0.0, 0.02)
+                    if m.bias is not None:
+                        m.bias.zero_()
+                elif isinstance(m, _BatchNorm):
+                    m.weight.normal_(1.0, 0.02)
+                    m.bias.zero_()
+
+    def _flatten(self):
+        """Re-home every parameter as a view of one flat buffer (and .grad of another)."""
+        params = list(self.parameters())
+        if not params:
+            return
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = torch.as_strided(flat, p.shape, p.stride(), o)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = torch.as_strided(grad, p.shape, p.stride(), o)
+        self._flat, self._flat_grad = flat, grad
+        for m in self.modules():
+            if isinstance(m, _VggLayer):
+                m._folded = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def flat_parameters(self):
+        return self._flat, self._flat_grad
+
+    def zero_grad(self, set_to_none: bool = False):
+        """Gradients are accumulated in place by the kernels: zero the flat buffer, keep the views attached."""
+        if self._flat_grad is None:
+            self._flatten()
+        self._flat_grad.zero_()
+        off = 0
+        for p in self.parameters():
+            if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
+                p.grad = torch.as_strided(self._flat_grad, p.shape, p.stride(), off)
+            off += (p.numel() + 3) // 4 * 4
+
+    def train(self, mode: bool = True):
+        for m in self.modules():
+            if isinstance(m, _VggLayer):
+                m._folded = None
+        return super().train(mode)
+
+    def _flush_bn_counters(self):
+        for m in self.modules():
+            if isinstance(m, _BatchNorm) and m.pending_updates:
+                m.num_batches_tracked += m.pending_updates
+                m.pending_updates = 0
+
+    def state_dict(self, *a, **k):
+        self._flush_bn_counters()
+        sd = super().state_dict(*a, **k)
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, **k):
+        out = super().load_state_dict(state_dict, strict=strict, **k)
+        for m in self.modules():
+            if isinstance(m, _VggLayer):
+                m._folded = None
+            if isinstance(m, _BatchNorm):
+                m.pending_updates = 0
+        return out
+
+    # ------------------------------------------------------------------ state
+    def init_hidden(self, batch_size=None):
+        """Initialize the recurrent states by batch size (dynamics.py:536-542)."""
+        self.frame_predictor.hidden = self.frame_predictor.init_hidden(batch_size)
+        self.posterior.hidden = self.posterior.init_hidden(batch_size)
+        self.prior.hidden = self.prior.init_hidden(batch_size)
+
+    def _eps(self, like_map: torch.Tensor) -> torch.Tensor:
+        b, h, w, z = like_map.shape
+        if self.eps_source is not None:
+            e = self.eps_source((b, z, h, w)).to(like_map.device, torch.float32)
+            return e.permute(0, 2, 3, 1).contiguous()
+        return torch.randn(b, h, w, z, device=like_map.device)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, image, mask, robot, heatmap, action, next_image=None, next_mask=None, next_robot=None,
+                next_heatmap=None, skip=None, force_use_prior=False, sample_mean=False):
+        """Predict the next frame (same contract as reference dynamics.py:544-644).
+
+        Returns (x_pred (B,4,H,W) in [0,1], skip list, mu, logvar, mu_p, logvar_p); mu/logvar are None
+        when `next_image` is None."""
+        x4, skip_maps, mu, logvar, mu_p, logvar_p = self.forward_maps(
+            image, mask, robot, heatmap, action, next_image is not None, next_robot,
+            None if skip is None else [s.permute(0, 2, 3, 1).contiguous() for s in skip],
+            force_use_prior, sample_mean)
+        v = ops.to_planes_view
+        return (v(x4), [v(s) for s in skip_maps], None if mu is None else v(mu),
+                None if logvar is None else v(logvar), v(mu_p), v(logvar_p))
+
+    def forward_maps(self, image, mask, robot, heatmap, action, posterior: bool, next_robot=None, skip=None,
+                     force_use_prior=False, sample_mean=False, zero_mask=None):
+        """`forward` on NHWC maps (no layout conversion of the results).  `zero_mask` fuses
+        zero_robot_region(mask, image) (src/utils/image.py:5-19) into the input packing."""
+        cf = self._config
+        image = image.contiguous()
+        mask_planes = None
+        if getattr(cf, "model_use_heatmap", False):
+            mask_planes = heatmap
+        if cf.model_use_mask:
+            mask_planes = mask if mask_planes is None else torch.cat([mask_planes, mask], 1)
+        if mask_planes is not None:
+            mask_planes = mask_planes.contiguous()
+        x_in = ops.PackInput.apply(image, zero_mask, mask_planes)
+        h, curr_skip = self.encoder(x_in, 2 if posterior else 1)
+        if cf.last_frame_skip or skip is None:
+            skip = curr_skip
+        a = action.contiguous()
+        r = r_next = None
+        if cf.model_use_robot_state:
+            if cf.model_use_future_robot_state:
+                r, r_next = robot
+                r, r_next = r.contiguous(), r_next.contiguous()
+            else:
+                r = robot.contiguous()
+        p = self.prior_input_conv
+        prior_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, None), None, p.weight, p.bias, ACT_NONE)
+        z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean)
+        z = mu_p if sample_mean else z_p
+        mu = logvar = None
+        if posterior:
+            q = self.posterior_input_conv
+            post_x = ops.TileCat.apply(next_robot.contiguous(), None, None, h, None) if cf.model_use_robot_state else h
+            post_in = ops.ConvBias.apply(post_x, None, q.weight, q.bias, ACT_NONE)
+            z_t, mu, logvar = self.posterior(post_in, self._eps)
+            if not force_use_prior:
+                z = z_t
+        f = self.frame_pred_input_conv
+        frame_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, z), None, f.weight, f.bias, ACT_NONE)
+        h_pred = self.frame_predictor(frame_in)
+        x4 = self.decoder(h_pred, skip)
+        return x4, skip, mu, logvar, mu_p, logvar_p

@@ -1,0 +1,524 @@
+"""Host-side operators over the C ABI: thin launch wrappers plus the
+`torch.autograd.Function`s that give the SVG model its backward pass.
+
+PyTorch is used for device memory (`torch.empty`), streams and the autograd tape;
+every arithmetic op on the hot path is a HIP kernel of librac_hip.so.
+
+Layouts: feature maps are contiguous (B, H, W, C) tensors ("maps", NHWC);
+frames at the model boundary are contiguous (B, C, H, W) tensors ("planes");
+conv weights are logical (Cout, Cin, k, k) parameters whose MEMORY is
+[Cout][k][k][Cin] (channels_last strides).
+
+Weight / bias / BatchNorm-affine gradients are accumulated by the kernels
+straight into `param.grad` (the model keeps one flat gradient buffer, zeroed by
+`zero_grad()`), so the corresponding autograd outputs are None: BPTT over the
+time steps then costs no extra read-modify-write passes over the 954 MB of
+weights.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvArgs, call, ptr, stream_ptr
+
+FWD, DGRAD, WGRAD = 0, 1, 2
+ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
+LOSS_KINDS = {"mse": 0, "l1": 1, "dontcare_mse": 2, "dontcare_l1": 3}
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+def _require_cuda(t: torch.Tensor):
+    if not t.is_cuda:
+        raise _lib.RacError("robot_aware_control_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+
+
+def weight_mem(w: torch.Tensor) -> torch.Tensor:
+    """Check that a (Cout,Cin,k,k) weight is stored [Cout][k][k][Cin]."""
+    co, ci, kh, kw = w.shape
+    if w.stride() != (kh * kw * ci, 1, kw * ci, ci):
+        raise _lib.RacError(f"conv weight {tuple(w.shape)} must use channels_last memory, strides {w.stride()}")
+    return w
+
+
+def grad_buffer(p: torch.Tensor) -> torch.Tensor:
+    """`p.grad`, allocated (zeroed, same strides) on first use."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)  # preserve_format keeps the channels_last strides
+    return p.grad
+
+
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
+def plan_split_k(M: int, N: int, nchunks: int) -> int:
+    """How many K-splits a FWD/DGRAD launch should use so that >= ~2 workgroups land on each of the 256 CUs."""
+    if N <= 32:
+        tiles = _cdiv(M, 128)
+    elif M >= 128 and N >= 128 and _cdiv(M, 128) * _cdiv(N, 128) >= 192:
+        tiles = _cdiv(M, 128) * _cdiv(N, 128)
+    else:
+        tiles = _cdiv(M, 64) * _cdiv(N, 64)
+    if tiles >= 384:
+        return 1
+    return max(1, min(8, _cdiv(512, tiles), nchunks // 8))
+
+
+# --------------------------------------------------------------------------- #
+# raw launches
+# --------------------------------------------------------------------------- #
+def conv_raw(mode: int, a0, a1, w, out0, out1=None, *, B, H, W, ksize, Cin, Cout, act=ACT_NONE, split_k=1,
+             slab_stride=0, accumulate=0, a_split=0, o_split=0, bias=None, scale=None, shift=None, stats=None):
+    args = ConvArgs(mode=mode, B=B, H=H, W=W, ksize=ksize, Cin=Cin, Cout=Cout, act=act, split_k=split_k,
+                    accumulate=accumulate, a_split=a_split, o_split=o_split, slab_stride=slab_stride,
+                    a0=ptr(a0), a1=ptr(a1), w=ptr(w), out0=ptr(out0), out1=ptr(out1), bias=ptr(bias),
+                    scale=ptr(scale), shift=ptr(shift), stats=ptr(stats))
+    call("rac_conv2d", C.byref(args), stream_ptr())
+
+
+def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
+                 allow_split=True, want_slabs=False):
+    """FWD conv over the virtual concat [x0 | x1].  Returns the (B,H,W,Cout) map, or
+    (slabs, n_slabs, slab_stride) when `want_slabs` (raw partial sums, no bias/epilogue)."""
+    _require_cuda(x0)
+    B, H, W, C0 = x0.shape
+    C1 = x1.shape[3] if x1 is not None else 0
+    Cout, Cin, k, _ = weight.shape
+    assert Cin == C0 + C1, (Cin, C0, C1)
+    weight_mem(weight)
+    M = B * H * W
+    nchunks = k * k * _cdiv(Cin, 32)
+    fused = act != ACT_NONE or scale is not None
+    split = plan_split_k(M, Cout, nchunks) if (allow_split and not fused) else 1
+    if want_slabs:
+        slabs = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
+        if split == 1:
+            conv_raw(FWD, x0, x1, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0)
+        else:
+            conv_raw(FWD, x0, x1, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0,
+                     split_k=split, slab_stride=M * Cout)
+        return slabs, split, M * Cout
+    out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
+    if split == 1:
+        conv_raw(FWD, x0, x1, weight, out, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, act=act,
+                 bias=bias, scale=scale, shift=shift, stats=stats)
+    else:
+        slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
+        conv_raw(FWD, x0, x1, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0,
+                 split_k=split, slab_stride=M * Cout)
+        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
+        if stats is not None:
+            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, stream_ptr())
+    return out
+
+
+def conv_dgrad(dy, weight, C0: int, C1: int = 0, transposed_head: bool = False):
+    """Data gradient of a conv whose input was the concat of C0 + C1 channels: returns (dx0, dx1|None)."""
+    B, H, W, Cout = dy.shape
+    Co, Cin, k, _ = weight.shape
+    assert Co == Cout and Cin == C0 + C1
+    M = B * H * W
+    nchunks = k * k * _cdiv(Cout, 32)
+    dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
+    dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32) if C1 else None
+    split = plan_split_k(M, Cin, nchunks) if C1 == 0 else 1
+    if split > 1:
+        slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
+        conv_raw(DGRAD, dy, None, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, split_k=split,
+                 slab_stride=M * Cin)
+        call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
+    else:
+        conv_raw(DGRAD, dy, None, weight, dx0, dx1, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout,
+                 o_split=C0 if C1 else 0)
+    return dx0, dx1
+
+
+def conv_wgrad_acc(dy, x0, x1, weight):
+    """weight.grad += dW  (x = virtual concat [x0 | x1]); split-K chosen by the library."""
+    B, H, W, Cout = dy.shape
+    Co, Cin, k, _ = weight.shape
+    C0 = x0.shape[3]
+    g = grad_buffer(weight)
+    weight_mem(g)
+    conv_raw(WGRAD, x0, x1, dy, g, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, accumulate=1, split_k=0)
+
+
+def bias_grad_acc(dy, bias):
+    M = dy.numel() // dy.shape[-1]
+    call("rac_colsum_acc", ptr(dy), ptr(grad_buffer(bias)), M, dy.shape[-1], stream_ptr())
+
+
+# --------------------------------------------------------------------------- #
+# autograd functions
+# --------------------------------------------------------------------------- #
+class ConvBias(torch.autograd.Function):
+    """Conv(k x k, same) + bias over [x0 | x1]; optional sigmoid epilogue.  (nn.Conv2d with bias:
+    reference dynamics.py:496-513, lstm.py:273-274.)"""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, bias, act):
+        y = conv_forward(x0, x1, weight, bias, act=act, allow_split=(act == ACT_NONE))
+        ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight, bias, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act != ACT_NONE:
+            d = torch.empty_like(dy)
+            call("rac_act_bwd", ptr(dy), ptr(y), ctx.act, ptr(d), dy.numel(), stream_ptr())
+            dy = d
+        C0 = x0.shape[3]
+        C1 = x1.shape[3] if x1 is not None else 0
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            dx0, dx1 = conv_dgrad(dy, weight, C0, C1)
+        if weight.requires_grad:
+            conv_wgrad_acc(dy, x0, x1, weight)
+        if bias is not None and bias.requires_grad:
+            bias_grad_acc(dy, bias)
+        return dx0, dx1, None, None, None
+
+
+class ConvTHead(torch.autograd.Function):
+    """ConvTranspose2d(Cin_w -> Cout_w, 3, 1, 1) + bias + Sigmoid (vgg_64.py:218-220).
+    weight is the ConvTranspose parameter (Cin_w, Cout_w, 3, 3); its forward is the DGRAD form."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, H, W, Ci = x.shape
+        Ciw, Cow, k, _ = weight.shape
+        assert Ci == Ciw
+        weight_mem(weight)
+        y = torch.empty((B, H, W, Cow), device=x.device, dtype=torch.float32)
+        conv_raw(DGRAD, x, None, weight, y, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, act=ACT_SIGMOID, bias=bias)
+        ctx.save_for_backward(x, weight, bias, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, bias, y = ctx.saved_tensors
+        B, H, W, Cow = y.shape
+        Ciw, _, k, _ = weight.shape
+        d = torch.empty_like(y)
+        call("rac_act_bwd", ptr(dy.contiguous()), ptr(y), ACT_SIGMOID, ptr(d), y.numel(), stream_ptr())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dx[ci] = sum_{tap,co} d[p+tap][co] * w[ci][tap][co]  -> FWD form with "Cout"=Ciw, "Cin"=Cow
+            conv_raw(FWD, d, None, weight, dx, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow)
+        if weight.requires_grad:
+            g = grad_buffer(weight)
+            # dw[ci][tap][co] += sum_p x[p][ci] * d[p+tap][co]  -> WGRAD with dy:=x, x:=d
+            conv_raw(WGRAD, d, None, x, g, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow, accumulate=1,
+                     split_k=0)
+        if bias.requires_grad:
+            bias_grad_acc(d, bias)
+        return dx, None, None
+
+
+class VggLayer(torch.autograd.Function):
+    """Conv3x3(no bias) -> BatchNorm2d -> LeakyReLU(0.2) over [x0 | x1]  (vgg_64.py:8-18).
+
+    training: batch statistics reduced in fp64 inside the conv epilogue; running stats get
+    `n_updates` momentum updates (the reference runs the encoder twice per step on the same frame).
+    eval: BatchNorm folded into the conv epilogue (`folded` = (scale, shift))."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, weight, gamma, beta, rmean, rvar, training, n_updates, folded):
+        Cout = weight.shape[0]
+        if not training:
+            scale, shift = folded
+            y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
+            ctx.mark_non_differentiable(y)  # frozen-model path (CEM / eval): no backward through folded BatchNorm
+            return y
+        dev = x0.device
+        stats = torch.zeros((2, Cout), device=dev, dtype=torch.float64)
+        raw = conv_forward(x0, x1, weight, None, stats=stats)
+        M = raw.numel() // Cout
+        aff = torch.empty((4, Cout), device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
+        call("rac_bn_finalize", ptr(stats), M, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
+             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, stream_ptr())
+        y = torch.empty_like(raw)
+        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, stream_ptr())
+        ctx.save_for_backward(x0, x1, weight, gamma, beta, raw, aff)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x0, x1, weight, gamma, beta, raw, aff = ctx.saved_tensors
+        dy = dy.contiguous()
+        Cout = weight.shape[0]
+        M = raw.numel() // Cout
+        sums = torch.zeros((2, Cout), device=dy.device, dtype=torch.float64)
+        call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M,
+             Cout, stream_ptr())
+        draw = torch.empty_like(raw)
+        want_affine = gamma.requires_grad
+        call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums),
+             ptr(draw), ptr(grad_buffer(gamma)) if want_affine else None,
+             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, stream_ptr())
+        C0 = x0.shape[3]
+        C1 = x1.shape[3] if x1 is not None else 0
+        dx0 = dx1 = None
+        if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            dx0, dx1 = conv_dgrad(draw, weight, C0, C1)
+        if weight.requires_grad:
+            conv_wgrad_acc(draw, x0, x1, weight)
+        return dx0, dx1, None, None, None, None, None, None, None, None
+
+
+class MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
+        call("rac_maxpool2_fwd", ptr(x), ptr(y), B, H, W, Cc, stream_ptr())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        call("rac_maxpool2_bwd", ptr(x), ptr(dy.contiguous()), ptr(dx), B, H, W, Cc, stream_ptr())
+        return dx
+
+
+class Upsample2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, h, w, Cc = x.shape
+        y = torch.empty((B, 2 * h, 2 * w, Cc), device=x.device, dtype=torch.float32)
+        call("rac_upsample2_fwd", ptr(x), ptr(y), B, h, w, Cc, stream_ptr())
+        ctx.shape = (B, h, w, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, Cc = ctx.shape
+        dx = torch.empty((B, h, w, Cc), device=dy.device, dtype=torch.float32)
+        call("rac_upsample2_bwd", ptr(dy.contiguous()), ptr(dx), B, h, w, Cc, stream_ptr())
+        return dx
+
+
+class TileCat(torch.autograd.Function):
+    """[tile(v0) | tile(v1) | tile(v2) | m0 | m1] along channels (dynamics.py:591-607,634-640).
+    Gradients flow to the maps only (actions / robot states are data)."""
+
+    @staticmethod
+    def forward(ctx, v0, v1, v2, m0, m1):
+        B, H, W, c0 = m0.shape
+        vs = [v for v in (v0, v1, v2) if v is not None]
+        vs += [None] * (3 - len(vs))
+        ns = [v.shape[1] if v is not None else 0 for v in vs]
+        c1 = m1.shape[3] if m1 is not None else 0
+        out = torch.empty((B, H, W, sum(ns) + c0 + c1), device=m0.device, dtype=torch.float32)
+        call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1,
+             ptr(out), B, H * W, stream_ptr())
+        ctx.meta = (sum(ns), c0, c1)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        nv, c0, c1 = ctx.meta
+        dout = dout.contiguous()
+        B, H, W, Ct = dout.shape
+        M = B * H * W
+        dm0 = dm1 = None
+        if ctx.needs_input_grad[3]:
+            dm0 = torch.empty((B, H, W, c0), device=dout.device, dtype=torch.float32)
+            call("rac_slice_channels", ptr(dout), Ct, nv, c0, ptr(dm0), M, stream_ptr())
+        if c1 and ctx.needs_input_grad[4]:
+            dm1 = torch.empty((B, H, W, c1), device=dout.device, dtype=torch.float32)
+            call("rac_slice_channels", ptr(dout), Ct, nv + c0, c1, ptr(dm1), M, stream_ptr())
+        return None, None, None, dm0, dm1
+
+
+class LstmCell(torch.autograd.Function):
+    """ConvLSTMCell (lstm.py:109-149): gates = Conv_k(cat(x, h_prev)) + b; i,f,o = sigmoid; g = tanh;
+    c = f*c_prev + i*g; h = o*tanh(c).  The gate GEMM writes split-K slabs that the cell kernel sums."""
+
+    @staticmethod
+    def forward(ctx, x, h_prev, c_prev, weight, bias):
+        B, H, W, g = x.shape
+        slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
+        h = torch.empty_like(x)
+        c = torch.empty_like(x)
+        need_bwd = any(ctx.needs_input_grad)  # all False under torch.no_grad() (frozen rollouts)
+        act = torch.empty((B, H, W, 4 * g), device=x.device, dtype=torch.float32) if need_bwd else None
+        call("rac_lstm_cell_fwd", ptr(slabs), n_slabs, stride, ptr(bias), ptr(c_prev), ptr(h), ptr(c), ptr(act),
+             B * H * W, g, stream_ptr())
+        if need_bwd:
+            ctx.save_for_backward(x, h_prev, c_prev, weight, bias, act, c)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        x, h_prev, c_prev, weight, bias, act, c = ctx.saved_tensors
+        B, H, W, g = x.shape
+        M = B * H * W
+        dgates = torch.empty_like(act)
+        dc_prev = torch.empty_like(c)
+        call("rac_lstm_cell_bwd", ptr(dh.contiguous()) if dh is not None else None,
+             ptr(dc.contiguous()) if dc is not None else None, ptr(act), ptr(c_prev), ptr(c), ptr(dgates),
+             ptr(dc_prev), M, g, stream_ptr())
+        dx = dh_prev = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx, dh_prev = conv_dgrad(dgates, weight, g, g)
+        if weight.requires_grad:
+            conv_wgrad_acc(dgates, x, h_prev, weight)
+        if bias.requires_grad:
+            bias_grad_acc(dgates, bias)
+        return dx, dh_prev, dc_prev, None, None
+
+
+class Reparam(torch.autograd.Function):
+    """z = eps * exp(0.5*logvar) + mu  (lstm.py:276-279)."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        z = torch.empty_like(mu)
+        call("rac_reparam_fwd", ptr(mu), ptr(logvar), ptr(eps), ptr(z), mu.numel(), stream_ptr())
+        ctx.save_for_backward(logvar, eps)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        logvar, eps = ctx.saved_tensors
+        dz = dz.contiguous()
+        dlv = torch.empty_like(dz)
+        call("rac_reparam_bwd", ptr(dz), ptr(logvar), ptr(eps), ptr(dlv), dz.numel(), stream_ptr())
+        return dz, dlv, None
+
+
+class PackInput(torch.autograd.Function):
+    """planes -> map: cat([img * (1 - zero_mask), mask], C) as NHWC (dynamics.py:578-582 + utils/image.py:5-19)."""
+
+    @staticmethod
+    def forward(ctx, img, zero_mask, mask):
+        B, _, H, W = img.shape
+        Cm = mask.shape[1] if mask is not None else 0
+        out = torch.empty((B, H, W, 3 + Cm), device=img.device, dtype=torch.float32)
+        call("rac_pack_input", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(out), B, H * W, stream_ptr())
+        ctx.save_for_backward(zero_mask)
+        ctx.C = 3 + Cm
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (zero_mask,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        dout = dout.contiguous()
+        B, H, W, _ = dout.shape
+        dimg = torch.empty((B, 3, H, W), device=dout.device, dtype=torch.float32)
+        call("rac_unpack_grad", ptr(dout), ctx.C, ptr(zero_mask), ptr(dimg), B, H * W, stream_ptr())
+        return dimg, None, None
+
+
+class ZeroRegion(torch.autograd.Function):
+    """zero_robot_region (src/utils/image.py:5-19), out of place."""
+
+    @staticmethod
+    def forward(ctx, img, mask):
+        B, _, H, W = img.shape
+        out = torch.empty_like(img)
+        call("rac_zero_region", ptr(img), ptr(mask), ptr(out), B, H * W, stream_ptr())
+        ctx.save_for_backward(mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (mask,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, _, H, W = dout.shape
+        d = torch.empty_like(dout)
+        call("rac_zero_region", ptr(dout), ptr(mask), ptr(d), B, H * W, stream_ptr())
+        return d, None
+
+
+class Composite(torch.autograd.Function):
+    """x_hat = (1 - m) * prev + m * rgb with [rgb | m] = x4 (trainer.py:406-407); x4 map -> planes."""
+
+    @staticmethod
+    def forward(ctx, x4, prev):
+        B, H, W, _ = x4.shape
+        out = torch.empty((B, 3, H, W), device=x4.device, dtype=torch.float32)
+        call("rac_composite_fwd", ptr(x4), ptr(prev), ptr(out), B, H * W, stream_ptr())
+        ctx.save_for_backward(x4, prev)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x4, prev = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, H, W, _ = x4.shape
+        dx4 = torch.empty_like(x4)
+        dprev = torch.empty_like(prev) if ctx.needs_input_grad[1] else None
+        call("rac_composite_bwd", ptr(dout), ptr(x4), ptr(prev), ptr(dx4), ptr(dprev), B, H * W, stream_ptr())
+        return dx4, dprev
+
+
+class ReconLoss(torch.autograd.Function):
+    """mse / l1 / dontcare_mse / dontcare_l1 (losses.py:11-50) and, in the same pass, the logging
+    metrics robot_mse / world_mse (losses.py:52-78).  Returns a (3,) tensor [loss, robot_mse, world_mse]."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, batch_weight, kind, robot_weight):
+        B, _, H, W = pred.shape
+        per = torch.empty((B, 8), device=pred.device, dtype=torch.float32)
+        out = torch.empty((3,), device=pred.device, dtype=torch.float32)
+        call("rac_recon_loss_fwd", kind, ptr(pred), ptr(target), ptr(mask), float(robot_weight), ptr(batch_weight),
+             ptr(per), ptr(out), B, H * W, stream_ptr())
+        ctx.save_for_backward(pred, target, mask, batch_weight, per)
+        ctx.kind, ctx.rw = kind, float(robot_weight)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pred, target, mask, bw, per = ctx.saved_tensors
+        B, _, H, W = pred.shape
+        g = gout.contiguous()  # only element 0 (the loss) carries gradient
+        dpred = torch.empty_like(pred)
+        call("rac_recon_loss_bwd", ctx.kind, ptr(pred), ptr(target), ptr(mask), ctx.rw, ptr(bw), ptr(per), ptr(g),
+             ptr(dpred), B, H * W, stream_ptr())
+        return dpred, None, None, None, None, None
+
+
+class KLLoss(torch.autograd.Function):
+    """kl_criterion (losses.py:97-106)."""
+
+    @staticmethod
+    def forward(ctx, mu1, lv1, mu2, lv2, bs):
+        out = torch.empty((1,), device=mu1.device, dtype=torch.float32)
+        part = torch.empty((1,), device=mu1.device, dtype=torch.float64)
+        call("rac_kl_fwd", ptr(mu1), ptr(lv1), ptr(mu2), ptr(lv2), mu1.numel(), bs, ptr(part), ptr(out), stream_ptr())
+        ctx.save_for_backward(mu1, lv1, mu2, lv2)
+        ctx.bs = bs
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        mu1, lv1, mu2, lv2 = ctx.saved_tensors
+        outs = [torch.empty_like(mu1) for _ in range(4)]
+        call("rac_kl_bwd", ptr(mu1), ptr(lv1), ptr(mu2), ptr(lv2), ptr(gout.contiguous()), mu1.numel(), ctx.bs,
+             *[ptr(o) for o in outs], stream_ptr())
+        return outs[0], outs[1], outs[2], outs[3], None
+
+
+def to_map(planes: torch.Tensor) -> torch.Tensor:
+    """(B,C,H,W) logical tensor -> contiguous (B,H,W,C) map (zero-copy for channels_last inputs)."""
+    return planes.permute(0, 2, 3, 1).contiguous()
+
+
+def to_planes_view(m: torch.Tensor) -> torch.Tensor:
+    """(B,H,W,C) map -> logical (B,C,H,W) view (channels_last strides, no copy)."""
+    return m.permute(0, 3, 1, 2)
