@@ -1,0 +1,89 @@
+"""CEMPolicy: cross-entropy-method planner over the frozen SVG model (API of reference
+src/cem/cem.py:14-111): sample N action sequences, roll them out in batches on the GPU(s),
+keep the top-K by summed cost, refit mean / std, repeat."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.distributions.normal import Normal
+
+from .state import DemoGoalState, State
+from .trajectory_sampler import TrajectorySampler
+
+
+class CEMPolicy(object):
+    """Given the current state and goal images, use CEM to find the best actions."""
+
+    def __init__(self, cfg, model, horizon=5, opt_iter=10, action_candidates=100, topk=5, init_std=1.0,
+                 cam_ext=None, franka_ik=None, wx250s_bot=None, push_height=None, default_pitch=None,
+                 default_roll=None, robot_model=None):
+        self.horizon = horizon
+        self.optimization_iter = opt_iter
+        self.num_actions = action_candidates
+        self.K = topk
+        self.init_std = init_std
+        self.sparse_cost = cfg.sparse_cost
+        self.action_dim = 2
+        self.cfg = cfg
+        self.model = model
+        self.traj_sampler = TrajectorySampler(cfg, self.model, cam_ext=cam_ext, franka_ik=franka_ik,
+                                              wx250s_bot=wx250s_bot, push_height=push_height,
+                                              default_pitch=default_pitch, default_roll=default_roll,
+                                              robot_model=robot_model)
+        self.plot_rollouts = cfg.debug_cem
+        if self.plot_rollouts:
+            self.debug_cem_dir = cfg.log_dir
+            os.makedirs(self.debug_cem_dir, exist_ok=True)
+        self.trace = None  # set to [] to record (act_seq, sum_cost, top_idx, mean, std) per iteration
+
+    def _sample(self, mean, std, N, noise=None):
+        """`Normal(mean, std).sample((N,))` (cem.py:80-81); every rank must see the same candidates,
+        so rank 0's draw is broadcast when running sharded."""
+        if noise is not None:
+            act_seq = mean + std * noise
+        else:
+            act_seq = Normal(mean, std).sample((N,))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dev = torch.device(self.cfg.device)
+            buf = act_seq.to(dev) if dist.get_backend() == "nccl" else act_seq.clone()
+            dist.broadcast(buf, src=0)
+            act_seq = buf.cpu()
+        return act_seq
+
+    def get_action(self, start, goal, ep_num, step, opt_traj=None, noise=None):
+        """Returns the refit mean action sequence, np.ndarray (horizon-1, 2).
+        `noise`: optional list of N(0,1) draws (N,T-1,2) per iteration (parity tests)."""
+        T, A, N = self.horizon, self.action_dim, self.num_actions
+        self.ep_num, self.step = ep_num, step
+        mean = torch.zeros(T - 1, A)
+        std = torch.ones(T - 1, A) * self.init_std
+        mean_top_costs = []
+        rollouts = {}
+        for i in range(self.optimization_iter):
+            act_seq = self._sample(mean, std, N, None if noise is None else noise[i])
+            if i == 0:
+                act_seq[-1] = 0  # always keep a "do nothing" candidate (cem.py:82-83)
+            act_seq.clamp_(-0.05, 0.05)
+            padded = torch.cat([act_seq, torch.zeros((N, T - 1, 3))], 2)
+            last = i == self.optimization_iter - 1
+            rollouts = self._get_rollouts(padded, start, goal, opt_traj if last else None,
+                                          self.plot_rollouts and last)
+            costs = torch.from_numpy(np.asarray(rollouts["sum_cost"]))
+            top_costs, top_idx = costs.topk(self.K)
+            top_act_seq = torch.index_select(act_seq, dim=0, index=top_idx)
+            mean_top_costs.append(f"{top_costs.mean():.3f}")
+            std, mean = torch.std_mean(top_act_seq, dim=0)
+            std = torch.max(0.001 * torch.ones_like(std), std)
+            if self.trace is not None:
+                self.trace.append({"act_seq": act_seq.numpy().copy(), "sum_cost": costs.numpy().copy(),
+                                   "top_idx": top_idx.numpy().copy(), "mean": mean.numpy().copy(),
+                                   "std": std.numpy().copy()})
+        self.mean_top_costs = mean_top_costs
+        return mean.numpy()
+
+    def _get_rollouts(self, act_seq, start: State, goal: DemoGoalState, opt_traj=None, plot=False):
+        return self.traj_sampler.generate_model_rollouts(act_seq, start, goal, ret_obs=self.plot_rollouts,
+                                                         opt_traj=opt_traj, suppress_print=True)

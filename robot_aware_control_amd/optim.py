@@ -1,0 +1,61 @@
+"""Fused Adam over the model's flat parameter buffer (one HIP launch per step).
+
+State-dict compatible with `torch.optim.Adam` (reference trainer.py:109-122,829-837): per-parameter
+`step`, `exp_avg`, `exp_avg_sq` entries are views of two flat moment buffers."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        params = list(model.parameters())
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
+        self._model = model
+        self._steps = 0
+        self._m = self._v = None
+
+    def _moments(self):
+        flat, _ = self._model.flat_parameters()
+        if self._m is None or self._m.numel() != flat.numel() or self._m.device != flat.device:
+            self._m, self._v = torch.zeros_like(flat), torch.zeros_like(flat)
+        return self._m, self._v
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        flat, grad = self._model.flat_parameters()
+        if not flat.is_cuda:
+            raise _lib.RacError("FusedAdam runs on the GPU only")
+        m, v = self._moments()
+        g = self.param_groups[0]
+        self._steps += 1
+        _lib.call("rac_adam_step", flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(),
+                  float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._steps,
+                  _lib.stream_ptr())
+
+    def _views(self):
+        m, v = self._moments()
+        off = 0
+        for p in self.param_groups[0]["params"]:
+            yield p, torch.as_strided(m, p.shape, p.stride(), off), torch.as_strided(v, p.shape, p.stride(), off)
+            off += (p.numel() + 3) // 4 * 4
+
+    def state_dict(self):
+        if self._steps:
+            for p, mv, vv in self._views():
+                self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": mv, "exp_avg_sq": vv}
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        steps = 0
+        for p, mv, vv in self._views():
+            st = self.state.get(p)
+            if st:
+                mv.copy_(st["exp_avg"])
+                vv.copy_(st["exp_avg_sq"])
+                steps = max(steps, int(st["step"]))
+        self._steps = steps
+        self.state.clear()

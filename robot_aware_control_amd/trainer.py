@@ -1,0 +1,301 @@
+"""PredictionTrainer: the SVG train step on librac_hip.so, API-compatible with the reference
+`src/prediction/trainer.py` (`PredictionTrainer(config)`, `_train_step`, `_train_video`, `train`,
+checkpoint format `{"model","optimizer","step"}`, ckpt_{step}.pt discovery).
+
+MI355X-first differences:
+  * no host sync inside the time loop: the 4 `.item()` calls per time step of the reference
+    (trainer.py:433-458) become one device->host copy per train step;
+  * zero_robot_region of the input frame is fused into the encoder's input packing;
+  * parameter gradients accumulate in place in one flat buffer; the DDP gradient all-reduce
+    (RCCL over xGMI, one process per GPU) runs on slices of that buffer, Adam is one launch.
+"""
+from __future__ import annotations
+
+import os
+from collections import defaultdict
+from glob import glob
+from math import floor
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .model import SVGConvModel
+from .optim import FusedAdam
+
+
+def _dist_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def allreduce_flat_grad(flat_grad: torch.Tensor, bucket_mb: int = 64):
+    """Mean of the flat gradient over all ranks: bucketed async all-reduce (RCCL; each bucket is a
+    contiguous slice, so there is no pack/unpack copy), then one scale."""
+    if not _dist_on():
+        return
+    world = dist.get_world_size()
+    n = flat_grad.numel()
+    step = max(1, bucket_mb * (1 << 20) // 4)
+    works = [dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=True)
+             for s in range(0, n, step)]
+    for w in works:
+        w.wait()
+    flat_grad.mul_(1.0 / world)
+
+
+class PredictionTrainer(object):
+    """Video prediction training (reference trainer.py:53-897, hot path only)."""
+
+    def __init__(self, config, logger=None):
+        self._config = config
+        if not torch.cuda.is_available():
+            raise ops._lib.RacError("PredictionTrainer needs an MI355X (no CPU fallback)")
+        local = int(os.environ.get("LOCAL_RANK", 0))
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        self._device = config.device = device
+        self._logger = logger
+        self._init_models(config)
+        self._scheduled_sampling = config.scheduled_sampling
+        self._step = 0
+        self._plot_rng = np.random.RandomState(self._config.seed)
+        self._video_sample_rng = np.random.RandomState(self._config.seed)
+        self._grad_seeds = {}
+        self._wandb = None
+        if getattr(config, "wandb", False):
+            import wandb  # only when asked for (reference trainer.py:70-84)
+            wandb.init(resume=config.jobname, project=config.wandb_project, config=config, dir=config.log_dir,
+                       entity=config.wandb_entity, group=config.wandb_group, job_type=config.wandb_job_type)
+            self._wandb = wandb
+
+    # ------------------------------------------------------------------ setup
+    def _init_models(self, cf):
+        if cf.model != "svg":  # trainer.py:99-107: det / copy / cdna_det are outside the accelerated path
+            raise ValueError(f"{cf.model}: only --model svg is built on the HIP path")
+        self.model = SVGConvModel(cf).to(self._device)
+        if _dist_on():  # identical initial weights on every rank
+            dist.broadcast(self.model.flat_parameters()[0], src=0)
+        if cf.optimizer != "adam":
+            raise ValueError("Unknown optimizer on the HIP path: %s" % cf.optimizer)
+        self.optimizer = FusedAdam(self.model, lr=cf.lr, betas=(cf.beta1, 0.999))
+
+    def _schedule_prob(self):
+        """Probability of feeding ground truth (trainer.py:132-140)."""
+        k = self._config.scheduled_sampling_k
+        use_truth = k / (k + np.exp(self._step / k))
+        return [use_truth, 1 - use_truth]
+
+    def _use_true_token(self):
+        """Scheduled sampling coin (trainer.py:142-147)."""
+        if not self._scheduled_sampling:
+            return True
+        return np.random.choice([True, False], p=self._schedule_prob())
+
+    def _loss_kind(self):
+        kind = self._config.reconstruction_loss
+        if kind not in ops.LOSS_KINDS:
+            raise NotImplementedError(f"{kind}")
+        return ops.LOSS_KINDS[kind]
+
+    def _recon_loss(self, prediction, target, mask=None, batch_weight=None):
+        """trainer.py:149-161; returns the (3,) [loss, robot_mse, world_mse] tensor of the fused kernel."""
+        cf = self._config
+        rw = cf.robot_pixel_weight if "dontcare" in cf.reconstruction_loss else 0.0
+        bw = batch_weight if cf.reconstruction_loss in ("l1", "dontcare_l1") else None
+        return ops.ReconLoss.apply(prediction, target, mask, bw, self._loss_kind(), rw)
+
+    def _seed(self, value: float, n: int = 1, first_only: bool = False):
+        key = (value, n, first_only)
+        if key not in self._grad_seeds:
+            t = torch.zeros(n, device=self._device)
+            if first_only:
+                t[0] = value
+            else:
+                t.fill_(value)
+            self._grad_seeds[key] = t
+        return self._grad_seeds[key]
+
+    # ------------------------------------------------------------- train step
+    def _train_video(self, data):
+        """Slice a video into n_past+n_future windows and train on each (trainer.py:259-324)."""
+        cf = self._config
+        x = data["images"]
+        T = len(x)
+        window = cf.n_past + cf.n_future
+        self.steps_per_train_video = floor(T / window)
+        all_losses = defaultdict(float)
+        for i in range(floor(T / window)):
+            if cf.random_snippet:
+                s = self._video_sample_rng.randint(0, (T - window) + 1)
+                e = s + window
+            else:
+                s, e = i * window, (i + 1) * window
+            batch = {"images": x[s:e], "states": data["states"][s:e], "actions": data["actions"][s:e - 1],
+                     "masks": data["masks"][s:e], "robot": data["robot"], "folder": data.get("folder")}
+            if "qpos" in data:
+                batch["qpos"] = data["qpos"][s:e]
+            if getattr(cf, "model_use_heatmap", False):
+                batch["heatmaps"] = data["heatmaps"][s:e]
+            if cf.load_movement_info:
+                batch["high_movement"] = data["high_movement"]
+            if "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state):
+                raise NotImplementedError("finetune_* experiments need the CPU analytical robot model "
+                                          "(trainer.py:294-319), which is outside the accelerated path")
+            losses = self._train_step(batch)
+            for k, v in losses.items():
+                all_losses[k] += v / floor(T / window)
+        return all_losses
+
+    def _train_step(self, data, use_truth=None):
+        """Forward and backward pass + optimiser step (trainer.py:326-465).  Returns the loss dict.
+        `use_truth[i]` overrides the scheduled-sampling coin at time index i (parity tests)."""
+        cf = self._config
+        dev = self._device
+        f32 = torch.float32
+        x = data["images"].to(dev, f32)
+        states = data["states"].to(dev, f32)
+        ac = data["actions"].to(dev, f32)
+        mask = data["masks"].to(dev, f32)
+        heatmaps = data["heatmaps"].to(dev, f32) if getattr(cf, "model_use_heatmap", False) else None
+        robot_name = np.array(data["robot"])
+        all_robots = sorted(set(robot_name))
+        batch_weight = None
+        if cf.load_movement_info:
+            mv = data["high_movement"].to(dev)
+            batch_weight = (cf.movement_weight * mv).to(f32)
+            batch_weight[~mv.bool()] = 1.0
+
+        self.model.zero_grad()
+        bs = min(cf.batch_size, x.shape[1])
+        self.model.init_hidden(bs)
+        dontcare = "dontcare" in cf.reconstruction_loss or cf.black_robot_input
+        roots, seeds, log = [], [], []  # autograd roots, their incoming grads, (name, tensor, index) for the readback
+        x_pred = None
+        skip = None
+        for i in range(1, cf.n_past + cf.n_future):
+            truth = True
+            if i > 1:
+                truth = self._use_true_token() if use_truth is None else bool(use_truth[i])
+            x_j = x[i - 1] if truth else x_pred  # scheduled sampling: gradients flow through the fed-back frame
+            m_j, r_j, a_j = mask[i - 1], states[i - 1], ac[i - 1]
+            x_i, m_i, r_i = x[i], mask[i], states[i]
+            if cf.last_frame_skip:
+                skip = None
+            m_in = torch.cat([m_j, m_i], 1) if cf.model_use_future_mask else m_j
+            r_in = (r_j, r_i) if cf.model_use_future_robot_state else r_j
+            hm_in = None
+            if heatmaps is not None:
+                hm_in = torch.cat([heatmaps[i - 1], heatmaps[i]], 1) if cf.model_use_future_heatmap else heatmaps[i - 1]
+            x4, curr_skip, mu, logvar, mu_p, logvar_p = self.model.forward_maps(
+                x_j, m_in, r_in, hm_in, a_j, True, r_i, skip, zero_mask=m_j if dontcare else None)
+            x_pred = ops.Composite.apply(x4, x_j.contiguous())  # un-blacked x_j (trainer.py:406-407)
+            if i <= cf.n_past:
+                skip = curr_skip
+            rec = self._recon_loss(x_pred, x_i.contiguous(), m_i.contiguous(), batch_weight)
+            roots.append(rec)
+            seeds.append(self._seed(1.0, 3, first_only=True))
+            log += [("recon_loss", rec, 0), ("robot_loss", rec, 1), ("world_loss", rec, 2)]
+            if len(all_robots) > 1:  # per-robot logging metrics (trainer.py:442-452)
+                with torch.no_grad():
+                    for r in all_robots:
+                        idx = torch.from_numpy(np.nonzero(robot_name == r)[0]).to(dev)
+                        sub = ops.ReconLoss.apply(x_pred.detach()[idx].contiguous(), x_i[idx].contiguous(),
+                                                  m_i[idx].contiguous(), None, 0, 0.0)
+                        log += [(f"{r}_robot_loss", sub, 1), (f"{r}_world_loss", sub, 2)]
+            kl = ops.KLLoss.apply(mu, logvar, mu_p, logvar_p, bs)
+            roots.append(kl)
+            seeds.append(self._seed(float(cf.beta)))
+            log.append(("kld", kl, 0))
+        # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
+        torch.autograd.backward(roots, seeds)
+        allreduce_flat_grad(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
+        self.optimizer.step()
+
+        vals = torch.stack([t[k] for _, t, k in log]).cpu().tolist()  # the one host sync of the step
+        losses = defaultdict(float)
+        for (name, _, _), v in zip(log, vals):
+            losses[name] += v
+        for k in losses:
+            losses[k] = losses[k] / cf.n_future
+        return losses
+
+    # ----------------------------------------------------------- outer loops
+    def train(self, batch_generator=None, test_hook=None):
+        """Epoch loop with checkpoint cadence (trainer.py:736-792).  `batch_generator` yields time-first
+        batches in the layout of `process_batch` (robonet_dataset.py:434-451)."""
+        cf = self._config
+        self._step = self._load_checkpoint(cf.dynamics_model_ckpt)
+        gen = batch_generator if batch_generator is not None else self._setup_data()
+        epoch = 0
+        for epoch in range(cf.niter):
+            self.model.train()
+            for _ in range(cf.epoch_size):
+                data = next(gen)
+                info = self._train_video(data)
+                if self._scheduled_sampling:
+                    info["sample_schedule"] = self._schedule_prob()[0]
+                self._step += self.steps_per_train_video
+                if self._wandb is not None:
+                    self._wandb.log({f"train/{k}": v for k, v in info.items()}, step=self._step)
+            if epoch % cf.checkpoint_interval == 0 and epoch > 0:
+                self._save_checkpoint()
+            if test_hook is not None and epoch % cf.eval_interval == 0:
+                self.model.eval()
+                test_hook(self, epoch)
+        self._save_checkpoint()
+        return info
+
+    def _setup_data(self):
+        """Dataloaders are I/O (h5py) and stay the reference's; `--data_root synthetic` feeds the
+        deterministic generator of robot_aware_control_amd.synthetic."""
+        cf = self._config
+        if cf.data_root == "synthetic":
+            from .synthetic import synth_video
+
+            def gen():
+                seed = cf.seed
+                while True:
+                    seed += 1
+                    yield synth_video(seed, cf.video_length, cf.batch_size, cf.image_height, cf.image_width,
+                                      cf.robot_dim, cf.action_dim)
+            return gen()
+        from src.dataset.robonet.robonet_dataloaders import create_loaders, get_batch  # reference data layer
+        train_loader, *_ = create_loaders(cf)
+        return get_batch(train_loader, self._device)
+
+    def _save_checkpoint(self):
+        """trainer.py:829-837."""
+        if _dist_on() and dist.get_rank() != 0:
+            return
+        os.makedirs(self._config.log_dir, exist_ok=True)
+        path = os.path.join(self._config.log_dir, f"ckpt_{self._step}.pt")
+        sd = {k: v.detach().clone().contiguous() if v.dim() != 4 else v.detach().clone()
+              for k, v in self.model.state_dict().items()}
+        torch.save({"model": sd, "optimizer": self.optimizer.state_dict(), "step": self._step}, path)
+        return path
+
+    def _load_checkpoint(self, ckpt_path=None):
+        """Load a given checkpoint, else the newest ckpt_*.pt of log_dir (trainer.py:846-897)."""
+        cf = self._config
+        if ckpt_path is None:
+            best, best_step = None, 0
+            for f in sorted(glob(os.path.join(cf.log_dir, "*.pt"))):
+                try:
+                    num = int(os.path.basename(f).split(".")[0].rsplit("_", 1)[-1])
+                except ValueError:
+                    continue
+                if num > best_step:
+                    best, best_step = f, num
+            if best is None:
+                return 0
+            ckpt_path = best
+            finetune_reset = False
+        else:
+            finetune_reset = "finetune" in cf.experiment
+        ckpt = torch.load(ckpt_path, map_location=self._device)
+        self.model.load_state_dict(ckpt["model"])
+        if finetune_reset:
+            return 0
+        self.optimizer.load_state_dict(ckpt["optimizer"])
+        return ckpt["step"]

@@ -1,0 +1,186 @@
+"""TrajectorySampler: batched candidate rollouts through the frozen SVG model, on the GPU
+(API of reference src/cem/trajectory_sampler.py:15-199).
+
+Per (batch, step) the reference runs model.forward, two elementwise passes, a cost reduction and a
+device->host copy (70 syncs per CEM iteration at N=1000).  Here the step tail -- compositing,
+zero_robot_region, the image cost and its fp64 accumulation -- is one kernel and the per-candidate
+sums stay on the device until the end: one D2H per call.
+
+Multi-GPU: candidates are independent, so with torch.distributed initialised each rank rolls out
+its contiguous slice and ONE all-gather (RCCL over xGMI) of the per-candidate fp64 costs precedes
+elite selection.
+"""
+from __future__ import annotations
+
+import time as timer
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+from .losses import RobotWorldCost
+from .state import DemoGoalState, State
+
+
+def shard_bounds(n: int, world: int, rank: int):
+    """Contiguous, near-equal candidate slices; the tail ranks get the remainder-free part."""
+    base, rem = divmod(n, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class TrajectorySampler(object):
+    def __init__(self, cfg, model, cam_ext=None, franka_ik=None, wx250s_bot=None, push_height=None,
+                 default_pitch=None, default_roll=None, robot_model=None) -> None:
+        self.cfg = cfg
+        self.model = model
+        self.cost = RobotWorldCost(cfg)
+        self.low = torch.tensor([[0.015, -0.3, 0.1, 0, 0]], dtype=torch.float32)   # trajectory_sampler.py:22-23
+        self.high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
+        self.robot_model = robot_model
+        self._robot_ctor = (cam_ext, franka_ik, wx250s_bot, push_height, default_pitch, default_roll)
+
+    def _needs_robot(self):
+        cfg = self.cfg
+        return (cfg.model_use_robot_state or cfg.model_use_mask or cfg.black_robot_input
+                or "dontcare" in cfg.reward_type)
+
+    def _get_robot_model(self):
+        """The analytical robot model (CPU IK + MuJoCo mask render, trajectory_sampler.py:26-33) is the
+        reference's own; pass `robot_model=` or run inside the reference tree."""
+        if self.robot_model is None:
+            cam_ext, franka_ik, wx250s_bot, push_height, pitch, roll = self._robot_ctor
+            if self.cfg.experiment == "control_franka":
+                from src.dataset.franka.franka_model import FrankaAnalyticalModel
+                self.robot_model = FrankaAnalyticalModel(self.cfg, franka_ik, cam_ext)
+            else:
+                from src.dataset.wx250s.wx250s_model import WX250sAnalyticalModel
+                self.robot_model = WX250sAnalyticalModel(self.cfg, wx250s_bot, push_height, pitch, roll,
+                                                         cam_ext=cam_ext)
+        return self.robot_model
+
+    def _predict_robot(self, action_sequences, start, N, T):
+        """states (T+1,N,5) normalised, masks (T+1,N,1,H,W) for every candidate (trajectory_sampler.py:86-109)."""
+        cfg = self.cfg
+        states = torch.zeros((T + 1, N, 5), dtype=torch.float32)
+        qpos = torch.zeros((T + 1, N, cfg.robot_joint_dim), dtype=torch.float32)
+        start_state = torch.tensor(start.state)
+        if cfg.experiment in ("control_franka", "control_wx250s"):
+            from src.utils.camera_calibration import LOCO_FRANKA_DIFF, LOCO_WX250S_DIFF
+            start_state[:2] = start_state[:2] + (LOCO_FRANKA_DIFF if cfg.experiment == "control_franka"
+                                                 else LOCO_WX250S_DIFF)
+        states[0, :] = (start_state - self.low) / (self.high - self.low)  # robonet_dataset.normalize
+        qpos[0, :] = torch.tensor(start.qpos)
+        start_data = {"states": states, "qpos": qpos, "actions": action_sequences.permute(1, 0, 2),
+                      "low": self.low.repeat(N, 1), "high": self.high.repeat(N, 1)}
+        return self._get_robot_model().predict_batch(start_data, thick=True)
+
+    @torch.no_grad()
+    def generate_model_rollouts(self, action_sequences, start: State, goal: DemoGoalState, opt_traj=None,
+                                ret_obs=False, ret_step_cost=False, suppress_print=True):
+        """Roll the candidate action sequences through the learned model and return
+        {"sum_cost": float64[N], ...} exactly as the reference does."""
+        cfg, model = self.cfg, self.model
+        dev = torch.device(cfg.device)
+        if dev.type != "cuda":
+            raise _lib.RacError("generate_model_rollouts needs cfg.device on the GPU (no CPU fallback)")
+        if opt_traj is not None:  # appended as candidate N+1 (trajectory_sampler.py:62-68)
+            opt = torch.cat([opt_traj, torch.zeros((len(opt_traj), 3))], 1).unsqueeze(0)
+            action_sequences = torch.cat([action_sequences, opt])
+        N, T = action_sequences.shape[0], action_sequences.shape[1]
+        H, W = cfg.image_height, cfg.image_width
+        start_time = timer.time()
+
+        goal_imgs = torch.stack([torch.from_numpy(g).permute(2, 0, 1).float() / 255 for g in goal.imgs]).to(dev)
+        goal_masks = None
+        if goal.masks is not None:
+            goal_masks = torch.stack([torch.from_numpy(np.asarray(g)) for g in goal.masks]).to(dev).to(torch.uint8)
+        states = masks = None
+        if self._needs_robot():
+            states, masks = self._predict_robot(action_sequences, start, N, T)
+            states = states.to(dev, non_blocking=True)
+            masks = masks.to(dev, torch.float32, non_blocking=True)
+        dontcare_in = "dontcare" in cfg.reconstruction_loss or cfg.black_robot_input
+        dontcare_cost = "dontcare" in cfg.reward_type
+        kind = 1 if dontcare_cost else 0
+        w_world = float(cfg.world_cost_weight)
+
+        # ---- candidate sharding over ranks (one process per GPU) ----
+        world, rank = 1, 0
+        if dist.is_available() and dist.is_initialized() and getattr(cfg, "cem_shard", True):
+            world, rank = dist.get_world_size(), dist.get_rank()
+        lo, hi = shard_bounds(N, world, rank)
+        n_local = hi - lo
+        per = cfg.candidates_batch_size
+        nb = max(n_local // per, 1)
+        sum_cost_dev = torch.zeros(max(n_local, 1), device=dev, dtype=torch.float64)
+        all_obs = torch.zeros((N, T, 3, H, W)) if ret_obs else None
+        step_cost = np.zeros((N, T)) if ret_step_cost else None
+        start_img = (torch.from_numpy(start.img.copy()).permute(2, 0, 1).float() / 255).to(dev)
+        actions_dev = action_sequences.to(dev, torch.float32)
+
+        for b in range(nb if n_local > 0 else 0):
+            s = lo + b * per
+            e = lo + (b + 1) * per if b < nb - 1 else hi
+            n = e - s
+            model.init_hidden(batch_size=n)
+            curr = start_img.expand(n, -1, -1, -1).contiguous()
+            if dontcare_in:
+                curr = ops.ZeroRegion.apply(curr, masks[0, s:e].contiguous())
+            for t in range(T):
+                ac = actions_dev[s:e, t].contiguous()
+                mask = masks[t, s:e] if cfg.model_use_mask else None
+                state = states[t, s:e] if cfg.model_use_robot_state else None
+                if cfg.model_use_future_mask:
+                    mask = torch.cat([mask, masks[t + 1, s:e]], 1)
+                if cfg.model_use_future_robot_state:
+                    state = (state, states[t + 1, s:e])
+                x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean)[0]
+                gi = t if t < len(goal_imgs) else -1
+                add = (not cfg.sparse_cost) or t == T - 1
+                nxt = torch.empty_like(curr)
+                before = sum_cost_dev[s - lo:e - lo].clone() if ret_step_cost else None
+                _lib.call(
+                    "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(),
+                    _lib.ptr(masks[t + 1, s:e].contiguous()) if dontcare_in else None, goal_imgs[gi].data_ptr(),
+                    _lib.ptr(masks[t + 1, s:e].contiguous()) if dontcare_cost else None,
+                    _lib.ptr(goal_masks[gi].contiguous()) if (dontcare_cost and goal_masks is not None) else None,
+                    kind, w_world, 1 if (add and w_world != 0) else 0, nxt.data_ptr(),
+                    sum_cost_dev[s - lo:e - lo].data_ptr(), n, H * W, _lib.stream_ptr())
+                if ret_obs:
+                    all_obs[s:e, t] = nxt.cpu()
+                if ret_step_cost:
+                    step_cost[s:e, t] = (sum_cost_dev[s - lo:e - lo] - before).cpu().numpy()
+                curr = nxt
+
+        # ---- gather the per-candidate costs: the only collective of a CEM iteration ----
+        if world > 1:
+            width = (N + world - 1) // world
+            send = torch.zeros(width, device=dev, dtype=torch.float64)
+            send[:n_local] = sum_cost_dev[:n_local]
+            recv = torch.empty(world * width, device=dev, dtype=torch.float64)
+            dist.all_gather_into_tensor(recv, send)
+            parts = recv.cpu().numpy().reshape(world, width)
+            sum_cost = np.concatenate([parts[r, :shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0]]
+                                       for r in range(world)])
+        else:
+            sum_cost = sum_cost_dev[:n_local].cpu().numpy()
+
+        if not suppress_print:
+            print("======= Samples Gathered  ======= | >>>> Time taken = %f " % (timer.time() - start_time))
+        rollouts = defaultdict(float)
+        if opt_traj is not None:
+            rollouts["optimal_sum_cost"] = sum_cost[-1]
+            if ret_obs:
+                rollouts["optimal_obs"] = all_obs[-1].numpy()
+            sum_cost = sum_cost[:-1]
+        rollouts["sum_cost"] = sum_cost
+        if ret_obs:
+            topk_idx = np.argsort(sum_cost)[-cfg.topk:]
+            rollouts["topk_idx"] = topk_idx
+            rollouts["obs"] = all_obs[topk_idx].numpy()
+        if ret_step_cost:
+            rollouts["step_cost"] = step_cost[:len(sum_cost)]
+        return rollouts

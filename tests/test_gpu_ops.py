@@ -38,7 +38,7 @@ def from_map(m):
 
 
 def relerr(a, b):
-    a, b = a.double(), b.double()
+    a, b = a.detach().double(), b.detach().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
 
 
@@ -284,7 +284,8 @@ def test_adam_matches_torch(dev):
         gg = g * step
         ref.grad = gg.clone()
         opt.step()
-        _lib.call("rac_adam_step", pd.data_ptr(), gg.to(dev).data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9,
+        gd = gg.to(dev)
+        _lib.call("rac_adam_step", pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9,
                   0.999, 1e-8, step, _lib.stream_ptr())
         torch.cuda.synchronize()
         assert relerr(pd.cpu(), ref.detach()) < 1e-6
@@ -298,12 +299,13 @@ def test_cem_step_tail(dev, golden_dir):
     N, _, H, W = curr.shape
     # identity compositing (m = 0) so that next == curr: isolates the cost reduction
     x4 = torch.zeros(N, H, W, 4, device=dev)
+    curr_d, goal_d = curr.to(dev), goal.to(dev)  # keep the device copies alive across the raw-pointer call
     for kind, key, cm, gm in ((0, "cost_l2", None, None), (1, "cost_dontcare", g["c_cmask"], g["c_gmask"])):
         nxt = torch.empty(N, 3, H, W, device=dev)
         cost = torch.zeros(N, device=dev, dtype=torch.float64)
         cmd = torch.from_numpy(cm.astype(np.float32)).to(dev) if cm is not None else None
         gmd = torch.from_numpy(gm.astype(np.uint8)).to(dev) if gm is not None else None
-        _lib.call("rac_cem_step_tail", x4.data_ptr(), curr.to(dev).data_ptr(), None, goal.to(dev).data_ptr(),
+        _lib.call("rac_cem_step_tail", x4.data_ptr(), curr_d.data_ptr(), None, goal_d.data_ptr(),
                   _lib.ptr(cmd), _lib.ptr(gmd), kind, 1.0, 1, nxt.data_ptr(), cost.data_ptr(), N, H * W,
                   _lib.stream_ptr())
         torch.cuda.synchronize()
