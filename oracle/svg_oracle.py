@@ -24,6 +24,7 @@ import torch.nn.functional as F
 Tensor = torch.Tensor
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+TRACE = None  # debugging aid: set to a list to collect (name, tensor-with-retained-grad) of every vgg block output
 
 
 # --------------------------------------------------------------------------- #
@@ -221,7 +222,11 @@ def vgg_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, training: bool) -> 
         sd[f"{base}.1.num_batches_tracked"] += 1
     y = F.batch_norm(y, sd[f"{base}.1.running_mean"], sd[f"{base}.1.running_var"],
                      sd[f"{base}.1.weight"], sd[f"{base}.1.bias"], training, BN_MOMENTUM, BN_EPS)
-    return F.leaky_relu(y, 0.2)
+    y = F.leaky_relu(y, 0.2)
+    if TRACE is not None and y.requires_grad:
+        y.retain_grad()
+        TRACE.append((prefix, y))
+    return y
 
 
 def _stack(sd, prefix, n, x, training):
