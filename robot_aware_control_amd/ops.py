@@ -71,8 +71,28 @@ def plan_split_k(M: int, N: int, nchunks: int) -> int:
 # --------------------------------------------------------------------------- #
 # raw launches
 # --------------------------------------------------------------------------- #
+# bench.py sets PROFILE = {"match": (mode, ksize, Cin, Cout), "events": []} to time ONE kernel shape with
+# HIP events on the launch stream (torch.cuda.Event records on the current stream = the launch stream).
+PROFILE = None
+
+
 def conv_raw(mode: int, a0, a1, w, out0, out1=None, *, B, H, W, ksize, Cin, Cout, act=ACT_NONE, split_k=1,
              slab_stride=0, accumulate=0, a_split=0, o_split=0, bias=None, scale=None, shift=None, stats=None):
+    prof = PROFILE
+    if prof is not None and prof["match"] == (mode, ksize, Cin, Cout):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
+                     a_split, o_split, bias, scale, shift, stats)
+        e1.record()
+        prof["events"].append((e0, e1, B * H * W))
+        return
+    _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
+                 a_split, o_split, bias, scale, shift, stats)
+
+
+def _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
+                 a_split, o_split, bias, scale, shift, stats):
     args = ConvArgs(mode=mode, B=B, H=H, W=W, ksize=ksize, Cin=Cin, Cout=Cout, act=act, split_k=split_k,
                     accumulate=accumulate, a_split=a_split, o_split=o_split, slab_stride=slab_stride,
                     a0=ptr(a0), a1=ptr(a1), w=ptr(w), out0=ptr(out0), out1=ptr(out1), bias=ptr(bias),
