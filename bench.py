@@ -54,6 +54,20 @@ def namespace(dev, **kw):
     return argparse.Namespace(**d)
 
 
+def log(msg):
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """Threads for the CPU baseline: the affinity mask, capped at the GPU box's CPU share (16 per GPU)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
 def barrier_sync(distributed):
     torch.cuda.synchronize()
     if distributed:
@@ -82,6 +96,7 @@ def profile_summary(prof, flops_per_pixel_row):
 
 def bench_train(args, dev, rank, world, distributed):
     cf = namespace(dev)
+    log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
     tr.model.train()
     B, T = cf.batch_size, cf.n_past + cf.n_future
@@ -89,6 +104,8 @@ def bench_train(args, dev, rank, world, distributed):
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     for i in range(args.warmup):
         tr._train_step(batches[i % 2])
+        torch.cuda.synchronize()
+        log(f"train warmup step {i} done")
     g = cf.g_dim
     # dominant kernel: ConvLSTM layer-0 gate GEMM, FWD  (M = B*64, N = 4g, K = 25 * 2g)
     prof = {"match": (ops.FWD, 5, 2 * g, 4 * g), "events": []}
@@ -99,6 +116,7 @@ def bench_train(args, dev, rank, world, distributed):
         tr._train_step(batches[i % 2])
     barrier_sync(distributed)
     dt = max_over_ranks(time.perf_counter() - t0, dev, distributed)
+    log(f"train: {args.steps} steps in {dt:.3f} s")
     ops.PROFILE = None
     frames = world * B * T * args.steps
     step_flop = 3 * B * (T - 1) * TRAIN_FWD_GFLOP_PER_SAMPLE_STEP * 1e9
@@ -122,8 +140,10 @@ def bench_cem(args, dev, rank, world, distributed, model=None):
     start = State(img=prob["start_img"])
     goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     g = cf.g_dim
+    log(f"cem: model built, {N} candidates")
     for _ in range(args.cem_warmup):
         pol.traj_sampler.generate_model_rollouts(prob["actions"], start, goal)
+        log("cem warmup iteration done")
     prof = {"match": (ops.FWD, 5, 2 * g, 4 * g), "events": []}
     ops.PROFILE = prof
     barrier_sync(distributed)
@@ -132,6 +152,7 @@ def bench_cem(args, dev, rank, world, distributed, model=None):
         ro = pol.traj_sampler.generate_model_rollouts(prob["actions"], start, goal)
     barrier_sync(distributed)
     dt = max_over_ranks(time.perf_counter() - t0, dev, distributed)
+    log(f"cem: {args.cem_iters} iterations in {dt:.3f} s")
     ops.PROFILE = None
     assert len(ro["sum_cost"]) == N and np.all(np.isfinite(ro["sum_cost"]))
     it_flop_per_gpu = n_per_gpu * (horizon - 1) * CEM_FWD_GFLOP_PER_CAND_STEP * 1e9
@@ -145,8 +166,9 @@ def cpu_baseline(train_state_dict, args):
     """The oracle (CPU restatement of the reference path, pinned by tests/golden) on this host's cores:
     a bounded sample of the same workloads."""
     from oracle import svg_oracle as orc
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(host_threads())
     cores = torch.get_num_threads()
+    log(f"cpu baseline on {cores} threads")
     Bs = 4
     cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=Bs, n_past=1, n_future=5, lr=1e-4, **RA)
     sd = {k: v.detach().cpu().clone().contiguous() for k, v in train_state_dict.items()}
@@ -155,6 +177,7 @@ def cpu_baseline(train_state_dict, args):
     t0 = time.perf_counter()
     orc.train_step(ts, data)
     t_train = time.perf_counter() - t0
+    log(f"cpu baseline train step: {t_train:.1f} s")
     ccfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=8, candidates_batch_size=8, sample_mean=True, reward_type="dense",
                    model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
                    reconstruction_loss="l1")
