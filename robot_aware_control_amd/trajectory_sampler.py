@@ -31,6 +31,23 @@ def shard_bounds(n: int, world: int, rank: int):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def gather_costs(local: torch.Tensor, N: int, world: int, rank: int) -> np.ndarray:
+    """All ranks' per-candidate fp64 cost sums -> one float64[N] on every rank (one all-gather; RCCL on the
+    GPU path, any backend works).  Slices are padded to a common width because shards may differ by one."""
+    if world == 1:
+        return local.cpu().numpy()
+    width = (N + world - 1) // world
+    send = torch.zeros(width, device=local.device, dtype=torch.float64)
+    send[:local.numel()] = local
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    out = []
+    for r, part in enumerate(parts):
+        lo, hi = shard_bounds(N, world, r)
+        out.append(part[:hi - lo].cpu().numpy())
+    return np.concatenate(out)
+
+
 class TrajectorySampler(object):
     def __init__(self, cfg, model, cam_ext=None, franka_ik=None, wx250s_bot=None, push_height=None,
                  default_pitch=None, default_roll=None, robot_model=None) -> None:
@@ -156,17 +173,7 @@ class TrajectorySampler(object):
                 curr = nxt
 
         # ---- gather the per-candidate costs: the only collective of a CEM iteration ----
-        if world > 1:
-            width = (N + world - 1) // world
-            send = torch.zeros(width, device=dev, dtype=torch.float64)
-            send[:n_local] = sum_cost_dev[:n_local]
-            recv = torch.empty(world * width, device=dev, dtype=torch.float64)
-            dist.all_gather_into_tensor(recv, send)
-            parts = recv.cpu().numpy().reshape(world, width)
-            sum_cost = np.concatenate([parts[r, :shard_bounds(N, world, r)[1] - shard_bounds(N, world, r)[0]]
-                                       for r in range(world)])
-        else:
-            sum_cost = sum_cost_dev[:n_local].cpu().numpy()
+        sum_cost = gather_costs(sum_cost_dev[:n_local], N, world, rank)
 
         if not suppress_print:
             print("======= Samples Gathered  ======= | >>>> Time taken = %f " % (timer.time() - start_time))
