@@ -1,0 +1,41 @@
+"""`python -um src.prediction.multirobot_trainer --jobname ... --model svg ...`
+
+The entry point the reference README / sbatch scripts call (README.md:103,111;
+scripts/train_multirobot_svg.sbatch:15).  Flags are those of src/config/__init__.py; under
+`python -m torch.distributed.run` it trains data-parallel, one process per GPU (RCCL)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+from robot_aware_control_amd.config import argparser
+from robot_aware_control_amd.trainer import PredictionTrainer
+
+
+def make_log_folder(config):
+    """log_dir/jobname (+ plot/video/trajectory sub-folders), as reference trainer.py:1411-1447."""
+    config.log_dir = os.path.join(config.log_dir, config.jobname or "default")
+    for sub in ("", "plot", "video", "trajectory"):
+        os.makedirs(os.path.join(config.log_dir, sub), exist_ok=True)
+    config.plot_dir = os.path.join(config.log_dir, "plot")
+    config.video_dir = os.path.join(config.log_dir, "video")
+    config.trajectory_dir = os.path.join(config.log_dir, "trajectory")
+
+
+def main():
+    config, _ = argparser()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+        dist.init_process_group("nccl")
+    torch.manual_seed(config.seed + int(os.environ.get("RANK", 0)))
+    make_log_folder(config)
+    trainer = PredictionTrainer(config)
+    trainer.train()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
