@@ -17,6 +17,8 @@
 //   KC: T[row][k]  row stride 36 floats; a lane reads 4 consecutive k (ds_read_b128)
 //   MC: T[k][row]  row stride BM/BN floats; a lane reads one float per MFMA (ds_read_b32)
 // Both use the same k assignment: MFMA (j,t) of lane half h consumes k = 8j + 4h + t.
+#include <stdlib.h>
+
 #include "rac_common.h"
 
 namespace rac {
@@ -68,6 +70,91 @@ __device__ __forceinline__ f32x4 ld_cat(const float* a0, const float* a1, int C,
     }
   }
   return v;
+}
+
+// Epilogue shared by both kernels.
+// C/D layout of 32x32 f32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+template <int MODE, int MT, int NT>
+__device__ __forceinline__ void epilogue(const ConvP& p, f32x16 (&acc)[MT][NT], int m0, int n0, int wg_tap, int wm,
+                                         int wn, int li, int lh) {
+  if (MODE == RAC_CONV_WGRAD) {
+    const long wrow = (long)p.taps * p.Cin;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = n0 + (wn * NT + nt) * 32 + li;
+      if (n >= p.Cin) continue;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= p.M) continue;
+          float* dst = p.out0 + m * wrow + (long)wg_tap * p.Cin + n;
+          const float v = acc[mt][nt][r];
+          if (p.split_k > 1)
+            atomicAdd(dst, v);
+          else if (p.accumulate)
+            *dst += v;
+          else
+            *dst = v;
+        }
+      }
+    }
+    return;
+  }
+
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + (wn * NT + nt) * 32 + li;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M || !nok) continue;
+        float v = acc[mt][nt][r];
+        if (slab) {
+          p.out0[(long)blockIdx.z * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        s1 += v;
+        s2 += v * v;
+        v = v * sc + sh;
+        if (p.act == RAC_ACT_LEAKY02)
+          v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == RAC_ACT_SIGMOID)
+          v = sigmoid_acc(v);
+        if (p.o_split > 0) {
+          if (n < p.o_split)
+            p.out0[(long)m * p.o_split + n] = v;
+          else
+            p.out1[(long)m * (p.N - p.o_split) + (n - p.o_split)] = v;
+        } else {
+          p.out0[(long)m * p.N + n] = v;
+        }
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0 && nok) {
+        atomicAdd(p.stats + n, (double)s1);
+        atomicAdd(p.stats + p.N + n, (double)s2);
+      }
+    }
+  }
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, bool AV, bool BV>
@@ -289,86 +376,317 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvP p) {
     }
   }
 
-  // ---- epilogue ----
-  // C/D layout of 32x32 f32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  epilogue<MODE, MT, NT>(p, acc, m0, n0, wg_tap, wm, wn, li, lh);
+}
+
+
+// --------------------------------------------------------------------------------------------
+// Fast path: same tiling / LDS forms / k assignment as igemm_kernel, but
+//   * every global load is a branch-free `buffer_load_dwordx4` through a wave-uniform buffer
+//     descriptor: out-of-image taps, partial channel chunks, tile tails and the chunk past the
+//     end are out-of-range offsets that the hardware returns as zeros -- no exec-mask branches,
+//     32-bit offset arithmetic only, so the whole K-chunk body is ONE basic block;
+//   * the next chunk's loads are issued in four slices between the four j-steps of MFMAs and the
+//     MFMA fragments are double-buffered, so address VALU, LDS reads and HBM latency sit under
+//     the 64-cycle fp32 MFMAs instead of in front of them.
+// Requires 16-B aligned operands, channel counts % 4 == 0, a chunk-uniform concat source
+// (FWD: a_split % 32 == 0; WGRAD: a_split % BN == 0) and operands < 4 GiB.
+// --------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(p)), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld4(rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void igemm_fast_kernel(ConvP p) {
+  constexpr int MT = BM / (32 * WM);
+  constexpr int NT = BN / (32 * WN);
+  constexpr bool A_KC = (MODE != RAC_CONV_WGRAD);
+  constexpr bool B_KC = (MODE == RAC_CONV_FWD);
+  constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
+  constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+  constexpr int A_PASS = A_KC ? BM / 32 : (BK * BM / 4) / 256;
+  constexpr int B_PASS = B_KC ? BN / 32 : (BK * BN / 4) / 256;
+  constexpr int A_TPR = BM / 4;
+  constexpr int B_TPR = BN / 4;
+  constexpr int A_RPP = 256 / A_TPR;  // MC form: k-rows covered per pass
+  constexpr int B_RPP = 256 / B_TPR;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31;
+  const int lh = lane >> 5;
+  const int wm = wid / WN;
+  const int wn = wid % WN;
+
+  const int m0 = blockIdx.x * BM;
+  int n0, wg_tap = 0;
   if (MODE == RAC_CONV_WGRAD) {
-    const long wrow = (long)p.taps * p.Cin;
+    wg_tap = blockIdx.y / p.ntile_per_tap;
+    n0 = (blockIdx.y - wg_tap * p.ntile_per_tap) * BN;
+  } else {
+    n0 = blockIdx.y * BN;
+  }
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+
+  // ---- loop-invariant per-thread row data ----
+  int a_pix[A_PASS], a_y[A_PASS], a_x[A_PASS];  // pixel-row A loader (FWD / DGRAD)
+  int b_row[B_PASS];                            // FWD: n*taps*Cin (or -1)
+  const int kcol = (tid & 7) * 4;               // KC form: channel offset inside the chunk
+  if (A_KC) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int n = n0 + (wn * NT + nt) * 32 + li;
-      if (n >= p.Cin) continue;
+    for (int i = 0; i < A_PASS; ++i) {
+      int m = m0 + (tid >> 3) + 32 * i;
+      if (m < p.M) {
+        int b = m / p.HW;
+        int r = m - b * p.HW;
+        int y = r / p.W;
+        a_pix[i] = m, a_y[i] = y, a_x[i] = r - y * p.W;
+      } else {
+        a_pix[i] = 0, a_y[i] = -100000, a_x[i] = 0;
+      }
+    }
+  }
+  if (MODE == RAC_CONV_FWD) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+    for (int i = 0; i < B_PASS; ++i) {
+      int n = n0 + (tid >> 3) + 32 * i;
+      b_row[i] = (n < p.N) ? n * p.taps * p.Cin : -1;
+    }
+  }
+  const int wg_dy = (MODE == RAC_CONV_WGRAD) ? wg_tap / p.ks - p.pad : 0;
+  const int wg_dx = (MODE == RAC_CONV_WGRAD) ? wg_tap % p.ks - p.pad : 0;
+
+  // descriptors that do not change over the K loop
+  const rsrc_t w_rsrc = make_rsrc(p.w, MODE == RAC_CONV_WGRAD ? (unsigned)p.P * p.Cout * 4u
+                                                                : (unsigned)p.Cout * p.taps * p.Cin * 4u);
+  // WGRAD: the x source of this block's channel range (block-uniform)
+  const bool wg_first = n0 < p.a_split;
+  const int wg_Cs = wg_first ? p.a_split : p.Cin - p.a_split;
+  const int wg_cl = (wg_first ? n0 : n0 - p.a_split) + (tid % B_TPR) * 4;
+  const rsrc_t x_rsrc = make_rsrc(wg_first ? p.a0 : (p.a1 ? p.a1 : p.a0), (unsigned)p.P * wg_Cs * 4u);
+
+  // Byte offsets of one chunk's loads (OOB where the hardware must return zeros) and the A-side descriptor.
+  auto chunk_offsets = [&](int kc, unsigned (&oa)[A_PASS], unsigned (&ob)[B_PASS], rsrc_t& a_rsrc) {
+    const bool live = kc < kc_end;
+    if (MODE != RAC_CONV_WGRAD) {
+      const int tap = kc / p.cchunks;
+      const int cc = kc - tap * p.cchunks;
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const int dy = (MODE == RAC_CONV_FWD) ? ky - p.pad : p.pad - ky;
+      const int dx = (MODE == RAC_CONV_FWD) ? kx - p.pad : p.pad - kx;
+      const int c0 = cc * BK;
+      const int CA = (MODE == RAC_CONV_FWD) ? p.Cin : p.Cout;
+      const int csplit = (MODE == RAC_CONV_FWD) ? p.a_split : CA;
+      const bool first = c0 < csplit;
+      const int Cs = first ? csplit : CA - csplit;
+      const int cl = (first ? c0 : c0 - csplit) + kcol;
+      a_rsrc = make_rsrc(first ? p.a0 : p.a1, (unsigned)p.P * Cs * 4u);
+      const int shift = dy * p.W + dx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= p.M) continue;
-          float* dst = p.out0 + m * wrow + (long)wg_tap * p.Cin + n;
-          const float v = acc[mt][nt][r];
-          if (p.split_k > 1)
-            atomicAdd(dst, v);
-          else if (p.accumulate)
-            *dst += v;
-          else
-            *dst = v;
+      for (int i = 0; i < A_PASS; ++i) {
+        int yy = a_y[i] + dy, xx = a_x[i] + dx;
+        bool ok = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && cl < Cs;
+        oa[i] = ok ? (unsigned)((a_pix[i] + shift) * Cs + cl) * 4u : OOB;
+      }
+      if (MODE == RAC_CONV_FWD) {
+        const int s0 = tap * p.Cin + c0 + kcol;
+        const bool cok = live && c0 + kcol < p.Cin;
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) ob[i] = (cok && b_row[i] >= 0) ? (unsigned)(b_row[i] + s0) * 4u : OOB;
+      } else {
+        const int n = n0 + (tid % B_TPR) * 4;
+#pragma unroll
+        for (int i = 0; i < B_PASS; ++i) {
+          int co = c0 + tid / B_TPR + B_RPP * i;
+          bool ok = live && co < p.Cout && n < p.N;
+          ob[i] = ok ? (unsigned)((co * p.taps + tap) * p.Cin + n) * 4u : OOB;
         }
       }
-    }
-    return;
-  }
-
-  const bool slab = p.split_k > 1;
+    } else {
+      a_rsrc = w_rsrc;
+      const int p0 = kc * BK;
+      const int m = m0 + (tid % A_TPR) * 4;
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + (wn * NT + nt) * 32 + li;
-    const bool nok = n < p.N;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (!slab && nok) {
-      if (p.bias) bias = p.bias[n];
-      if (p.scale) {
-        sc = p.scale[n];
-        sh = p.shift[n];
+      for (int i = 0; i < A_PASS; ++i) {
+        int px = p0 + tid / A_TPR + A_RPP * i;
+        bool ok = live && px < p.P && m < p.M;
+        oa[i] = ok ? (unsigned)(px * p.Cout + m) * 4u : OOB;
+      }
+      const int shift = wg_dy * p.W + wg_dx;
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) {
+        int px = p0 + tid / B_TPR + B_RPP * i;
+        int b = px / p.HW;
+        int r = px - b * p.HW;
+        int y = r / p.W;
+        int x = r - y * p.W;
+        int yy = y + wg_dy, xx = x + wg_dx;
+        bool ok = live && px < p.P && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && wg_cl < wg_Cs;
+        ob[i] = ok ? (unsigned)((px + shift) * wg_Cs + wg_cl) * 4u : OOB;
       }
     }
-    float s1 = 0.f, s2 = 0.f;
+  };
+  auto issue_loads = [&](const unsigned (&oa)[A_PASS], const unsigned (&ob)[B_PASS], rsrc_t a_rsrc,
+                         f32x4 (&ra)[A_PASS], f32x4 (&rb)[B_PASS]) {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) ra[i] = buf_ld4(a_rsrc, oa[i]);
+    const rsrc_t b_rsrc = (MODE == RAC_CONV_WGRAD) ? x_rsrc : w_rsrc;
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) rb[i] = buf_ld4(b_rsrc, ob[i]);
+  };
+
+  // LDS store of staged load number q (A loads first, then B) into buffer `buf`
+  auto store_one = [&](int buf, int q, const f32x4 (&ra)[A_PASS], const f32x4 (&rb)[B_PASS]) {
+    float* As = smem + buf * (A_SZ + B_SZ);
+    float* Bs = As + A_SZ;
+    if (q < A_PASS) {
+      const int i = q;
+      if (A_KC)
+        *reinterpret_cast<f32x4*>(As + ((tid >> 3) + 32 * i) * LDK + kcol) = ra[i];
+      else
+        *reinterpret_cast<f32x4*>(As + (tid / A_TPR + A_RPP * i) * BM + (tid % A_TPR) * 4) = ra[i];
+    } else {
+      const int i = q - A_PASS;
+      if (B_KC)
+        *reinterpret_cast<f32x4*>(Bs + ((tid >> 3) + 32 * i) * LDK + kcol) = rb[i];
+      else
+        *reinterpret_cast<f32x4*>(Bs + (tid / B_TPR + B_RPP * i) * BN + (tid % B_TPR) * 4) = rb[i];
+    }
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto read_frags = [&](const float* As, const float* Bs, int j, f32x4 (&fa)[MT], f32x4 (&fb)[NT]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
+      const int row = (wm * MT + mt) * 32 + li;
+      if (A_KC) {
+        fa[mt] = *reinterpret_cast<const f32x4*>(As + row * LDK + 8 * j + 4 * lh);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= p.M || !nok) continue;
-        float v = acc[mt][nt][r];
-        if (slab) {
-          p.out0[(long)blockIdx.z * p.slab_stride + (long)m * p.N + n] = v;
-          continue;
-        }
-        v += bias;
-        s1 += v;
-        s2 += v * v;
-        v = v * sc + sh;
-        if (p.act == RAC_ACT_LEAKY02)
-          v = v > 0.f ? v : 0.2f * v;
-        else if (p.act == RAC_ACT_SIGMOID)
-          v = sigmoid_acc(v);
-        if (p.o_split > 0) {
-          if (n < p.o_split)
-            p.out0[(long)m * p.o_split + n] = v;
-          else
-            p.out1[(long)m * (p.N - p.o_split) + (n - p.o_split)] = v;
-        } else {
-          p.out0[(long)m * p.N + n] = v;
-        }
+        for (int t = 0; t < 4; ++t) fa[mt][t] = As[(8 * j + 4 * lh + t) * BM + row];
       }
     }
-    if (p.stats && !slab) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lh == 0 && nok) {
-        atomicAdd(p.stats + n, (double)s1);
-        atomicAdd(p.stats + p.N + n, (double)s2);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int row = (wn * NT + nt) * 32 + li;
+      if (B_KC) {
+        fb[nt] = *reinterpret_cast<const f32x4*>(Bs + row * LDK + 8 * j + 4 * lh);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fb[nt][t] = Bs[(8 * j + 4 * lh + t) * BN + row];
       }
+    }
+  };
+
+  if (kc_begin < kc_end) {
+    constexpr int NLOADS = A_PASS + B_PASS;
+    unsigned oa[A_PASS], ob[B_PASS];
+    rsrc_t ars;
+    f32x4 ra0[A_PASS], rb0[B_PASS], ra1[A_PASS], rb1[B_PASS];  // two staging sets: loads run two chunks ahead
+
+    // One K-chunk.  On entry: LDS[buf] holds chunk kc, (cra, crb) hold chunk kc+1 (issued one chunk ago),
+    // (oa, ob, ars) address chunk kc+2.  The body issues kc+2 into (nra, nrb), derives the offsets of kc+3,
+    // and writes kc+1 into LDS[buf^1] between the MFMAs of the third j-step, so that only the barrier is
+    // left at the end of the chunk.
+    auto body = [&](int kc, f32x4 (&cra)[A_PASS], f32x4 (&crb)[B_PASS], f32x4 (&nra)[A_PASS], f32x4 (&nrb)[B_PASS]) {
+      const int buf = (kc - kc_begin) & 1;
+      const float* As = smem + buf * (A_SZ + B_SZ);
+      const float* Bs = As + A_SZ;
+      issue_loads(oa, ob, ars, nra, nrb);
+      __builtin_amdgcn_sched_barrier(0);
+      unsigned na[A_PASS], nb[B_PASS];
+      rsrc_t nrs;
+      chunk_offsets(kc + 3, na, nb, nrs);
+      f32x4 fa[2][MT], fb[2][NT];
+      read_frags(As, Bs, 0, fa[0], fb[0]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < 3) read_frags(As, Bs, j + 1, fa[(j + 1) & 1], fb[(j + 1) & 1]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][mt][t], fb[j & 1][nt][t], acc[mt][nt], 0,
+                                                                 0, 0);
+              const int q = (t * MT + mt) * NT + nt;  // compile-time after unrolling
+              if (j == 2 && q < NLOADS) store_one(buf ^ 1, q, cra, crb);
+            }
+        if (j == 2 && NLOADS > 4 * MT * NT) {
+#pragma unroll
+          for (int q = 4 * MT * NT; q < NLOADS; ++q) store_one(buf ^ 1, q, cra, crb);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < A_PASS; ++i) oa[i] = na[i];
+#pragma unroll
+      for (int i = 0; i < B_PASS; ++i) ob[i] = nb[i];
+      ars = nrs;
+    };
+
+    chunk_offsets(kc_begin, oa, ob, ars);
+    issue_loads(oa, ob, ars, ra0, rb0);
+    chunk_offsets(kc_begin + 1, oa, ob, ars);
+    issue_loads(oa, ob, ars, ra1, rb1);
+    chunk_offsets(kc_begin + 2, oa, ob, ars);
+#pragma unroll
+    for (int q = 0; q < NLOADS; ++q) store_one(0, q, ra0, rb0);
+    __syncthreads();
+    for (int kc = kc_begin; kc < kc_end; kc += 2) {
+      body(kc, ra1, rb1, ra0, rb0);
+      if (kc + 1 < kc_end) body(kc + 1, ra0, rb0, ra1, rb1);
     }
   }
+  epilogue<MODE, MT, NT>(p, acc, m0, n0, wg_tap, wm, wn, li, lh);
+}
+
+template <int MODE, int BM, int BN, int WM, int WN>
+static int launch_fast(const ConvP& p, dim3 grid, hipStream_t st) {
+  constexpr bool A_KC = (MODE != RAC_CONV_WGRAD);
+  constexpr bool B_KC = (MODE == RAC_CONV_FWD);
+  constexpr int A_SZ = A_KC ? BM * LDK : BK * BM;
+  constexpr int B_SZ = B_KC ? BN * LDK : BK * BN;
+  constexpr size_t lds = 2 * (A_SZ + B_SZ) * sizeof(float);
+  auto k = igemm_fast_kernel<MODE, BM, BN, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (lds > 48 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute(lds=%zu): %s", lds, hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  return check_launch("rac_conv2d(fast)");
 }
 
 template <int MODE, int BM, int BN, int WM, int WN, bool AV, bool BV>
@@ -409,7 +727,15 @@ static int launch_mode(ConvP& p, hipStream_t st, bool av, bool bv) {
   const long gm = p.M, gn = (MODE == RAC_CONV_WGRAD) ? p.Cin : p.N;
   const long tapmul = (MODE == RAC_CONV_WGRAD) ? p.taps : 1;
   int bm, bn;
-  if (gn <= 32) {
+  static const int forced = [] {  // RAC_IGEMM_TILE=128|64|32 pins the tile (benchmark A/B only)
+    const char* e = getenv("RAC_IGEMM_TILE");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced == 128 && gn > 32) {
+    bm = bn = 128;
+  } else if (forced == 64 && gn > 32) {
+    bm = bn = 64;
+  } else if (gn <= 32) {
     bm = 128, bn = 32;
   } else {
     long t128 = (long)cdiv(gm, 128) * cdiv(gn, 128) * tapmul;
@@ -428,6 +754,21 @@ static int launch_mode(ConvP& p, hipStream_t st, bool av, bool bv) {
   p.cps = cdiv(p.nchunks, p.split_k);
   p.ntile_per_tap = cdiv(gn, bn);
   dim3 grid(cdiv(gm, bm), (unsigned)(cdiv(gn, bn) * tapmul), p.split_k);
+  static const bool no_fast = getenv("RAC_IGEMM_GENERIC") != nullptr;  // A/B switch for benchmarks
+  bool fast = av && bv && !no_fast;
+  {
+    const long a_ch = (MODE == RAC_CONV_DGRAD) ? p.Cout : p.Cin;
+    const long w_bytes = (MODE == RAC_CONV_WGRAD) ? (long)p.P * p.Cout * 4 : (long)p.Cout * p.taps * p.Cin * 4;
+    fast = fast && (long)p.P * a_ch * 4 < 0xFFFFFF00L && w_bytes < 0xFFFFFF00L;
+    const bool concat = p.a_split < ((MODE == RAC_CONV_DGRAD) ? p.Cout : p.Cin);
+    if (MODE == RAC_CONV_FWD && concat) fast = fast && (p.a_split % BK == 0);
+    if (MODE == RAC_CONV_WGRAD && concat) fast = fast && (p.a_split % bn == 0);
+  }
+  if (fast) {
+    if (bn == 32) return launch_fast<MODE, 128, 32, 4, 1>(p, grid, st);
+    if (bm == 128) return launch_fast<MODE, 128, 128, 2, 2>(p, grid, st);
+    return launch_fast<MODE, 64, 64, 2, 2>(p, grid, st);
+  }
   if (bn == 32) return launch_vec<MODE, 128, 32, 4, 1>(p, grid, st, av, bv);
   if (bm == 128) return launch_vec<MODE, 128, 128, 2, 2>(p, grid, st, av, bv);
   return launch_vec<MODE, 64, 64, 2, 2>(p, grid, st, av, bv);

@@ -18,6 +18,7 @@ weights.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -63,6 +64,9 @@ def plan_split_k(M: int, N: int, nchunks: int) -> int:
         tiles = _cdiv(M, 128) * _cdiv(N, 128)
     else:
         tiles = _cdiv(M, 64) * _cdiv(N, 64)
+    forced = os.environ.get("RAC_SPLIT")
+    if forced:
+        return max(1, min(int(forced), nchunks))
     if tiles >= 384:
         return 1
     return max(1, min(8, _cdiv(512, tiles), nchunks // 8))
