@@ -124,6 +124,10 @@ int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* strea
 /* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
                     int64_t n, int32_t N, void* stream);
+/* as rac_slab_reduce for [M][N] slabs, but columns [0,o_split) go to out0 (row stride o_split) and the rest to
+ * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat */
+int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
+                     int32_t N, int32_t o_split, void* stream);
 /* stats[c] += sum_m x[m][c]; stats[C+c] += sum_m x[m][c]^2  (fp64; BatchNorm statistics after a split-K combine) */
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream);
 /* dx = dy * act'(.) expressed through the activation OUTPUT y (sigmoid: y(1-y); leaky: y>0 ? 1 : 0.2) */

@@ -248,29 +248,22 @@ __global__ void slice_channels_kernel(const float* src, int Csrc, int off, int n
   }
 }
 
+// grid = (row blocks, 64-channel groups): bias gradients of the 4g-wide gate tensors have few rows (B*64) and many
+// channels, so both dimensions are needed to fill the chip.
 __global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int rows_per_block) {
   __shared__ float s1[256];
-  const int TC = C < 64 ? C : 64;
-  const int RL = 256 / TC;
-  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;  // 4 row lanes
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(r_begin + rows_per_block, M);
-  for (int c0 = 0; c0 < C; c0 += TC) {
-    const int c = c0 + cl;
-    float a = 0.f;
-    if (c < C && rl < RL)
-      for (long r = r_begin + rl; r < r_end; r += RL) a += x[r * C + c];
-    s1[threadIdx.x] = a;
-    __syncthreads();
-    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
-      float t = 0.f;
-      for (int k = 0; k < RL; ++k) t += s1[k * TC + threadIdx.x];
-      atomicAdd(out + c0 + threadIdx.x, t);
-    }
-    __syncthreads();
-  }
+  float a = 0.f;
+  if (c < C)
+    for (long r = r_begin + rl; r < r_end; r += 4) a += x[r * C + c];
+  s1[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C) atomicAdd(out + c, (s1[threadIdx.x] + s1[threadIdx.x + 64]) +
+                                                        (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]));
 }
-
 
 __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out,
                                    long n, int N) {
@@ -321,6 +314,21 @@ __global__ void act_bwd_kernel(const float* dy, const float* y, int act, float* 
     else if (act == RAC_ACT_LEAKY02)
       g *= (yv > 0.f ? 1.f : 0.2f);
     dx[i] = g;
+  }
+}
+
+__global__ void slab_reduce2_kernel(const float* slabs, int n_slabs, long slab_stride, float* out0, float* out1, long M,
+                                    int N, int o_split) {
+  const long n = M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / N;
+    int c = (int)(i - m * N);
+    float a = 0.f;
+    for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + i];
+    if (c < o_split)
+      out0[m * o_split + c] = a;
+    else
+      out1[m * (N - o_split) + (c - o_split)] = a;
   }
 }
 
@@ -535,9 +543,13 @@ int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, 
 
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(x && out && M > 0 && C > 0, "rac_colsum_acc: bad args");
-  int nb;
-  int rpb = rows_per_block_for(M, &nb);
-  hipLaunchKernelGGL(colsum_acc_kernel, dim3(nb), dim3(256), 0, ST(stream), x, out, (long)M, C, rpb);
+  const int cgroups = cdiv(C, 64);
+  long nb = 1024 / cgroups;  // ~1024 workgroups in total
+  if (nb < 1) nb = 1;
+  if (nb > (M + 15) / 16) nb = (M + 15) / 16;
+  const int rpb = (int)((M + nb - 1) / nb);
+  hipLaunchKernelGGL(colsum_acc_kernel, dim3(cdiv(M, rpb), cgroups), dim3(256), 0, ST(stream), x, out, (long)M, C,
+                     rpb);
   return check_launch("rac_colsum_acc");
 }
 
@@ -547,6 +559,15 @@ int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, co
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), slabs, n_slabs,
                      (long)slab_stride, bias, out, (long)n, N);
   return check_launch("rac_slab_reduce");
+}
+
+int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
+                     int32_t N, int32_t o_split, void* stream) {
+  RAC_REQUIRE(slabs && out0 && out1 && n_slabs >= 1 && M > 0 && N > 0 && o_split > 0 && o_split < N,
+              "rac_slab_reduce2: bad args");
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, ST(stream), slabs, n_slabs,
+                     (long)slab_stride, out0, out1, (long)M, N, o_split);
+  return check_launch("rac_slab_reduce2");
 }
 
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream) {

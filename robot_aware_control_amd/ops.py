@@ -57,19 +57,26 @@ def _cdiv(a, b):
 
 
 def plan_split_k(M: int, N: int, nchunks: int) -> int:
-    """How many K-splits a FWD/DGRAD launch should use so that >= ~2 workgroups land on each of the 256 CUs."""
-    if N <= 32:
-        tiles = _cdiv(M, 128)
-    elif M >= 128 and N >= 128 and _cdiv(M, 128) * _cdiv(N, 128) >= 192:
-        tiles = _cdiv(M, 128) * _cdiv(N, 128)
-    else:
-        tiles = _cdiv(M, 64) * _cdiv(N, 64)
+    """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
+    choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
     forced = os.environ.get("RAC_SPLIT")
     if forced:
         return max(1, min(int(forced), nchunks))
+    cap = max(1, nchunks // 8)  # keep >= 8 chunks per split: the pipeline prologue/epilogue must amortise
+    if N <= 32:
+        tiles = _cdiv(M, 128)
+        return 1 if tiles >= 384 else max(1, min(8, _cdiv(512, tiles), cap))
+    if M >= 128 and N >= 128:
+        t128 = _cdiv(M, 128) * _cdiv(N, 128)
+        if t128 >= 384:
+            return 1
+        split = max(1, min(8, _cdiv(512, t128), cap))
+        if t128 * split >= 192:
+            return split
+    tiles = _cdiv(M, 64) * _cdiv(N, 64)
     if tiles >= 384:
         return 1
-    return max(1, min(8, _cdiv(512, tiles), nchunks // 8))
+    return max(1, min(8, _cdiv(512, tiles), cap))
 
 
 # --------------------------------------------------------------------------- #
@@ -149,12 +156,15 @@ def conv_dgrad(dy, weight, C0: int, C1: int = 0, transposed_head: bool = False):
     nchunks = k * k * _cdiv(Cout, 32)
     dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
     dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32) if C1 else None
-    split = plan_split_k(M, Cin, nchunks) if C1 == 0 else 1
+    split = plan_split_k(M, Cin, nchunks)
     if split > 1:
         slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
         conv_raw(DGRAD, dy, None, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, split_k=split,
                  slab_stride=M * Cin)
-        call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
+        if C1:
+            call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
+        else:
+            call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
     else:
         conv_raw(DGRAD, dy, None, weight, dx0, dx1, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout,
                  o_split=C0 if C1 else 0)

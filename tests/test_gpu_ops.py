@@ -132,19 +132,25 @@ def test_vgg_layer_train_and_eval(dev, shape):
     beta = rnd(4, Cout, scale=0.1).requires_grad_(True)
     rm, rv = rnd(5, Cout, scale=0.1), 1 + rnd(6, Cout, scale=0.1).abs()
     rm_ref, rv_ref = rm.clone(), rv.clone()
-    y_ref = F.leaky_relu(F.batch_norm(F.conv2d(x, w, None, 1, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5), 0.2)
-    gy = rnd(7, *y_ref.shape)
-    y_ref.backward(gy)
-    # second momentum update on the same batch (the double encoder pass of the reference)
-    with torch.no_grad():
-        F.batch_norm(F.conv2d(x, w, None, 1, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
-
     x0 = to_map(x.detach()[:, :C0], dev).requires_grad_(True)
     x1 = to_map(x.detach()[:, C0:], dev).requires_grad_(True) if C1 else None
     wd = cl_weight(w.detach()).to(dev).requires_grad_(True)
     gd, bd = gamma.detach().to(dev).requires_grad_(True), beta.detach().to(dev).requires_grad_(True)
     rmd, rvd = rm.to(dev), rv.to(dev)
     y = ops.VggLayer.apply(x0, x1, wd, gd, bd, rmd, rvd, True, 2, None)
+    # The reference uses the GPU's LeakyReLU slope pattern: a pre-activation within rounding distance of zero
+    # may take the other slope, which changes the backward pass discontinuously (see test_gpu_model.py).
+    z_ref = F.batch_norm(F.conv2d(x, w, None, 1, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    mask = from_map(y) > 0
+    flips = (z_ref.detach() > 0) != mask
+    assert int(flips.sum()) <= 3 and float(z_ref.detach()[flips].abs().max() if flips.any() else 0.0) < 1e-5
+    y_ref = z_ref * torch.where(mask, 1.0, 0.2)
+    gy = rnd(7, *y_ref.shape)
+    y_ref.backward(gy)
+    # second momentum update on the same batch (the double encoder pass of the reference)
+    with torch.no_grad():
+        F.batch_norm(F.conv2d(x, w, None, 1, 1), rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+
     assert relerr(from_map(y), y_ref.detach()) < 3e-5
     assert relerr(rmd.cpu(), rm_ref) < 1e-5 and relerr(rvd.cpu(), rv_ref) < 1e-5
     y.backward(to_map(gy, dev))
