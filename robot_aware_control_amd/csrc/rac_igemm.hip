@@ -34,6 +34,7 @@ struct ConvP {
   const float *bias, *scale, *shift;
   double* stats;
   int M, N, HW, P, taps, cchunks, nchunks, cps, ntile_per_tap;
+  unsigned long long magic_hw, magic_w;  // ceil(2^40 / d): n / d == (n * magic) >> 40 for n * d < 2^40
 };
 
 template <bool VEC>
@@ -393,6 +394,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(ConvP p) {
 // (FWD: a_split % 32 == 0; WGRAD: a_split % BN == 0) and operands < 4 GiB.
 // --------------------------------------------------------------------------------------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ int udiv40(int n, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)n * magic) >> 40);
+}
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
 __device__ __forceinline__ const float* uniform_ptr(const float* p) {
@@ -501,20 +505,20 @@ __global__ __launch_bounds__(256, 2) void igemm_fast_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         int yy = a_y[i] + dy, xx = a_x[i] + dx;
-        bool ok = live && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && cl < Cs;
+        bool ok = live & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W) & (cl < Cs);
         oa[i] = ok ? (unsigned)((a_pix[i] + shift) * Cs + cl) * 4u : OOB;
       }
       if (MODE == RAC_CONV_FWD) {
         const int s0 = tap * p.Cin + c0 + kcol;
-        const bool cok = live && c0 + kcol < p.Cin;
+        const bool cok = live & (c0 + kcol < p.Cin);
 #pragma unroll
-        for (int i = 0; i < B_PASS; ++i) ob[i] = (cok && b_row[i] >= 0) ? (unsigned)(b_row[i] + s0) * 4u : OOB;
+        for (int i = 0; i < B_PASS; ++i) ob[i] = (cok & (b_row[i] >= 0)) ? (unsigned)(b_row[i] + s0) * 4u : OOB;
       } else {
         const int n = n0 + (tid % B_TPR) * 4;
 #pragma unroll
         for (int i = 0; i < B_PASS; ++i) {
           int co = c0 + tid / B_TPR + B_RPP * i;
-          bool ok = live && co < p.Cout && n < p.N;
+          bool ok = live & (co < p.Cout) & (n < p.N);
           ob[i] = ok ? (unsigned)((co * p.taps + tap) * p.Cin + n) * 4u : OOB;
         }
       }
@@ -525,19 +529,19 @@ __global__ __launch_bounds__(256, 2) void igemm_fast_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < A_PASS; ++i) {
         int px = p0 + tid / A_TPR + A_RPP * i;
-        bool ok = live && px < p.P && m < p.M;
+        bool ok = live & (px < p.P) & (m < p.M);
         oa[i] = ok ? (unsigned)(px * p.Cout + m) * 4u : OOB;
       }
       const int shift = wg_dy * p.W + wg_dx;
 #pragma unroll
       for (int i = 0; i < B_PASS; ++i) {
         int px = p0 + tid / B_TPR + B_RPP * i;
-        int b = px / p.HW;
+        int b = udiv40(px, p.magic_hw);
         int r = px - b * p.HW;
-        int y = r / p.W;
+        int y = udiv40(r, p.magic_w);
         int x = r - y * p.W;
         int yy = y + wg_dy, xx = x + wg_dx;
-        bool ok = live && px < p.P && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W && wg_cl < wg_Cs;
+        bool ok = live & (px < p.P) & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W) & (wg_cl < wg_Cs);
         ob[i] = ok ? (unsigned)((px + shift) * wg_Cs + wg_cl) * 4u : OOB;
       }
     }
@@ -634,7 +638,11 @@ __global__ __launch_bounds__(256, 2) void igemm_fast_kernel(ConvP p) {
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][mt][t], fb[j & 1][nt][t], acc[mt][nt], 0,
                                                                  0, 0);
               const int q = (t * MT + mt) * NT + nt;  // compile-time after unrolling
-              if (j == 2 && q < NLOADS) store_one(buf ^ 1, q, cra, crb);
+              if (j == 2 && q < NLOADS) {  // one LDS store per MFMA gap, pinned there
+                __builtin_amdgcn_sched_barrier(0);
+                store_one(buf ^ 1, q, cra, crb);
+                __builtin_amdgcn_sched_barrier(0);
+              }
             }
         if (j == 2 && NLOADS > 4 * MT * NT) {
 #pragma unroll
@@ -795,6 +803,8 @@ extern "C" int rac_conv2d(const rac_conv_args* a, void* stream) {
   p.P = a->B * p.HW;
   p.taps = a->ksize * a->ksize;
   p.o_split = 0;
+  p.magic_hw = ((1ULL << 40) + p.HW - 1) / p.HW;
+  p.magic_w = ((1ULL << 40) + a->W - 1) / a->W;
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   RAC_REQUIRE(!(a->scale && !a->shift), "rac_conv2d: scale without shift");
 
