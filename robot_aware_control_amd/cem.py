@@ -33,6 +33,9 @@ class CEMPolicy(object):
                                               wx250s_bot=wx250s_bot, push_height=push_height,
                                               default_pitch=default_pitch, default_roll=default_roll,
                                               robot_model=robot_model)
+        self.clamp = 0.05  # real-robot planar displacements (cem.py:85); the sim variants use 1.0
+        self.null_candidate = True  # cem.py:82-83; the sim variants do not force a do-nothing candidate
+        self.gripper_clamp = None  # pick variant: (-0.01, 0) on the last action dim (pick/cem.py:88)
         self.plot_rollouts = cfg.debug_cem
         if self.plot_rollouts:
             self.debug_cem_dir = cfg.log_dir
@@ -64,10 +67,13 @@ class CEMPolicy(object):
         rollouts = {}
         for i in range(self.optimization_iter):
             act_seq = self._sample(mean, std, N, None if noise is None else noise[i])
-            if i == 0:
+            if i == 0 and self.null_candidate:
                 act_seq[-1] = 0  # always keep a "do nothing" candidate (cem.py:82-83)
-            act_seq.clamp_(-0.05, 0.05)
-            padded = torch.cat([act_seq, torch.zeros((N, T - 1, 3))], 2)
+            act_seq.clamp_(-self.clamp, self.clamp)
+            if self.gripper_clamp is not None:
+                act_seq[:, :, -1].clamp_(*self.gripper_clamp)
+            pad = max(0, getattr(self.cfg, "action_dim", 5) - A)
+            padded = torch.cat([act_seq, torch.zeros((N, T - 1, pad))], 2) if pad else act_seq
             last = i == self.optimization_iter - 1
             rollouts = self._get_rollouts(padded, start, goal, opt_traj if last else None,
                                           self.plot_rollouts and last)
@@ -87,3 +93,31 @@ class CEMPolicy(object):
     def _get_rollouts(self, act_seq, start: State, goal: DemoGoalState, opt_traj=None, plot=False):
         return self.traj_sampler.generate_model_rollouts(act_seq, start, goal, ret_obs=self.plot_rollouts,
                                                          opt_traj=opt_traj, suppress_print=True)
+
+
+class SimCEMPolicy(CEMPolicy):
+    """Constructor / clamp conventions of the simulator variants (reference src/cem/push/cem.py:15-104,
+    src/cem/pick/cem.py): `CEMPolicy(cfg, physics="learned", horizon, opt_iter, action_candidates, topk, init_std)`
+    loads the model itself from `cfg.dynamics_model_ckpt` and clamps actions to [-1, 1]; `action_dim` is 2 (push)
+    or 4 (pick).  Only the `physics="learned"` branch runs here -- `"gt"` steps MuJoCo on the CPU and is outside
+    the accelerated path.  Per-candidate masks/states come from `robot_model` (see TrajectorySampler)."""
+
+    def __init__(self, cfg, physics="learned", horizon=5, opt_iter=10, action_candidates=100, topk=5, init_std=1.0,
+                 action_dim=2, robot_model=None, model=None):
+        if physics != "learned":
+            raise NotImplementedError("physics='gt' rolls candidates through MuJoCo on the CPU (reference "
+                                      "src/cem/push/trajectory_sampler.py:60-167); use the reference for that branch")
+        if model is None:
+            from .model import SVGConvModel
+            model = SVGConvModel(cfg)
+            if getattr(cfg, "dynamics_model_ckpt", None):
+                ckpt = torch.load(cfg.dynamics_model_ckpt, map_location=cfg.device)
+                model.load_state_dict(ckpt["model"])
+            model.eval()
+        super().__init__(cfg, model, horizon=horizon, opt_iter=opt_iter, action_candidates=action_candidates,
+                         topk=topk, init_std=init_std, robot_model=robot_model)
+        self.action_dim = action_dim
+        self.clamp = 1.0
+        self.null_candidate = False
+        if action_dim == 4:
+            self.gripper_clamp = (-0.01, 0.0)
