@@ -114,8 +114,13 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
 /* out[b][p][:] = [v0[b] | v1[b] | v2[b] | m0[b][p] | m1[b][p]]   (dynamics.py:591-607,634-640:
  * action / robot-state tiling + channel concat in front of the three input convs) */
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
-                    const float* m0, int32_t c0, const float* m1, int32_t c1, float* out, int32_t B, int32_t HW,
-                    void* stream);
+                    const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
+                    int32_t HW, void* stream); /* `pad` trailing zero channels */
+/* dst[r][0:C] = src[r][0:C], dst[r][C:Cpad] = 0  -- 16-byte aligned rows for the vector-load conv path
+ * (weights of the convs whose channel count is not a multiple of 4: first encoder layer, the three input convs) */
+int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t R, void* stream);
+/* dst[r][0:C] += src[r][0:C]   (src rows are Cpad wide): folds a padded weight gradient back */
+int rac_unpad_add(const float* src, int32_t Cpad, float* dst, int32_t C, int64_t R, void* stream);
 /* dst[m][0:n] = src[m][off:off+n]  (row strides Csrc / n) */
 int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t n, float* dst, int64_t M, void* stream);
 /* out[c] += sum_m x[m][c]   (bias gradients) */
@@ -152,8 +157,8 @@ int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, floa
  * ------------------------------------------------------------------------ */
 /* packed[b][p][:] = [img[b][0..2][p] * (zmask ? 1-zmask[b][p] : 1) | mask[b][0..Cm-1][p]]
  * = zero_robot_region (src/utils/image.py:5-19) + cat([img, mask]) (dynamics.py:578-582), NCHW -> NHWC */
-int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, float* packed, int32_t B,
-                   int32_t HW, void* stream);
+int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, int32_t pad, float* packed,
+                   int32_t B, int32_t HW, void* stream); /* `pad` trailing zero channels */
 /* dimg[b][c][p] = dpacked[b][p][c] * (zmask ? 1-zmask : 1), c < 3 */
 int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,
                     void* stream);

@@ -39,7 +39,9 @@ _SIGS = {
     "rac_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_bwd": [vp, vp, i32, i32, i32, i32, vp],
-    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp],
+    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
+    "rac_pad_rows": [vp, i32, vp, i32, i64, vp],
+    "rac_unpad_add": [vp, i32, vp, i32, i64, vp],
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
     "rac_colsum_acc": [vp, vp, i64, i32, vp],
     "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp],
@@ -50,7 +52,7 @@ _SIGS = {
     "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_reparam_fwd": [vp, vp, vp, vp, i64, vp],
     "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
-    "rac_pack_input": [vp, vp, vp, i32, vp, i32, i32, vp],
+    "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],
     "rac_unpack_grad": [vp, i32, vp, vp, i32, i32, vp],
     "rac_zero_region": [vp, vp, vp, i32, i32, vp],
     "rac_composite_fwd": [vp, vp, vp, i32, i32, vp],

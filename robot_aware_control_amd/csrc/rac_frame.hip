@@ -11,9 +11,9 @@ static inline int grid_for(long work_items) {
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
-__global__ void pack_input_kernel(const float* img, const float* zmask, const float* mask, int Cm, float* packed,
-                                  int B, int HW) {
-  const int C = 3 + Cm;
+__global__ void pack_input_kernel(const float* img, const float* zmask, const float* mask, int Cm, int pad,
+                                  float* packed, int B, int HW) {
+  const int C = 3 + Cm + pad;
   const long n = (long)B * HW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long b = i / HW;
@@ -26,6 +26,7 @@ __global__ void pack_input_kernel(const float* img, const float* zmask, const fl
       o[c] = zero ? v * 0.f : v;
     }
     for (int c = 0; c < Cm; ++c) o[3 + c] = mask[(b * Cm + c) * HW + p];
+    for (int c = 0; c < pad; ++c) o[3 + Cm + c] = 0.f;
   }
 }
 
@@ -277,11 +278,11 @@ using namespace rac;
 
 extern "C" {
 
-int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, float* packed, int32_t B,
-                   int32_t HW, void* stream) {
-  RAC_REQUIRE(img && packed && B > 0 && HW > 0 && Cm >= 0 && (Cm == 0 || mask), "rac_pack_input: bad args");
+int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, int32_t pad, float* packed,
+                   int32_t B, int32_t HW, void* stream) {
+  RAC_REQUIRE(img && packed && B > 0 && HW > 0 && Cm >= 0 && pad >= 0 && (Cm == 0 || mask), "rac_pack_input: bad args");
   hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), img, zmask, mask, Cm,
-                     packed, B, HW);
+                     pad, packed, B, HW);
   return check_launch("rac_pack_input");
 }
 

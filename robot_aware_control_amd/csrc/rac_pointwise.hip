@@ -72,43 +72,34 @@ __global__ void affine_act_kernel1(const float* x, const float* scale, const flo
   }
 }
 
-// Per-channel reductions over M rows: block = 256 threads = (256/TC) row-lanes x TC channel-lanes,
-// TC = min(C,64) channels per block column group; partials combined through LDS then fp64 atomics.
+// Per-channel reductions over M rows.  grid = (row blocks, 64-channel groups), block = 4 row lanes x 64 channel
+// lanes; partials combined through LDS, then one fp64 atomic per (block, channel).
 __global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const float* scale, const float* shift,
                                      const float* mean, const float* invstd, double* sums, long M, int C,
                                      int rows_per_block) {
   __shared__ float s1[256], s2[256];
-  const int TC = C < 64 ? C : 64;
-  const int RL = 256 / TC;
-  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(r_begin + rows_per_block, M);
-  for (int c0 = 0; c0 < C; c0 += TC) {
-    const int c = c0 + cl;
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C && rl < RL) {
-      const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-      for (long r = r_begin + rl; r < r_end; r += RL) {
-        float xv = x[r * C + c];
-        float z = xv * sc + sh;
-        float dz = dy[r * C + c] * (z > 0.f ? 1.f : 0.2f);
-        a1 += dz;
-        a2 += dz * ((xv - mu) * is);
-      }
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C) {
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    for (long r = r_begin + rl; r < r_end; r += 4) {
+      float xv = x[r * C + c];
+      float z = xv * sc + sh;
+      float dz = dy[r * C + c] * (z > 0.f ? 1.f : 0.2f);
+      a1 += dz;
+      a2 += dz * ((xv - mu) * is);
     }
-    s1[threadIdx.x] = a1;
-    s2[threadIdx.x] = a2;
-    __syncthreads();
-    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < RL; ++k) {
-        t1 += s1[k * TC + threadIdx.x];
-        t2 += s2[k * TC + threadIdx.x];
-      }
-      atomicAdd(sums + c0 + threadIdx.x, (double)t1);
-      atomicAdd(sums + C + c0 + threadIdx.x, (double)t2);
-    }
-    __syncthreads();
+  }
+  s1[threadIdx.x] = a1;
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C) {
+    const int t = threadIdx.x;
+    atomicAdd(sums + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
+    atomicAdd(sums + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
   }
 }
 
@@ -217,8 +208,9 @@ __global__ void upsample2_bwd_kernel(const T* dy, T* dx, int B, int h, int w, in
 
 // ------------------------------------------------------------ tiling / slices
 __global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1, const float* v2, int n2,
-                               const float* m0, int c0, const float* m1, int c1, float* out, int B, int HW) {
-  const int Ct = n0 + n1 + n2 + c0 + c1;
+                               const float* m0, int c0, const float* m1, int c1, int pad, float* out, int B, int HW) {
+  const int Cv = n0 + n1 + n2 + c0 + c1;
+  const int Ct = Cv + pad;
   const long n = (long)B * HW * Ct;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % Ct);
@@ -233,9 +225,28 @@ __global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1,
       v = v2[b * n2 + (c - n0 - n1)];
     else if (c < n0 + n1 + n2 + c0)
       v = m0[q * c0 + (c - n0 - n1 - n2)];
-    else
+    else if (c < Cv)
       v = m1[q * c1 + (c - n0 - n1 - n2 - c0)];
+    else
+      v = 0.f;
     out[i] = v;
+  }
+}
+
+__global__ void pad_rows_kernel(const float* src, int C, float* dst, int Cpad, long R) {
+  const long n = R * Cpad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / Cpad;
+    int c = (int)(i - r * Cpad);
+    dst[i] = c < C ? src[r * C + c] : 0.f;
+  }
+}
+__global__ void unpad_add_kernel(const float* src, int Cpad, float* dst, int C, long R) {
+  const long n = R * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long r = i / C;
+    int c = (int)(i - r * C);
+    dst[i] += src[r * Cpad + c];
   }
 }
 
@@ -276,33 +287,24 @@ __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_st
 
 __global__ void col_stats_kernel(const float* x, double* stats, long M, int C, int rows_per_block) {
   __shared__ float s1[256], s2[256];
-  const int TC = C < 64 ? C : 64;
-  const int RL = 256 / TC;
-  const int cl = threadIdx.x % TC, rl = threadIdx.x / TC;
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
   const long r_begin = (long)blockIdx.x * rows_per_block;
   const long r_end = min(r_begin + rows_per_block, M);
-  for (int c0 = 0; c0 < C; c0 += TC) {
-    const int c = c0 + cl;
-    float a1 = 0.f, a2 = 0.f;
-    if (c < C && rl < RL)
-      for (long r = r_begin + rl; r < r_end; r += RL) {
-        float v = x[r * C + c];
-        a1 += v;
-        a2 += v * v;
-      }
-    s1[threadIdx.x] = a1;
-    s2[threadIdx.x] = a2;
-    __syncthreads();
-    if (threadIdx.x < TC && c0 + threadIdx.x < C) {
-      float t1 = 0.f, t2 = 0.f;
-      for (int k = 0; k < RL; ++k) {
-        t1 += s1[k * TC + threadIdx.x];
-        t2 += s2[k * TC + threadIdx.x];
-      }
-      atomicAdd(stats + c0 + threadIdx.x, (double)t1);
-      atomicAdd(stats + C + c0 + threadIdx.x, (double)t2);
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C)
+    for (long r = r_begin + rl; r < r_end; r += 4) {
+      float v = x[r * C + c];
+      a1 += v;
+      a2 += v * v;
     }
-    __syncthreads();
+  s1[threadIdx.x] = a1;
+  s2[threadIdx.x] = a2;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C) {
+    const int t = threadIdx.x;
+    atomicAdd(stats + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
+    atomicAdd(stats + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
   }
 }
 
@@ -450,6 +452,16 @@ int rac_affine_act(const float* x, const float* scale, const float* shift, int32
   return check_launch("rac_affine_act");
 }
 
+// (row blocks, 64-channel groups) with ~1024 workgroups in total and >= 16 rows per block
+static dim3 reduce_grid(long M, int C, int* rows_per_block) {
+  const int cgroups = cdiv(C, 64);
+  long nb = 1024 / cgroups;
+  if (nb < 1) nb = 1;
+  if (nb > (M + 15) / 16) nb = (M + 15) / 16;
+  *rows_per_block = (int)((M + nb - 1) / nb);
+  return dim3(cdiv(M, *rows_per_block), cgroups);
+}
+
 static int rows_per_block_for(long M, int* nblocks) {
   long nb = M / 64;
   if (nb < 1) nb = 1;
@@ -462,9 +474,9 @@ static int rows_per_block_for(long M, int* nblocks) {
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                       const float* invstd, double* sums, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0, "rac_bn_bwd_reduce: bad args");
-  int nb;
-  int rpb = rows_per_block_for(M, &nb);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), 0, ST(stream), dy, x, scale, shift, mean, invstd, sums,
+  int rpb;
+  dim3 grid = reduce_grid(M, C, &rpb);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, x, scale, shift, mean, invstd, sums,
                      (long)M, C, rpb);
   return check_launch("rac_bn_bwd_reduce");
 }
@@ -522,16 +534,30 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
 }
 
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
-                    const float* m0, int32_t c0, const float* m1, int32_t c1, float* out, int32_t B, int32_t HW,
-                    void* stream) {
-  RAC_REQUIRE(out && B > 0 && HW > 0, "rac_tilecat_fwd: bad args");
+                    const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
+                    int32_t HW, void* stream) {
+  RAC_REQUIRE(out && B > 0 && HW > 0 && pad >= 0, "rac_tilecat_fwd: bad args");
   RAC_REQUIRE((n0 == 0 || v0) && (n1 == 0 || v1) && (n2 == 0 || v2) && (c0 == 0 || m0) && (c1 == 0 || m1),
               "rac_tilecat_fwd: null source with non-zero width");
-  long n = (long)B * HW * (n0 + n1 + n2 + c0 + c1);
+  long n = (long)B * HW * (n0 + n1 + n2 + c0 + c1 + pad);
   RAC_REQUIRE(n > 0, "rac_tilecat_fwd: empty");
   hipLaunchKernelGGL(tilecat_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1,
-                     c1, out, B, HW);
+                     c1, pad, out, B, HW);
   return check_launch("rac_tilecat_fwd");
+}
+
+int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t R, void* stream) {
+  RAC_REQUIRE(src && dst && C > 0 && Cpad >= C && R > 0, "rac_pad_rows: bad args");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3(grid_for((long)R * Cpad)), dim3(256), 0, ST(stream), src, C, dst, Cpad,
+                     (long)R);
+  return check_launch("rac_pad_rows");
+}
+
+int rac_unpad_add(const float* src, int32_t Cpad, float* dst, int32_t C, int64_t R, void* stream) {
+  RAC_REQUIRE(src && dst && C > 0 && Cpad >= C && R > 0, "rac_unpad_add: bad args");
+  hipLaunchKernelGGL(unpad_add_kernel, dim3(grid_for((long)R * C)), dim3(256), 0, ST(stream), src, Cpad, dst, C,
+                     (long)R);
+  return check_launch("rac_unpad_add");
 }
 
 int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, float* dst, int64_t M, void* stream) {
@@ -543,13 +569,9 @@ int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, 
 
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(x && out && M > 0 && C > 0, "rac_colsum_acc: bad args");
-  const int cgroups = cdiv(C, 64);
-  long nb = 1024 / cgroups;  // ~1024 workgroups in total
-  if (nb < 1) nb = 1;
-  if (nb > (M + 15) / 16) nb = (M + 15) / 16;
-  const int rpb = (int)((M + nb - 1) / nb);
-  hipLaunchKernelGGL(colsum_acc_kernel, dim3(cdiv(M, rpb), cgroups), dim3(256), 0, ST(stream), x, out, (long)M, C,
-                     rpb);
+  int rpb;
+  dim3 grid = reduce_grid(M, C, &rpb);
+  hipLaunchKernelGGL(colsum_acc_kernel, grid, dim3(256), 0, ST(stream), x, out, (long)M, C, rpb);
   return check_launch("rac_colsum_acc");
 }
 
@@ -572,9 +594,9 @@ int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, f
 
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(x && stats && M > 0 && C > 0, "rac_col_stats: bad args");
-  int nb;
-  int rpb = rows_per_block_for(M, &nb);
-  hipLaunchKernelGGL(col_stats_kernel, dim3(nb), dim3(256), 0, ST(stream), x, stats, (long)M, C, rpb);
+  int rpb;
+  dim3 grid = reduce_grid(M, C, &rpb);
+  hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(stream), x, stats, (long)M, C, rpb);
   return check_launch("rac_col_stats");
 }
 

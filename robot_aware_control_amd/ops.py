@@ -56,6 +56,42 @@ def _cdiv(a, b):
     return (a + b - 1) // b
 
 
+# Convs whose input-channel count is not a multiple of 4 (first encoder layer: 3..7 channels; the three input
+# convs: g + 5..15 (+ z)) run on a zero-padded copy of the weight ([Cout][k][k][Cpad], 16-byte rows) so that they
+# take the vector-load kernel; their inputs are produced already padded (rac_pack_input / rac_tilecat_fwd `pad`).
+PARAM_EPOCH = 0  # bumped by FusedAdam.step(): parameters changed behind torch's version counters
+_PAD_CACHE = {}
+
+
+def pad4(c: int) -> int:
+    return (-c) % 4
+
+
+def padded_weight(weight: torch.Tensor) -> torch.Tensor:
+    """Zero-padded (Cout, Cin + pad, k, k) channels_last copy of `weight`, cached until the parameter changes."""
+    co, ci, k, _ = weight.shape
+    key = weight.data_ptr()
+    tag = (weight._version, PARAM_EPOCH, tuple(weight.shape))
+    hit = _PAD_CACHE.get(key)
+    if hit is not None and hit[0] == tag:
+        return hit[1]
+    cp = ci + pad4(ci)
+    wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
+    _PAD_CACHE[key] = (tag, wp)
+    return wp
+
+
+def wgrad_padded_acc(dy, x0, weight):
+    """weight.grad += unpad(dW_pad) for a conv that ran on a padded weight / padded input x0."""
+    co, ci, k, _ = weight.shape
+    cp = x0.shape[3]
+    gp = torch.zeros((co, k, k, cp), device=dy.device, dtype=torch.float32).permute(0, 3, 1, 2)
+    B, H, W, Cout = dy.shape
+    conv_raw(WGRAD, x0, None, dy, gp, B=B, H=H, W=W, ksize=k, Cin=cp, Cout=Cout, a_split=cp, accumulate=1, split_k=0)
+    call("rac_unpad_add", ptr(gp), cp, ptr(weight_mem(grad_buffer(weight))), ci, co * k * k, stream_ptr())
+
+
 def plan_split_k(M: int, N: int, nchunks: int) -> int:
     """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
     choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
@@ -191,13 +227,16 @@ def bias_grad_acc(dy, bias):
 # --------------------------------------------------------------------------- #
 class ConvBias(torch.autograd.Function):
     """Conv(k x k, same) + bias over [x0 | x1]; optional sigmoid epilogue.  (nn.Conv2d with bias:
-    reference dynamics.py:496-513, lstm.py:273-274.)"""
+    reference dynamics.py:496-513, lstm.py:273-274.)  If the weight's Cin is not a multiple of 4, x0 must
+    carry the zero pad channels (see `padded_weight`)."""
 
     @staticmethod
     def forward(ctx, x0, x1, weight, bias, act):
-        y = conv_forward(x0, x1, weight, bias, act=act, allow_split=(act == ACT_NONE))
+        padded = weight.shape[1] % 4 != 0 and x1 is None and x0.shape[3] == weight.shape[1] + pad4(weight.shape[1])
+        w = padded_weight(weight) if padded else weight
+        y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
         ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
-        ctx.act = act
+        ctx.act, ctx.padded = act, padded
         return y
 
     @staticmethod
@@ -212,9 +251,12 @@ class ConvBias(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dx0, dx1 = conv_dgrad(dy, weight, C0, C1)
+            dx0, dx1 = conv_dgrad(dy, padded_weight(weight) if ctx.padded else weight, C0, C1)
         if weight.requires_grad:
-            conv_wgrad_acc(dy, x0, x1, weight)
+            if ctx.padded:
+                wgrad_padded_acc(dy, x0, weight)
+            else:
+                conv_wgrad_acc(dy, x0, x1, weight)
         if bias is not None and bias.requires_grad:
             bias_grad_acc(dy, bias)
         return dx0, dx1, None, None, None
@@ -267,6 +309,10 @@ class VggLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, rmean, rvar, training, n_updates, folded):
         Cout = weight.shape[0]
+        padded = weight.shape[1] % 4 != 0 and x1 is None and x0.shape[3] == weight.shape[1] + pad4(weight.shape[1])
+        ctx.padded = padded
+        wfull, weight_used = weight, (padded_weight(weight) if padded else weight)
+        weight = weight_used
         if not training:
             scale, shift = folded
             y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
@@ -281,7 +327,7 @@ class VggLayer(torch.autograd.Function):
              n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, stream_ptr())
         y = torch.empty_like(raw)
         call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, stream_ptr())
-        ctx.save_for_backward(x0, x1, weight, gamma, beta, raw, aff)
+        ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
         return y
 
     @staticmethod
@@ -302,9 +348,12 @@ class VggLayer(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dx0, dx1 = conv_dgrad(draw, weight, C0, C1)
+            dx0, dx1 = conv_dgrad(draw, padded_weight(weight) if ctx.padded else weight, C0, C1)
         if weight.requires_grad:
-            conv_wgrad_acc(draw, x0, x1, weight)
+            if ctx.padded:
+                wgrad_padded_acc(draw, x0, weight)
+            else:
+                conv_wgrad_acc(draw, x0, x1, weight)
         return dx0, dx1, None, None, None, None, None, None, None, None
 
 
@@ -344,8 +393,8 @@ class Upsample2(torch.autograd.Function):
 
 
 class TileCat(torch.autograd.Function):
-    """[tile(v0) | tile(v1) | tile(v2) | m0 | m1] along channels (dynamics.py:591-607,634-640).
-    Gradients flow to the maps only (actions / robot states are data)."""
+    """[tile(v0) | tile(v1) | tile(v2) | m0 | m1 | 0-pad to a multiple of 4] along channels
+    (dynamics.py:591-607,634-640).  Gradients flow to the maps only (actions / robot states are data)."""
 
     @staticmethod
     def forward(ctx, v0, v1, v2, m0, m1):
@@ -354,8 +403,10 @@ class TileCat(torch.autograd.Function):
         vs += [None] * (3 - len(vs))
         ns = [v.shape[1] if v is not None else 0 for v in vs]
         c1 = m1.shape[3] if m1 is not None else 0
-        out = torch.empty((B, H, W, sum(ns) + c0 + c1), device=m0.device, dtype=torch.float32)
-        call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1,
+        ct = sum(ns) + c0 + c1
+        pad = pad4(ct)
+        out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
+        call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
              ptr(out), B, H * W, stream_ptr())
         ctx.meta = (sum(ns), c0, c1)
         return out
@@ -434,16 +485,18 @@ class Reparam(torch.autograd.Function):
 
 
 class PackInput(torch.autograd.Function):
-    """planes -> map: cat([img * (1 - zero_mask), mask], C) as NHWC (dynamics.py:578-582 + utils/image.py:5-19)."""
+    """planes -> map: cat([img * (1 - zero_mask), mask, 0-pad to a multiple of 4], C) as NHWC
+    (dynamics.py:578-582 + utils/image.py:5-19)."""
 
     @staticmethod
     def forward(ctx, img, zero_mask, mask):
         B, _, H, W = img.shape
         Cm = mask.shape[1] if mask is not None else 0
-        out = torch.empty((B, H, W, 3 + Cm), device=img.device, dtype=torch.float32)
-        call("rac_pack_input", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(out), B, H * W, stream_ptr())
+        pad = pad4(3 + Cm)
+        out = torch.empty((B, H, W, 3 + Cm + pad), device=img.device, dtype=torch.float32)
+        call("rac_pack_input", ptr(img), ptr(zero_mask), ptr(mask), Cm, pad, ptr(out), B, H * W, stream_ptr())
         ctx.save_for_backward(zero_mask)
-        ctx.C = 3 + Cm
+        ctx.C = 3 + Cm + pad
         return out
 
     @staticmethod

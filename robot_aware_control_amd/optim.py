@@ -6,7 +6,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 
 
 class FusedAdam(torch.optim.Optimizer):
@@ -31,6 +31,7 @@ class FusedAdam(torch.optim.Optimizer):
         m, v = self._moments()
         g = self.param_groups[0]
         self._steps += 1
+        ops.PARAM_EPOCH += 1  # invalidates caches derived from the parameters (padded weight copies)
         _lib.call("rac_adam_step", flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(),
                   float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._steps,
                   _lib.stream_ptr())

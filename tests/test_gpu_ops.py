@@ -219,9 +219,10 @@ def test_pool_upsample_tilecat(dev):
     gy = rnd(9, *ref.shape)
     ref.backward(gy)
     hd, zd = to_map(hmap.detach(), dev).requires_grad_(True), to_map(zmap.detach(), dev).requires_grad_(True)
-    out = ops.TileCat.apply(a.to(dev), r.to(dev), None, hd, zd)
-    assert torch.equal(from_map(out), ref.detach())
-    out.backward(to_map(gy, dev))
+    out = ops.TileCat.apply(a.to(dev), r.to(dev), None, hd, zd)  # 22 channels + 2 zero pad channels
+    assert out.shape[3] == 24 and float(out[..., 22:].abs().max()) == 0.0
+    assert torch.equal(from_map(out)[:, :22], ref.detach())
+    out.backward(torch.cat([to_map(gy, dev), torch.zeros(B, 8, 8, 2, device=dev)], 3))
     assert torch.equal(from_map(hd.grad), hmap.grad) and torch.equal(from_map(zd.grad), zmap.grad)
 
 
@@ -268,9 +269,10 @@ def test_frame_ops_and_losses(dev, golden_dir):
     gy = rnd(7, *ref.shape)
     ref.backward(gy)
     imgd = img.detach().to(dev).requires_grad_(True)
-    out = ops.PackInput.apply(imgd, m.to(dev), m2.to(dev))
-    assert torch.equal(from_map(out), ref.detach())
-    out.backward(to_map(gy, dev))
+    out = ops.PackInput.apply(imgd, m.to(dev), m2.to(dev))  # 5 channels + 3 zero pad channels
+    assert out.shape[3] == 8 and float(out[..., 5:].abs().max()) == 0.0
+    assert torch.equal(from_map(out)[:, :5], ref.detach())
+    out.backward(torch.cat([to_map(gy, dev), torch.zeros(2, 16, 16, 3, device=dev)], 3))
     assert torch.equal(imgd.grad.cpu(), img.grad)
 
     mu, lv, eps = [rnd(i, 2, 8, 8, 4).to(dev).requires_grad_(i < 12) for i in (10, 11, 12)]
