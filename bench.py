@@ -83,6 +83,23 @@ def max_over_ranks(x, dev, distributed):
     return float(t.item())
 
 
+def pmc_traffic(tag, kernel_substr, workgroups):
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC profile
+    (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        rows = json.load(open(files[-1])).get(tag, [])
+    except (OSError, ValueError):
+        return None, None
+    for r in rows:
+        if kernel_substr in r["kernel"] and r["workgroups"] == workgroups:
+            return r["hbm_side_bytes_per_launch"], os.path.relpath(files[-1], ROOT)
+    return None, None
+
+
 def profile_summary(prof, flops_per_pixel_row):
     """Average HIP-event duration of the profiled kernel and its algorithmic FLOP rate."""
     if not prof["events"]:
@@ -242,9 +259,11 @@ def main():
                            "global_batch": train["global_batch"], "parallelism": f"ddp{world}",
                            "algorithmic_tflop_per_step_per_gpu": 8.70})
         k = train["kernel"]
+        traffic, traffic_src = pmc_traffic("train", "igemm_fast_kernel<0, 128, 128", 512)
         out["roofline"] = {"bound": "mfma", "kernel": "igemm FWD 5x5 ConvLSTM gate GEMM (M=1024,N=2048,K=25600)",
                            "achieved": k["tflops"], "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": k["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                           "frac": k["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                           "traffic_source": traffic_src,
                            "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                            "step_achieved": train["step_tflops_per_gpu"],
                            "step_frac": train["step_tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS}

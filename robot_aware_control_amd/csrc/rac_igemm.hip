@@ -745,6 +745,8 @@ static int launch_mode(ConvP& p, hipStream_t st, bool av, bool bv) {
     bm = bn = 64;
   } else if (gn <= 32) {
     bm = 128, bn = 32;
+  } else if (gn <= 64 && gm >= 128 * 256) {  // 64-channel layers at full resolution: tall tile, 2 accumulators / wave
+    bm = 128, bn = 64;
   } else {
     long t128 = (long)cdiv(gm, 128) * cdiv(gn, 128) * tapmul;
     if (gm >= 128 && gn >= 128 && t128 * (p.split_k > 0 ? p.split_k : 1) >= 192)
@@ -774,10 +776,12 @@ static int launch_mode(ConvP& p, hipStream_t st, bool av, bool bv) {
   }
   if (fast) {
     if (bn == 32) return launch_fast<MODE, 128, 32, 4, 1>(p, grid, st);
+    if (bm == 128 && bn == 64) return launch_fast<MODE, 128, 64, 2, 2>(p, grid, st);
     if (bm == 128) return launch_fast<MODE, 128, 128, 2, 2>(p, grid, st);
     return launch_fast<MODE, 64, 64, 2, 2>(p, grid, st);
   }
   if (bn == 32) return launch_vec<MODE, 128, 32, 4, 1>(p, grid, st, av, bv);
+  if (bm == 128 && bn == 64) return launch_vec<MODE, 128, 64, 2, 2>(p, grid, st, av, bv);
   if (bm == 128) return launch_vec<MODE, 128, 128, 2, 2>(p, grid, st, av, bv);
   return launch_vec<MODE, 64, 64, 2, 2>(p, grid, st, av, bv);
 }
