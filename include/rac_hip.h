@@ -148,6 +148,27 @@ int rac_lstm_cell_fwd(const float* gate_slabs, int32_t n_slabs, int64_t slab_str
 int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev,
                       const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, void* stream);
 
+/* ------------------------------------------------------------------------ *
+ * NormConvLSTMCell (--lstm_group_norm True, lstm.py:151-198): GroupNorm(16, C) on NHWC maps and the
+ * cell arithmetic split around the cell-state normalisation.
+ * ------------------------------------------------------------------------ */
+/* y = (x - mean_{b,g}) * rstd_{b,g} * gamma_c + beta_c over groups of C/G channels x HW pixels (biased variance,
+ * eps); mean/rstd = fp32 [B][G] saved for the backward pass. */
+int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int32_t B, int32_t HW, int32_t C, int32_t G, float eps, void* stream);
+/* dx; dgamma += sum dy*xhat; dbeta += sum dy  (dgamma/dbeta may be NULL together) */
+int rac_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, float* dgamma, float* dbeta, int32_t B, int32_t HW, int32_t C, int32_t G,
+                      void* stream);
+/* h = o * tanh(c) with o = act[m][2g + c]  (lstm.py:196); backward: d_act [M][4g] (only the o slot non-zero), dc */
+int rac_lstm_out_fwd(const float* act, const float* c, float* h, int64_t M, int32_t g, void* stream);
+int rac_lstm_out_bwd(const float* dh, const float* act, const float* c, float* d_act, float* dc, int64_t M, int32_t g,
+                     void* stream);
+/* gate pre-activation gradients of the split cell: dc_raw (gradient of the un-normalised cell f*c_prev + i*g) and
+ * d_act (gradient of the activated gates [M][4g], may be NULL) -> dgates [M][4g], dc_prev [M][g] */
+int rac_lstm_core_bwd(const float* dc_raw, const float* d_act, const float* act, const float* c_prev, float* dgates,
+                      float* dc_prev, int64_t M, int32_t g, void* stream);
+
 /* z = eps*exp(0.5*logvar) + mu (lstm.py:276-279); dlogvar = dz*eps*0.5*exp(0.5*logvar) */
 int rac_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);
 int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, float* dlogvar, int64_t n, void* stream);

@@ -270,6 +270,45 @@ CEM_GAIN = 200.0
 CEM_SEED = {"vanilla": 5, "ra": 4}
 
 
+def gen_groupnorm():
+    """NormConvLSTMCell (--lstm_group_norm True): two eval forwards + one train step."""
+    from src.prediction.trainer import PredictionTrainer
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, lstm_group_norm=True,
+                  **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=11)
+    data = syn.synth_video(seed=3, T=3, B=2)
+    eps = syn.synth_eps(seed=5, steps=2, B=2, z=16, h=8, w=8)
+    m = ref_model(cfg, sd)
+    m.init_hidden(2)
+    out = {}
+    with torch.no_grad():
+        x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1)
+        _EPS.extend([eps[0][0], eps[0][1]])
+        o = m(x_j, m_in, r, None, a, x_i, m_next, r_i, None, None)
+        out["s1_x_pred"], out["s1_mu"], out["s1_logvar_p"] = o[0], o[2], o[5]
+        x_j, m_in, r, a, _, _, _ = step_inputs(cfg, data, 2)
+        _EPS.extend([eps[1][0]])
+        o = m.forward(x_j, m_in, r, None, a, sample_mean=True)
+        out["s2_x_pred"], out["s2_mu_p"] = o[0], o[4]
+    ns = ns_for(cfg, wandb=False, jobname="g", wandb_project="x", wandb_entity="x", wandb_group=None,
+                wandb_job_type=None, img_augmentation=False, seed=0, scheduled_sampling_k=4000,
+                learned_robot_model=False)
+    tr = PredictionTrainer(ns)
+    sd2 = orc.make_weights(cfg, seed=12, randomize_bn_stats=False)
+    tr.model.load_state_dict({k: v.clone() for k, v in sd2.items()})
+    tr.model.train()
+    tr._step = 0
+    for e in syn.synth_eps(seed=40, steps=2, B=2, z=16, h=8, w=8):
+        _EPS.extend(e)
+    losses = tr._train_step(syn.synth_video(seed=20, T=3, B=2))
+    for k, v in losses.items():
+        out[f"train_{k}"] = v
+    grads = dict(tr.model.named_parameters())
+    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    out["train_grad_norms"] = np.array([grads[k].grad.double().norm().item() for k in pk])
+    save("groupnorm_ra", **out)
+
+
 class _FakeRobotModel:
     def __init__(self, states, masks):
         self.states, self.masks = states, masks
@@ -351,7 +390,7 @@ def gen_cem():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem"]
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm"]
     if "forward" in which:
         gen_forward()
     if "shape" in which:
@@ -362,3 +401,5 @@ if __name__ == "__main__":
         gen_train()
     if "cem" in which:
         gen_cem()
+    if "groupnorm" in which:
+        gen_groupnorm()

@@ -129,11 +129,21 @@ def _vgg_entries(prefix: str, cin: int, cout: int):
     ]
 
 
-def _lstm_entries(prefix: str, g: int):
+def _lstm_entries(prefix: str, g: int, group_norm: bool = False):
     out = []
     for i, k in enumerate((5, 3)):  # lstm.py:207-212
-        out.append((f"{prefix}.lstm.{i}.gates.weight", (4 * g, 2 * g, k, k), "conv_w"))
-        out.append((f"{prefix}.lstm.{i}.gates.bias", (4 * g,), "conv_b"))
+        base = f"{prefix}.lstm.{i}"
+        if group_norm:  # NormConvLSTMCell (lstm.py:163-172)
+            for part in ("ih_gates", "hh_gates"):
+                out.append((f"{base}.{part}.0.weight", (4 * g, g, k, k), "conv_w"))
+                out.append((f"{base}.{part}.0.bias", (4 * g,), "conv_b"))
+                out.append((f"{base}.{part}.1.weight", (4 * g,), "bn_w"))
+                out.append((f"{base}.{part}.1.bias", (4 * g,), "bn_b"))
+            out.append((f"{base}.c_norm.weight", (g,), "bn_w"))
+            out.append((f"{base}.c_norm.bias", (g,), "bn_b"))
+        else:
+            out.append((f"{base}.gates.weight", (4 * g, 2 * g, k, k), "conv_w"))
+            out.append((f"{base}.gates.bias", (4 * g,), "conv_b"))
     return out
 
 
@@ -148,13 +158,13 @@ def param_spec(cfg: Cfg) -> List[Tuple[str, Tuple[int, ...], str]]:
             spec += _vgg_entries(f"encoder.{name}.{i}", chans[i], chans[i + 1])
     spec.append(("frame_pred_input_conv.weight", (g, cfg.lstm_in_channels(), 3, 3), "conv_w"))
     spec.append(("frame_pred_input_conv.bias", (g,), "conv_b"))
-    spec += _lstm_entries("frame_predictor", g)
+    spec += _lstm_entries("frame_predictor", g, cfg.lstm_group_norm)
     spec.append(("posterior_input_conv.weight", (g, cfg.post_in_channels(), 3, 3), "conv_w"))
     spec.append(("posterior_input_conv.bias", (g,), "conv_b"))
     spec.append(("prior_input_conv.weight", (g, cfg.prior_in_channels(), 3, 3), "conv_w"))
     spec.append(("prior_input_conv.bias", (g,), "conv_b"))
     for nm in ("posterior", "prior"):
-        spec += _lstm_entries(nm, g)
+        spec += _lstm_entries(nm, g, cfg.lstm_group_norm)
         for head in ("mu_net", "logvar_net"):  # lstm.py:273-274
             spec.append((f"{nm}.{head}.weight", (z, g, 3, 3), "conv_w"))
             spec.append((f"{nm}.{head}.bias", (z,), "conv_b"))
@@ -185,7 +195,7 @@ def make_weights(cfg: Cfg, seed: int = 0, action_gain: float = 1.0,
         rng = np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), seed]))
         if kind in ("conv_w", "convT_w"):
             fan_in = int(np.prod(shape[1:])) if kind == "conv_w" else shape[0] * shape[2] * shape[3]
-            std = math.sqrt(1.0 / fan_in) if ".gates." in key else math.sqrt(2.0 / fan_in)
+            std = math.sqrt(1.0 / fan_in) if "gates." in key else math.sqrt(2.0 / fan_in)
             if "mu_net" in key or "logvar_net" in key:
                 std = 0.5 * math.sqrt(1.0 / fan_in)
             w = rng.standard_normal(shape, dtype=np.float32) * np.float32(std)
@@ -270,10 +280,26 @@ def convlstm_cell(sd, prefix: str, layer: int, x: Tensor, state: Tuple[Tensor, T
     return h, c
 
 
+def norm_convlstm_cell(sd, prefix: str, layer: int, x: Tensor, state: Tuple[Tensor, Tensor]):
+    """NormConvLSTMCell.forward (lstm.py:174-198)."""
+    h_prev, c_prev = state
+    pad = 2 if layer == 0 else 1
+    base = f"{prefix}.lstm.{layer}"
+    ih = F.group_norm(F.conv2d(x, sd[f"{base}.ih_gates.0.weight"], sd[f"{base}.ih_gates.0.bias"], 1, pad), 16,
+                      sd[f"{base}.ih_gates.1.weight"], sd[f"{base}.ih_gates.1.bias"])
+    hh = F.group_norm(F.conv2d(h_prev, sd[f"{base}.hh_gates.0.weight"], sd[f"{base}.hh_gates.0.bias"], 1, pad), 16,
+                      sd[f"{base}.hh_gates.1.weight"], sd[f"{base}.hh_gates.1.bias"])
+    gi, gf, go, gg = (ih + hh).chunk(4, 1)
+    c = torch.sigmoid(gf) * c_prev + torch.sigmoid(gi) * torch.tanh(gg)
+    c = F.group_norm(c, 16, sd[f"{base}.c_norm.weight"], sd[f"{base}.c_norm.bias"])
+    return torch.sigmoid(go) * torch.tanh(c), c
+
+
 def convlstm(sd, prefix: str, x: Tensor, hidden: List[Tuple[Tensor, Tensor]]) -> Tensor:
     """ConvLSTM.forward (lstm.py:252-257); mutates `hidden` in place."""
+    cell = norm_convlstm_cell if f"{prefix}.lstm.0.c_norm.weight" in sd else convlstm_cell
     for i in range(2):
-        hidden[i] = convlstm_cell(sd, prefix, i, x, hidden[i])
+        hidden[i] = cell(sd, prefix, i, x, hidden[i])
         x = hidden[i][0]
     return x
 

@@ -50,6 +50,11 @@ _SIGS = {
     "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "rac_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],
+    "rac_lstm_out_bwd": [vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_lstm_core_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_reparam_fwd": [vp, vp, vp, vp, i64, vp],
     "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
     "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],

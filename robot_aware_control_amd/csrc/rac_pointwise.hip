@@ -652,3 +652,182 @@ int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ GroupNorm / NormConvLSTMCell pieces
+namespace rac {
+
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// grid (G, B), 256 threads: one (sample, group) per workgroup; the group is HW rows of Cg contiguous channels.
+__global__ void groupnorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y, float* mean_o,
+                                     float* rstd_o, int HW, int C, int G, float eps) {
+  __shared__ float sh[4];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int Cg = C / G;
+  const int n = HW * Cg;
+  const float* xb = x + (long)b * HW * C + g * Cg;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += xb[(long)(i / Cg) * C + (i % Cg)];
+  const float mean = block_sum256(s, sh) / n;
+  float q = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float d = xb[(long)(i / Cg) * C + (i % Cg)] - mean;
+    q += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(block_sum256(q, sh) / n + eps);
+  float* yb = y + (long)b * HW * C + g * Cg;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % Cg;
+    const long o = (long)(i / Cg) * C + c;
+    yb[o] = (xb[o] - mean) * rstd * gamma[g * Cg + c] + beta[g * Cg + c];
+  }
+  if (threadIdx.x == 0) {
+    mean_o[b * G + g] = mean;
+    rstd_o[b * G + g] = rstd;
+  }
+}
+
+__global__ void groupnorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean_i,
+                                     const float* rstd_i, float* dx, float* dgamma, float* dbeta, int HW, int C,
+                                     int G) {
+  __shared__ float sh[4];
+  extern __shared__ float chan[];  // [2][Cg] per-channel partials of dgamma / dbeta
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int Cg = C / G;
+  const int n = HW * Cg;
+  const float mean = mean_i[b * G + g], rstd = rstd_i[b * G + g];
+  const long base = (long)b * HW * C + g * Cg;
+  for (int i = threadIdx.x; i < 2 * Cg; i += 256) chan[i] = 0.f;
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % Cg;
+    const long o = base + (long)(i / Cg) * C + c;
+    const float xh = (x[o] - mean) * rstd;
+    const float d = dy[o];
+    const float dg = d * gamma[g * Cg + c];
+    s1 += dg;
+    s2 += dg * xh;
+    if (dgamma) {
+      atomicAdd(&chan[c], d * xh);
+      atomicAdd(&chan[Cg + c], d);
+    }
+  }
+  const float m1 = block_sum256(s1, sh) / n;
+  const float m2 = block_sum256(s2, sh) / n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % Cg;
+    const long o = base + (long)(i / Cg) * C + c;
+    const float xh = (x[o] - mean) * rstd;
+    dx[o] = rstd * (dy[o] * gamma[g * Cg + c] - m1 - xh * m2);
+  }
+  if (dgamma) {
+    __syncthreads();
+    for (int c = threadIdx.x; c < Cg; c += 256) {
+      atomicAdd(dgamma + g * Cg + c, chan[c]);
+      atomicAdd(dbeta + g * Cg + c, chan[Cg + c]);
+    }
+  }
+}
+
+__global__ void lstm_out_fwd_kernel(const float* act, const float* c, float* h, long M, int g) {
+  const long n = M * g;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / g;
+    int ch = (int)(i - m * g);
+    h[i] = act[m * 4 * g + 2 * g + ch] * tanhf(c[i]);
+  }
+}
+__global__ void lstm_out_bwd_kernel(const float* dh, const float* act, const float* c, float* d_act, float* dc, long M,
+                                    int g) {
+  const long n = M * g;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / g;
+    int ch = (int)(i - m * g);
+    const float tc = tanhf(c[i]), o = act[m * 4 * g + 2 * g + ch], d = dh[i];
+    float* da = d_act + m * 4 * g + ch;  // gradient w.r.t. the activated gates: only the o slot is non-zero
+    da[0] = 0.f;
+    da[g] = 0.f;
+    da[2 * g] = d * tc;
+    da[3 * g] = 0.f;
+    dc[i] = d * o * (1.f - tc * tc);
+  }
+}
+__global__ void lstm_core_bwd_kernel(const float* dc_raw, const float* d_act, const float* act, const float* c_prev,
+                                     float* dgates, float* dc_prev, long M, int g) {
+  const long n = M * g;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / g;
+    int ch = (int)(i - m * g);
+    const float* a = act + m * 4 * g + ch;
+    const float gi = a[0], gf = a[g], go = a[2 * g], gg = a[3 * g];
+    const float dc = dc_raw ? dc_raw[i] : 0.f;
+    float di = dc * gg, df = dc * c_prev[i], dov = 0.f, dg = dc * gi;
+    if (d_act) {  // direct gradients on the activated gates (the o slot from h = o * tanh(norm(c)))
+      const float* e = d_act + m * 4 * g + ch;
+      di += e[0], df += e[g], dov += e[2 * g], dg += e[3 * g];
+    }
+    float* d = dgates + m * 4 * g + ch;
+    d[0] = di * gi * (1.f - gi);
+    d[g] = df * gf * (1.f - gf);
+    d[2 * g] = dov * go * (1.f - go);
+    d[3 * g] = dg * (1.f - gg * gg);
+    dc_prev[i] = dc * gf;
+  }
+}
+
+}  // namespace rac
+
+extern "C" {
+
+int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int32_t B, int32_t HW, int32_t C, int32_t G, float eps, void* stream) {
+  RAC_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0,
+              "rac_groupnorm_fwd: bad args (C must be divisible by G)");
+  hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(G, B), dim3(256), 0, ST(stream), x, gamma, beta, y, mean, rstd, HW, C,
+                     G, eps);
+  return check_launch("rac_groupnorm_fwd");
+}
+
+int rac_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, float* dgamma, float* dbeta, int32_t B, int32_t HW, int32_t C, int32_t G,
+                      void* stream) {
+  RAC_REQUIRE(dy && x && gamma && mean && rstd && dx && B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0,
+              "rac_groupnorm_bwd: bad args");
+  RAC_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rac_groupnorm_bwd: dgamma/dbeta must come together");
+  const size_t lds = 2 * (size_t)(C / G) * sizeof(float);
+  RAC_REQUIRE(lds <= 48 * 1024, "rac_groupnorm_bwd: group too wide");
+  hipLaunchKernelGGL(groupnorm_bwd_kernel, dim3(G, B), dim3(256), lds, ST(stream), dy, x, gamma, mean, rstd, dx,
+                     dgamma, dbeta, HW, C, G);
+  return check_launch("rac_groupnorm_bwd");
+}
+
+int rac_lstm_out_fwd(const float* act, const float* c, float* h, int64_t M, int32_t g, void* stream) {
+  RAC_REQUIRE(act && c && h && M > 0 && g > 0, "rac_lstm_out_fwd: bad args");
+  hipLaunchKernelGGL(lstm_out_fwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), act, c, h, (long)M, g);
+  return check_launch("rac_lstm_out_fwd");
+}
+
+int rac_lstm_out_bwd(const float* dh, const float* act, const float* c, float* d_act, float* dc, int64_t M, int32_t g,
+                     void* stream) {
+  RAC_REQUIRE(dh && act && c && d_act && dc && M > 0 && g > 0, "rac_lstm_out_bwd: bad args");
+  hipLaunchKernelGGL(lstm_out_bwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), dh, act, c, d_act, dc,
+                     (long)M, g);
+  return check_launch("rac_lstm_out_bwd");
+}
+
+int rac_lstm_core_bwd(const float* dc_raw, const float* d_act, const float* act, const float* c_prev, float* dgates,
+                      float* dc_prev, int64_t M, int32_t g, void* stream) {
+  RAC_REQUIRE(act && c_prev && dgates && dc_prev && M > 0 && g > 0, "rac_lstm_core_bwd: bad args");
+  hipLaunchKernelGGL(lstm_core_bwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), dc_raw, d_act, act,
+                     c_prev, dgates, dc_prev, (long)M, g);
+  return check_launch("rac_lstm_core_bwd");
+}
+
+}  // extern "C"

@@ -131,9 +131,47 @@ class _Decoder(nn.Module):
 
 
 class _LstmCell(nn.Module):
+    """ConvLSTMCell (lstm.py:109-149)."""
+
     def __init__(self, g, k):
         super().__init__()
         self.gates = _Conv(2 * g, 4 * g, k)
+
+    def forward(self, x, state):
+        return ops.LstmCell.apply(x, state[0], state[1], self.gates.weight, self.gates.bias)
+
+
+class _GroupNorm(nn.Module):
+    """Holder with nn.GroupNorm's parameter names (default init ones / zeros: init_weights skips it)."""
+
+    def __init__(self, groups, c):
+        super().__init__()
+        self.groups = groups
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+    def forward(self, x):
+        return ops.GroupNorm.apply(x, self.weight, self.bias, self.groups)
+
+
+class _NormLstmCell(nn.Module):
+    """NormConvLSTMCell (lstm.py:151-198, `--lstm_group_norm True`): separate input / hidden gate convs, each
+    followed by GroupNorm(16, 4g); GroupNorm(16, g) on the cell state."""
+
+    def __init__(self, g, k):
+        super().__init__()
+        self.ih_gates = nn.ModuleList([_Conv(g, 4 * g, k), _GroupNorm(16, 4 * g)])
+        self.hh_gates = nn.ModuleList([_Conv(g, 4 * g, k), _GroupNorm(16, 4 * g)])
+        self.c_norm = _GroupNorm(16, g)
+
+    def forward(self, x, state):
+        h_prev, c_prev = state
+        ci, ch = self.ih_gates[0], self.hh_gates[0]
+        g_ih = self.ih_gates[1](ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE))
+        g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE))
+        c_raw, act = ops.NormCellCore.apply(g_ih, g_hh, c_prev)
+        c = self.c_norm(c_raw)
+        return ops.LstmOut.apply(act, c), c
 
 
 class _ConvLSTM(nn.Module):
@@ -141,25 +179,23 @@ class _ConvLSTM(nn.Module):
 
     def __init__(self, config, g):
         super().__init__()
-        if getattr(config, "lstm_group_norm", False):
-            raise NotImplementedError("--lstm_group_norm True (NormConvLSTMCell, lstm.py:151-198) is not built yet")
+        Cell = _NormLstmCell if getattr(config, "lstm_group_norm", False) else _LstmCell
         self.hid_ch = g
-        self.lstm = nn.ModuleList([_LstmCell(g, 5), _LstmCell(g, 3)])
+        self.lstm = nn.ModuleList([Cell(g, 5), Cell(g, 3)])
         self.batch_size = config.batch_size
         self._hw = (config.image_height // 8, config.image_width // 8)
         self.hidden = None
 
     def init_hidden(self, batch_size=None):
         b = self.batch_size if batch_size is None else batch_size
-        dev = self.lstm[0].gates.weight.device
+        dev = next(self.parameters()).device
         h, w = self._hw
         return [(torch.zeros(b, h, w, self.hid_ch, device=dev), torch.zeros(b, h, w, self.hid_ch, device=dev))
                 for _ in self.lstm]
 
     def forward(self, x):
         for i, cell in enumerate(self.lstm):
-            h_prev, c_prev = self.hidden[i]
-            self.hidden[i] = ops.LstmCell.apply(x, h_prev, c_prev, cell.gates.weight, cell.gates.bias)
+            self.hidden[i] = cell(x, self.hidden[i])
             x = self.hidden[i][0]
         return x
 

@@ -465,6 +465,87 @@ class LstmCell(torch.autograd.Function):
         return dx, dh_prev, dc_prev, None, None
 
 
+class GroupNorm(torch.autograd.Function):
+    """nn.GroupNorm(G, C) on an NHWC map (lstm.py:165-172), eps 1e-5."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G):
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty((2, B, G), device=x.device, dtype=torch.float32)
+        call("rac_groupnorm_fwd", ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stat[0]), ptr(stat[1]), B, H * W, Cc, G,
+             1e-5, stream_ptr())
+        ctx.save_for_backward(x, gamma, beta, stat)
+        ctx.G = G
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stat = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dx = torch.empty_like(x)
+        want = gamma.requires_grad
+        call("rac_groupnorm_bwd", ptr(dy.contiguous()), ptr(x), ptr(gamma), ptr(stat[0]), ptr(stat[1]), ptr(dx),
+             ptr(grad_buffer(gamma)) if want else None, ptr(grad_buffer(beta)) if want else None, B, H * W, Cc,
+             ctx.G, stream_ptr())
+        return dx, None, None, None
+
+
+class NormCellCore(torch.autograd.Function):
+    """Gate activations and the un-normalised cell of NormConvLSTMCell (lstm.py:178-193):
+    (g_ih + g_hh) -> i,f,o = sigmoid, g = tanh; c_raw = f*c_prev + i*g.  Returns (c_raw, act [.,4g])."""
+
+    @staticmethod
+    def forward(ctx, g_ih, g_hh, c_prev):
+        B, H, W, g4 = g_ih.shape
+        g = g4 // 4
+        M = B * H * W
+        two = torch.stack([g_ih, g_hh]) if (g_hh.data_ptr() - g_ih.data_ptr()) % 4 else None
+        base = two if two is not None else g_ih
+        stride = M * g4 if two is not None else (g_hh.data_ptr() - g_ih.data_ptr()) // 4
+        zero_bias = torch.zeros(g4, device=g_ih.device)
+        c_raw = torch.empty_like(c_prev)
+        h_unused = torch.empty_like(c_prev)
+        act = torch.empty((B, H, W, g4), device=g_ih.device, dtype=torch.float32)
+        call("rac_lstm_cell_fwd", ptr(base), 2, stride, ptr(zero_bias), ptr(c_prev), ptr(h_unused), ptr(c_raw),
+             ptr(act), M, g, stream_ptr())
+        ctx.save_for_backward(act, c_prev)
+        return c_raw, act
+
+    @staticmethod
+    def backward(ctx, dc_raw, d_act):
+        act, c_prev = ctx.saved_tensors
+        B, H, W, g4 = act.shape
+        g = g4 // 4
+        dgates = torch.empty_like(act)
+        dc_prev = torch.empty_like(c_prev)
+        call("rac_lstm_core_bwd", ptr(dc_raw.contiguous()) if dc_raw is not None else None,
+             ptr(d_act.contiguous()) if d_act is not None else None, ptr(act), ptr(c_prev), ptr(dgates), ptr(dc_prev),
+             B * H * W, g, stream_ptr())
+        return dgates, dgates, dc_prev
+
+
+class LstmOut(torch.autograd.Function):
+    """hidden = out_gate * tanh(cell)  (lstm.py:196) with the gate read from the activation tensor."""
+
+    @staticmethod
+    def forward(ctx, act, c):
+        B, H, W, g = c.shape
+        h = torch.empty_like(c)
+        call("rac_lstm_out_fwd", ptr(act), ptr(c), ptr(h), B * H * W, g, stream_ptr())
+        ctx.save_for_backward(act, c)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        act, c = ctx.saved_tensors
+        B, H, W, g = c.shape
+        d_act = torch.empty_like(act)
+        dc = torch.empty_like(c)
+        call("rac_lstm_out_bwd", ptr(dh.contiguous()), ptr(act), ptr(c), ptr(d_act), ptr(dc), B * H * W, g, stream_ptr())
+        return d_act, dc
+
+
 class Reparam(torch.autograd.Function):
     """z = eps * exp(0.5*logvar) + mu  (lstm.py:276-279)."""
 

@@ -108,8 +108,12 @@ def test_state_dict_matches_reference_inventory(flags):
     assert w.data_ptr() >= flat.data_ptr()  # still aliased
     with pytest.raises(ValueError):
         SVGConvModel(_ns(image_width=48))
-    with pytest.raises(NotImplementedError):
-        SVGConvModel(_ns(lstm_group_norm=True))
+    # NormConvLSTMCell variant (--lstm_group_norm True): reference key names
+    ns_gn = _ns(lstm_group_norm=True)
+    sd_gn = SVGConvModel(ns_gn).state_dict()
+    spec_gn = orc.param_spec(orc.cfg_from_namespace(ns_gn))
+    assert list(sd_gn.keys()) == [k for k, _, _ in spec_gn]
+    assert "prior.lstm.0.ih_gates.1.weight" in sd_gn and "frame_predictor.lstm.1.c_norm.bias" in sd_gn
 
 
 def test_fused_adam_state_dict_is_torch_adam_compatible():

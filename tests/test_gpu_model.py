@@ -277,3 +277,35 @@ def test_checkpoint_roundtrip_and_reference_keys(dev, tmp_path):
     l2 = tr2._train_step(syn.synth_video(seed=21, T=3, B=2))
     for k in ("recon_loss", "world_loss", "kld"):
         np.testing.assert_allclose(l1[k], l2[k], rtol=1e-5)
+
+
+def test_groupnorm_lstm_vs_reference_golden(dev, golden_dir):
+    """--lstm_group_norm True (NormConvLSTMCell, lstm.py:151-198): forward <= 1e-4, train losses <= 1e-4."""
+    g = load(golden_dir, "groupnorm_ra")
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, lstm_group_norm=True,
+                  **FLAGSETS["ra"])
+    model = build_model(cfg, orc.make_weights(cfg, seed=11), dev)
+    data = syn.synth_video(seed=3, T=3, B=2)
+    eps = syn.synth_eps(seed=5, steps=2, B=2, z=16, h=8, w=8)
+    queue = []
+    model.eps_source = lambda shape: queue.pop(0)
+    model.init_hidden(2)
+    with torch.no_grad():
+        x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1, dev)
+        queue.extend([eps[0][0], eps[0][1]])
+        o = model(x_j, m_in, r, None, a, x_i, m_next, r_i, None, None)
+        assert rel(o[0], g["s1_x_pred"]) < 1e-4 and rel(o[2], g["s1_mu"]) < 1e-4 and rel(o[5], g["s1_logvar_p"]) < 1e-4
+        x_j, m_in, r, a, _, _, _ = step_inputs(cfg, data, 2, dev)
+        o = model.forward(x_j, m_in, r, None, a, sample_mean=True)
+        assert rel(o[0], g["s2_x_pred"]) < 1e-4 and rel(o[4], g["s2_mu_p"]) < 1e-4
+    tr = make_trainer(cfg, orc.make_weights(cfg, seed=12, randomize_bn_stats=False), dev)
+    queue2 = [e for pair in syn.synth_eps(seed=40, steps=2, B=2, z=16, h=8, w=8) for e in pair]
+    tr.model.eps_source = lambda shape: queue2.pop(0)
+    tr.optimizer.step = lambda: None
+    losses = tr._train_step(syn.synth_video(seed=20, T=3, B=2))
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        np.testing.assert_allclose(losses[k], float(g[f"train_{k}"]), rtol=1e-4)
+    grads = dict(tr.model.named_parameters())
+    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    gn = np.array([grads[k].grad.double().norm().item() for k in pk])
+    np.testing.assert_allclose(gn, g["train_grad_norms"], rtol=GRAD_TOL, atol=1e-9)

@@ -169,3 +169,29 @@ def test_cem(golden_dir, tag):
         assert np.array_equal(trace[i]["act_seq"], g[f"ga_act{i}"])
         assert np.array_equal(trace[i]["sum_cost"], g[f"ga_cost{i}"])
     assert np.array_equal(mean, g["ga_mean"])
+
+
+def test_groupnorm_lstm(golden_dir):
+    """NormConvLSTMCell (--lstm_group_norm True, lstm.py:151-198) against the reference."""
+    g = load(golden_dir, "groupnorm_ra")
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, lstm_group_norm=True,
+                  **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=11)
+    data = syn.synth_video(seed=3, T=3, B=2)
+    eps = syn.synth_eps(seed=5, steps=2, B=2, z=16, h=8, w=8)
+    hidden = orc.init_hidden(cfg, 2)
+    with torch.no_grad():
+        x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1)
+        o = orc.svg_forward(sd, cfg, hidden, x_j, m_in, r, None, a, x_i, m_next, r_i, None, None,
+                            eps_prior=eps[0][0], eps_post=eps[0][1])
+        close(o[0], g["s1_x_pred"]); close(o[2], g["s1_mu"]); close(o[5], g["s1_logvar_p"])
+        x_j, m_in, r, a, _, _, _ = step_inputs(cfg, data, 2)
+        o = orc.svg_forward(sd, cfg, hidden, x_j, m_in, r, None, a, sample_mean=True, eps_prior=eps[1][0])
+        close(o[0], g["s2_x_pred"]); close(o[4], g["s2_mu_p"])
+    ts = orc.TrainState.create(cfg, orc.make_weights(cfg, seed=12, randomize_bn_stats=False))
+    losses = orc.train_step(ts, syn.synth_video(seed=20, T=3, B=2), syn.synth_eps(seed=40, steps=2, B=2, z=16, h=8, w=8),
+                            do_update=False)
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        close(losses[k], g[f"train_{k}"], rtol=2e-5)
+    gn = np.array([ts.sd[k].grad.double().norm().item() for k in ts.param_keys])
+    close(gn, g["train_grad_norms"], rtol=1e-4, atol=1e-10)
