@@ -206,6 +206,16 @@ int rac_kl_fwd(const float* mu1, const float* lv1, const float* mu2, const float
 int rac_kl_bwd(const float* mu1, const float* lv1, const float* mu2, const float* lv2, const float* gout, int64_t n,
                int32_t bs, float* dmu1, float* dlv1, float* dmu2, float* dlv2, void* stream);
 
+/* Evaluation metrics of the eval path (src/utils/metrics.py:13-78, trainer.py:681-693), one launch:
+ *   a' = zero_robot_region(mask, a), b' likewise (mask may be NULL);
+ *   sq_err[n] += sum_{c,h,w} (clamp01(a') - clamp01(b'))^2 / 4          -> PSNR = 10 log10(1 / (sq_err / (3HW)))
+ *                                                                         (the reference maps both to (x+1)/2 first)
+ *   ssim_sum[n] += sum of the SSIM map of (a', b'): 11x11 Gaussian window sigma 1.5, zero padding, C1 = 0.01^2,
+ *   C2 = 0.03^2; the map itself is written to ssim_map [N][3][H][W] when non-NULL.
+ * sq_err / ssim_sum are fp32 [N] and must be zero on entry. */
+int rac_psnr_ssim(const float* a, const float* b, const float* mask, float* sq_err, float* ssim_sum, float* ssim_map,
+                  int32_t N, int32_t H, int32_t W, void* stream);
+
 /* CEM step tail (trajectory_sampler.py:149-169 + losses.py:224-263), fused:
  *   next = (1-m)*curr + m*rgb; next *= (1-next_mask) if next_mask;
  *   cost = -sqrt(sum (255*(next-goal))^2) [dontcare: robot|goal-mask pixels dropped, / #world pixels]

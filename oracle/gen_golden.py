@@ -309,6 +309,37 @@ def gen_groupnorm():
     save("groupnorm_ra", **out)
 
 
+def gen_eval():
+    """_eval_step (1-step and autoregressive) + raw psnr/ssim vectors."""
+    from src.prediction.trainer import PredictionTrainer
+    from src.utils.metrics import psnr as ref_psnr, ssim as ref_ssim
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=7)
+    ns = ns_for(cfg, wandb=False, jobname="g", wandb_project="x", wandb_entity="x", wandb_group=None,
+                wandb_job_type=None, img_augmentation=False, seed=0, scheduled_sampling_k=4000,
+                learned_robot_model=False, n_eval=4, test_batch_size=2)
+    tr = PredictionTrainer(ns)
+    tr.model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    tr.model.eval()
+    data = syn.synth_video(seed=31, T=4, B=2)
+    data["pred_masks"] = data["masks"]
+    out = {}
+    for autoreg in (False, True):
+        for e in syn.synth_eps(seed=50, steps=3, B=2, z=16, h=8, w=8):
+            _EPS.extend(e)
+        losses = tr._eval_step(data, autoregressive=autoreg)
+        assert not _EPS
+        for k, v in losses.items():
+            out[f"{'ar' if autoreg else 'one'}:{k}"] = v
+    g = np.random.Generator(np.random.Philox(key=[13, 0]))
+    a = torch.from_numpy(g.random((2, 3, 48, 64), dtype=np.float32))
+    b = (a + torch.from_numpy(g.standard_normal((2, 3, 48, 64), dtype=np.float32)) * 0.1).clamp(0, 1)
+    out["m_a"], out["m_b"] = a, b
+    out["m_psnr"] = ref_psnr(a, b)
+    out["m_ssim"] = ref_ssim(a, b)
+    save("eval_ra", **out)
+
+
 class _FakeRobotModel:
     def __init__(self, states, masks):
         self.states, self.masks = states, masks
@@ -390,7 +421,7 @@ def gen_cem():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm"]
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval"]
     if "forward" in which:
         gen_forward()
     if "shape" in which:
@@ -403,3 +434,5 @@ if __name__ == "__main__":
         gen_cem()
     if "groupnorm" in which:
         gen_groupnorm()
+    if "eval" in which:
+        gen_eval()

@@ -541,6 +541,71 @@ def train_step(ts: TrainState, data: Dict[str, Tensor], eps: Optional[List[Tuple
 
 
 # --------------------------------------------------------------------------- #
+# eval path (src/utils/metrics.py:13-78, PredictionTrainer._eval_step trainer.py:566-734)
+# --------------------------------------------------------------------------- #
+def psnr(estimates: Tensor, targets: Tensor) -> Tensor:
+    """metrics.py:61-78: both mapped to (x+1)/2, per-sample mean over (C,H,W), 10 log10(1/mse)."""
+    mse = (((estimates + 1) / 2) - ((targets + 1) / 2)).pow(2).mean((1, 2, 3))
+    return 10 * torch.log(1.0 / mse) / math.log(10)
+
+
+def ssim_map(img1: Tensor, img2: Tensor) -> Tensor:
+    """metrics.py:13-58: 11x11 Gaussian (sigma 1.5) depthwise window, zero padding, C1=0.01^2, C2=0.03^2."""
+    g = torch.tensor([math.exp(-(i - 5) ** 2 / (2 * 1.5 ** 2)) for i in range(11)])
+    g = (g / g.sum()).unsqueeze(1)
+    w = (g @ g.t()).float().expand(3, 1, 11, 11).contiguous()
+    blur = lambda t: F.conv2d(t, w, padding=5, groups=3)
+    m1, m2 = blur(img1), blur(img2)
+    v1, v2, v12 = blur(img1 * img1) - m1 * m1, blur(img2 * img2) - m2 * m2, blur(img1 * img2) - m1 * m2
+    return ((2 * m1 * m2 + 1e-4) * (2 * v12 + 9e-4)) / ((m1 * m1 + m2 * m2 + 1e-4) * (v1 + v2 + 9e-4))
+
+
+@torch.no_grad()
+def eval_step(sd, cfg: Cfg, data: Dict[str, Tensor], n_eval: int, autoregressive: bool,
+              eps: List[Tuple[Tensor, Tensor]]) -> Dict[str, float]:
+    """_eval_step with the model in eval mode; `eps[i-1]` = (prior, posterior) draws of step i."""
+    x, states, ac, masks = data["images"], data["states"], data["actions"], data["masks"]
+    bs = x.shape[1]
+    hidden = init_hidden(cfg, bs)
+    prefix = "autoreg" if autoregressive else "1step"
+    dontcare = "dontcare" in cfg.reconstruction_loss or cfg.black_robot_input
+    losses: Dict[str, float] = {}
+    k_losses: Dict[str, float] = {}
+    add = lambda k, v: losses.__setitem__(k, losses.get(k, 0.0) + float(v))
+    x_pred = skip = None
+    for i in range(1, n_eval):
+        x_j = x_pred.clone() if (autoregressive and i > 1) else x[i - 1]
+        m_j, r_j, a_j, m_i, r_i, x_i = masks[i - 1], states[i - 1], ac[i - 1], masks[i], states[i], x[i]
+        x_j_black, x_i_black = (zero_robot_region(m_j, x_j), zero_robot_region(m_i, x_i)) if dontcare else (x_j, x_i)
+        if cfg.last_frame_skip:
+            skip = None
+        m_in = torch.cat([m_j, m_i], 1) if cfg.model_use_future_mask else m_j
+        r_in = (r_j, r_i) if cfg.model_use_future_robot_state else r_j
+        m_next = m_i.repeat(1, 2, 1, 1) if cfg.model_use_future_mask else m_i
+        x4, curr_skip, mu, logvar, mu_p, logvar_p = svg_forward(
+            sd, cfg, hidden, x_j_black, m_in, r_in, None, a_j, x_i_black, m_next, r_i, None, skip,
+            force_use_prior=True, eps_prior=eps[i - 1][0], eps_post=eps[i - 1][1])
+        x_pred = composite(x4, x_j)
+        if i <= cfg.n_past:
+            skip = curr_skip
+        add(f"{prefix}_recon_loss", recon_loss(cfg, x_pred, x_i, m_i))
+        add(f"{prefix}_robot_loss", robot_mse(x_pred, x_i, m_i))
+        wm = float(world_mse(x_pred, x_i, m_i))
+        add(f"{prefix}_world_loss", wm)
+        pb, tb = zero_robot_region(m_i, x_pred), zero_robot_region(m_i, x_i)
+        p = float(psnr(tb.clamp(0, 1), pb.clamp(0, 1)).mean())
+        s_ = float(ssim_map(tb, pb).mean())
+        add(f"{prefix}_psnr", p)
+        add(f"{prefix}_ssim", s_)
+        if autoregressive:
+            k_losses.update({f"{i}_step_psnr": p, f"{i}_step_ssim": s_, f"{i}_step_world_loss": wm})
+        add(f"{prefix}_kld", kl_loss(mu, logvar, mu_p, logvar_p, bs))
+    out = {k: v / (n_eval - 1) for k, v in losses.items()}
+    out.update(k_losses)
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # CEM (src/cem/trajectory_sampler.py:35-199, src/cem/cem.py:56-111)
 # --------------------------------------------------------------------------- #
 @torch.no_grad()

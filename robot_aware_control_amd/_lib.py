@@ -66,6 +66,7 @@ _SIGS = {
     "rac_recon_loss_bwd": [i32, vp, vp, vp, f32, vp, vp, vp, vp, i32, i32, vp],
     "rac_kl_fwd": [vp, vp, vp, vp, i64, i32, vp, vp, vp],
     "rac_kl_bwd": [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
+    "rac_psnr_ssim": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rac_cem_step_tail": [vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, i32, vp],
     "rac_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
     "rac_version": [],

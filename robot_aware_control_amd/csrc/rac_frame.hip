@@ -378,3 +378,105 @@ int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask
 }
 
 }  // extern "C"
+
+// ---- PSNR / SSIM of the eval path ---------------------------------------------------------------
+namespace rac {
+
+constexpr int SS_T = 16;             // output tile edge
+constexpr int SS_R = 5;              // window radius (11x11)
+constexpr int SS_E = SS_T + 2 * SS_R;  // staged edge incl. halo
+
+struct SsimWin {
+  float g[11];
+};
+
+// grid (tiles_x * tiles_y, 3, N), 256 threads: one 16x16 tile of one channel plane per workgroup.
+__global__ void psnr_ssim_kernel(const float* a, const float* b, const float* mask, float* sq_err, float* ssim_sum,
+                                 float* ssim_map, int H, int W, int tiles_x, SsimWin win) {
+  __shared__ float sa[SS_E][SS_E + 1], sb[SS_E][SS_E + 1];
+  __shared__ float red[8];
+  const int n = blockIdx.z, c = blockIdx.y;
+  const int ty0 = (blockIdx.x / tiles_x) * SS_T, tx0 = (blockIdx.x % tiles_x) * SS_T;
+  const long plane = ((long)n * 3 + c) * H * W;
+  for (int i = threadIdx.x; i < SS_E * SS_E; i += 256) {
+    const int ly = i / SS_E, lx = i - ly * SS_E;
+    const int y = ty0 + ly - SS_R, x = tx0 + lx - SS_R;
+    float va = 0.f, vb = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const bool zero = mask && mask[(long)n * H * W + (long)y * W + x] != 0.f;
+      va = a[plane + (long)y * W + x];
+      vb = b[plane + (long)y * W + x];
+      if (zero) {
+        va *= 0.f;
+        vb *= 0.f;
+      }
+    }
+    sa[ly][lx] = va;
+    sb[ly][lx] = vb;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / SS_T, lx = threadIdx.x % SS_T;
+  const int y = ty0 + ly, x = tx0 + lx;
+  float se = 0.f, ss = 0.f;
+  if (y < H && x < W) {
+    float m1 = 0.f, m2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        const float w = win.g[i] * win.g[j];
+        const float p = sa[ly + i][lx + j], q = sb[ly + i][lx + j];
+        m1 += w * p;
+        m2 += w * q;
+        s11 += w * (p * p);
+        s22 += w * (q * q);
+        s12 += w * (p * q);
+      }
+    }
+    const float m1s = m1 * m1, m2s = m2 * m2, m12 = m1 * m2;
+    const float v1 = s11 - m1s, v2 = s22 - m2s, v12 = s12 - m12;
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    ss = ((2.f * m12 + C1) * (2.f * v12 + C2)) / ((m1s + m2s + C1) * (v1 + v2 + C2));
+    if (ssim_map) ssim_map[plane + (long)y * W + x] = ss;
+    const float pa = fminf(fmaxf(sa[ly + SS_R][lx + SS_R], 0.f), 1.f);
+    const float pb = fminf(fmaxf(sb[ly + SS_R][lx + SS_R], 0.f), 1.f);
+    const float d = (pa + 1.f) * 0.5f - (pb + 1.f) * 0.5f;
+    se = d * d;
+  }
+  se = wave_sum(se);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) {
+    red[threadIdx.x >> 6] = se;
+    red[4 + (threadIdx.x >> 6)] = ss;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(sq_err + n, (red[0] + red[1]) + (red[2] + red[3]));
+    atomicAdd(ssim_sum + n, (red[4] + red[5]) + (red[6] + red[7]));
+  }
+}
+
+}  // namespace rac
+
+extern "C" int rac_psnr_ssim(const float* a, const float* b, const float* mask, float* sq_err, float* ssim_sum,
+                             float* ssim_map, int32_t N, int32_t H, int32_t W, void* stream) {
+  using namespace rac;
+  RAC_REQUIRE(a && b && sq_err && ssim_sum && N > 0 && H > 0 && W > 0, "rac_psnr_ssim: bad args");
+  SsimWin win;
+  double tot = 0.0;
+  double gd[11];
+  for (int i = 0; i < 11; ++i) {  // gaussian(11, 1.5) of src/utils/metrics.py:13-15, normalised in fp32 like torch
+    gd[i] = exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5));
+  }
+  float gf[11], sum = 0.f;
+  for (int i = 0; i < 11; ++i) {
+    gf[i] = (float)gd[i];
+    sum += gf[i];
+  }
+  (void)tot;
+  for (int i = 0; i < 11; ++i) win.g[i] = gf[i] / sum;
+  const int tx = cdiv(W, SS_T), ty = cdiv(H, SS_T);
+  hipLaunchKernelGGL(psnr_ssim_kernel, dim3(tx * ty, 3, N), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a, b,
+                     mask, sq_err, ssim_sum, ssim_map, H, W, tx, win);
+  return check_launch("rac_psnr_ssim");
+}

@@ -220,6 +220,103 @@ class PredictionTrainer(object):
             losses[k] = losses[k] / cf.n_future
         return losses
 
+    # ------------------------------------------------------------------- eval
+    def _compute_epoch_metrics(self, data_loader, name):
+        """Average the per-video eval metrics over a loader (trainer.py:467-488)."""
+        from .data import process_batch
+        losses = defaultdict(list)
+        for data in data_loader:
+            data = process_batch(data, self._device)
+            info = self._eval_video(data, autoregressive=True)
+            for k, v in info.items():
+                losses[k].append(v)
+        return {f"{name}/{k}": float(np.mean(v)) for k, v in losses.items()}
+
+    def _eval_video(self, data, autoregressive=False):
+        """Evaluate a whole video in n_eval windows (trainer.py:490-564); ground-truth masks drive the rollout."""
+        cf = self._config
+        if "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state):
+            raise NotImplementedError("finetune_* eval needs the CPU analytical robot model (trainer.py:520-543)")
+        x = data["images"]
+        T = len(x)
+        window = cf.n_eval
+        total = defaultdict(float)
+        for i in range(floor(T / window)):
+            s, e = i * window, (i + 1) * window
+            batch = {"images": x[s:e], "states": data["states"][s:e], "actions": data["actions"][s:e - 1],
+                     "masks": data["masks"][s:e], "pred_masks": data["masks"][s:e], "robot": data["robot"]}
+            if getattr(cf, "model_use_heatmap", False):
+                batch["heatmaps"] = data["heatmaps"][s:e]
+            for k, v in self._eval_step(batch, autoregressive).items():
+                total[k] += v
+        for k in total:
+            total[k] /= floor(T / window)
+        return total
+
+    @torch.no_grad()
+    def _eval_step(self, data, autoregressive=False):
+        """Evaluate one n_eval snippet (trainer.py:566-734): prior-driven prediction (`force_use_prior`), optional
+        autoregressive feeding, recon / robot / world losses, PSNR, SSIM, KL.  One host sync at the end."""
+        from .metrics import masked_psnr_ssim
+        cf = self._config
+        dev, f32 = self._device, torch.float32
+        x = data["images"].to(dev, f32)
+        states = data["states"].to(dev, f32)
+        ac = data["actions"].to(dev, f32)
+        true_masks = data["masks"].to(dev, f32)
+        masks = data["pred_masks"].to(dev, f32)
+        heatmaps = data["heatmaps"].to(dev, f32) if getattr(cf, "model_use_heatmap", False) else None
+        robot_name = np.array(data["robot"])
+        all_robots = sorted(set(robot_name))
+        bs = min(cf.test_batch_size, x.shape[1])
+        self.model.init_hidden(bs)
+        prefix = "autoreg" if autoregressive else "1step"
+        dontcare = "dontcare" in cf.reconstruction_loss or cf.black_robot_input
+        log, klog = [], []
+        x_pred = skip = None
+        for i in range(1, cf.n_eval):
+            x_j = x_pred if (autoregressive and i > 1) else x[i - 1]
+            m_j, r_j, a_j = masks[i - 1], states[i - 1], ac[i - 1]
+            m_i, r_i = masks[i], states[i]
+            if cf.last_frame_skip:
+                skip = None
+            m_in = torch.cat([m_j, m_i], 1) if cf.model_use_future_mask else m_j
+            r_in = (r_j, r_i) if cf.model_use_future_robot_state else r_j
+            hm_in = None
+            if heatmaps is not None:
+                hm_in = torch.cat([heatmaps[i - 1], heatmaps[i]], 1) if cf.model_use_future_heatmap else heatmaps[i - 1]
+            x4, curr_skip, mu, logvar, mu_p, logvar_p = self.model.forward_maps(
+                x_j, m_in, r_in, hm_in, a_j, True, r_i, skip, force_use_prior=True,
+                zero_mask=m_j if dontcare else None)
+            x_pred = ops.Composite.apply(x4, x_j.contiguous())
+            if i <= cf.n_past:
+                skip = curr_skip
+            tm = true_masks[i].contiguous()
+            rec = self._recon_loss(x_pred, x[i].contiguous(), tm)
+            log += [(f"{prefix}_recon_loss", rec[0]), (f"{prefix}_robot_loss", rec[1]), (f"{prefix}_world_loss", rec[2])]
+            p, s = masked_psnr_ssim(x_pred, x[i].contiguous(), tm)  # robot region blacked with the true mask
+            p = p.mean()
+            log += [(f"{prefix}_psnr", p), (f"{prefix}_ssim", s)]
+            if autoregressive:
+                klog += [(f"{i}_step_psnr", p), (f"{i}_step_ssim", s), (f"{i}_step_world_loss", rec[2])]
+            if len(all_robots) > 1:
+                for r in all_robots:
+                    idx = torch.from_numpy(np.nonzero(robot_name == r)[0]).to(dev)
+                    sub = ops.ReconLoss.apply(x_pred[idx].contiguous(), x[i][idx].contiguous(), tm[idx].contiguous(),
+                                              None, 0, 0.0)
+                    log += [(f"{prefix}_{r}_robot_loss", sub[1]), (f"{prefix}_{r}_world_loss", sub[2])]
+            kl = ops.KLLoss.apply(mu, logvar, mu_p, logvar_p, bs)
+            log.append((f"{prefix}_kld", kl[0]))
+        vals = torch.stack([t.reshape(()) for _, t in log + klog]).cpu().tolist()
+        losses = defaultdict(float)
+        for (name, _), v in zip(log, vals[:len(log)]):
+            losses[name] += v
+        for k in losses:
+            losses[k] = losses[k] / (cf.n_eval - 1)
+        for (name, _), v in zip(klog, vals[len(log):]):
+            losses[name] = v
+        return losses
+
     # ----------------------------------------------------------- outer loops
     def train(self, batch_generator=None, test_hook=None):
         """Epoch loop with checkpoint cadence (trainer.py:736-792).  `batch_generator` yields time-first

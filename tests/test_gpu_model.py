@@ -309,3 +309,29 @@ def test_groupnorm_lstm_vs_reference_golden(dev, golden_dir):
     pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
     gn = np.array([grads[k].grad.double().norm().item() for k in pk])
     np.testing.assert_allclose(gn, g["train_grad_norms"], rtol=GRAD_TOL, atol=1e-9)
+
+
+def test_eval_path_vs_reference_golden(dev, golden_dir):
+    """_eval_step (1-step and autoregressive, force_use_prior) and the PSNR / SSIM kernels."""
+    from robot_aware_control_amd import metrics
+    g = load(golden_dir, "eval_ra")
+    a, b = torch.from_numpy(g["m_a"]).to(dev), torch.from_numpy(g["m_b"]).to(dev)
+    np.testing.assert_allclose(metrics.psnr(a, b).cpu().numpy(), g["m_psnr"], rtol=1e-5)
+    np.testing.assert_allclose(metrics.ssim(a, b), g["m_ssim"], rtol=2e-4, atol=2e-5)
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, **FLAGSETS["ra"])
+    tr = make_trainer(cfg, orc.make_weights(cfg, seed=7), dev, n_eval=4, test_batch_size=2)
+    tr.model.eval()
+    data = syn.synth_video(seed=31, T=4, B=2)
+    data["pred_masks"] = data["masks"]
+    for tag, autoreg in (("one", False), ("ar", True)):
+        queue = [e for pair in syn.synth_eps(seed=50, steps=3, B=2, z=16, h=8, w=8) for e in pair]
+        tr.model.eps_source = lambda shape: queue.pop(0)
+        got = tr._eval_step(data, autoregressive=autoreg)
+        assert not queue
+        ref = {k.split(":", 1)[1]: float(g[k]) for k in g.files if k.startswith(tag + ":")}
+        assert set(got) == set(ref)
+        for k in ref:
+            np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, err_msg=k)
+    tr.model.eps_source = None  # device RNG
+    video = tr._eval_video({**syn.synth_video(seed=32, T=8, B=2)}, autoregressive=True)
+    assert "autoreg_psnr" in video and np.isfinite(video["autoreg_psnr"])

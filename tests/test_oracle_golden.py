@@ -195,3 +195,20 @@ def test_groupnorm_lstm(golden_dir):
         close(losses[k], g[f"train_{k}"], rtol=2e-5)
     gn = np.array([ts.sd[k].grad.double().norm().item() for k in ts.param_keys])
     close(gn, g["train_grad_norms"], rtol=1e-4, atol=1e-10)
+
+
+def test_eval_step_and_metrics(golden_dir):
+    """_eval_step (trainer.py:566-734) and psnr / ssim (src/utils/metrics.py) against the reference."""
+    g = load(golden_dir, "eval_ra")
+    a, b = torch.from_numpy(g["m_a"]), torch.from_numpy(g["m_b"])
+    close(orc.psnr(a, b), g["m_psnr"], rtol=1e-6)
+    close(orc.ssim_map(a, b), g["m_ssim"], rtol=1e-5, atol=1e-6)
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=7)
+    data = syn.synth_video(seed=31, T=4, B=2)
+    for tag, autoreg in (("one", False), ("ar", True)):
+        got = orc.eval_step(sd, cfg, data, 4, autoreg, syn.synth_eps(seed=50, steps=3, B=2, z=16, h=8, w=8))
+        ref = {k.split(":", 1)[1]: float(g[k]) for k in g.files if k.startswith(tag + ":")}
+        assert set(got) == set(ref)
+        for k in ref:
+            close(got[k], ref[k], rtol=1e-5)
