@@ -82,6 +82,21 @@ int rac_conv2d(const rac_conv_args* a, void* stream);
 
 
 /* ------------------------------------------------------------------------ *
+ * Split-precision path for the frozen-model (CEM) gate GEMMs: every fp32 operand is the exact sum of three
+ * bf16 parts, x = p1 + p2 + p3 (8+8+8 mantissa bits); the product keeps the six terms of order <= 2^-16
+ * (p1q1, p1q2, p2q1, p1q3, p2q2, p3q1) on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32
+ * MFMA rate) with fp32 accumulation: fp32-level accuracy (dropped terms <= 2^-24 relative) at up to 2.67x
+ * the fp32-MFMA roofline.
+ * ------------------------------------------------------------------------ */
+/* parts[k*part_stride + i] = k-th bf16 part of x[i], k = 0..2 (round-to-nearest-even at every level) */
+int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream);
+/* FWD conv (as rac_conv2d mode RAC_CONV_FWD) on split operands: a0 / a1 / w point to bf16 part arrays
+ * ([3][pixels][C] and [3][Cout][k][k][Cin]; *_part_stride in elements).  Needs Cin % 8 == 0, a_split % 32 == 0.
+ * Epilogue fields (bias, scale/shift, act, stats, split_k slabs) behave as in rac_conv2d. */
+int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t a1_part_stride,
+                         int64_t w_part_stride, void* stream);
+
+/* ------------------------------------------------------------------------ *
  * BatchNorm2d (training statistics) + LeakyReLU(0.2)
  *   src/prediction/models/vgg_64.py:12-14 (nn.BatchNorm2d, nn.LeakyReLU(0.2))
  * ------------------------------------------------------------------------ */

@@ -1,0 +1,292 @@
+// Split-precision implicit-GEMM convolution (forward only) for the frozen-model gate GEMMs of the CEM
+// rollouts: operands arrive as three bf16 parts (x = p1 + p2 + p3 exactly), six part-products run on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  Same tiling as rac_igemm.hip's fast path (128x128 tile,
+// 4 waves x 2x2 accumulators, K chunks of 32, branch-free buffer loads with hardware zero fill), but one
+// LDS buffer per workgroup (48 KB: three parts of both operands, XOR-swizzled 64-byte rows) so that two to
+// three workgroups share a CU and cover each other's barrier phases; the next chunk's 12 loads per lane are
+// in flight while the current chunk's 48 MFMAs run.
+#include <stdlib.h>
+
+#include "rac_common.h"
+
+namespace rac {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+struct SplitP {
+  int B, H, W, ks, pad, Cin, Cout, act, split_k, a_split;
+  long slab_stride;
+  const unsigned short *a0, *a1, *w;
+  long a0_ps, a1_ps, w_ps;  // part strides in elements
+  float* out0;
+  const float *bias, *scale, *shift;
+  double* stats;
+  int M, N, HW, P, taps, cchunks, nchunks, cps;
+};
+
+constexpr unsigned OOBS = 0xFFFFFFF0u;
+constexpr int SBM = 128, SBN = 128, SBK = 32;
+
+__device__ __forceinline__ const void* uniform_vptr(const void* p) {
+  unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_vptr(p)), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 ld16(rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+// LDS image of one operand: [part 3][row 128][4 chunks of 16 B], chunk index XOR-swizzled by (row >> 2) & 3 so that
+// the 16 lanes of a ds_read_b128 group (16 consecutive rows, same logical chunk) hit 16 distinct 4-bank slots.
+__device__ __forceinline__ int lds_off(int part, int row, int chunk) {  // in 16-byte units
+  return (part * 128 + row) * 4 + (chunk ^ ((row >> 2) & 3));
+}
+
+__global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2 operands][3][128][4] x 16 B = 48 KB
+  u32x4* As = lds;
+  u32x4* Bs = lds + 3 * 128 * 4;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * SBM, n0 = blockIdx.y * SBN;
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+
+  // staging map: lane handles rows {tid/4, tid/4 + 64} x chunk (tid & 3) x 3 parts, for A and for B
+  const int srow = tid >> 2, schunk = tid & 3;
+  int a_pix[2], a_y[2], a_x[2], b_row[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int m = m0 + srow + 64 * i;
+    if (m < p.M) {
+      int b = m / p.HW;
+      int r = m - b * p.HW;
+      int y = r / p.W;
+      a_pix[i] = m, a_y[i] = y, a_x[i] = r - y * p.W;
+    } else {
+      a_pix[i] = 0, a_y[i] = -100000, a_x[i] = 0;
+    }
+    int n = n0 + srow + 64 * i;
+    b_row[i] = (n < p.N) ? n * p.taps * p.Cin : -1;
+  }
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+
+  u32x4 ra[6], rb[6];  // [part][row]
+  auto issue = [&](int kc) {
+    const bool live = kc < kc_end;
+    const int tap = kc / p.cchunks;
+    const int cc = kc - tap * p.cchunks;
+    const int ky = tap / p.ks, kx = tap - ky * p.ks;
+    const int dy = ky - p.pad, dx = kx - p.pad;
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = (first ? c0 : c0 - p.a_split) + schunk * 8;
+    const long aps = first ? p.a0_ps : p.a1_ps;
+    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+    const int shift = dy * p.W + dx;
+    const int s0 = tap * p.Cin + c0 + schunk * 8;
+    const bool cok = live & (c0 + schunk * 8 < p.Cin);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      bool ok = live & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W) & (cl < Cs);
+      unsigned oa = (unsigned)((a_pix[i] + shift) * Cs + cl) * 2u;
+      bool okb = cok & (b_row[i] >= 0);
+      unsigned ob = (unsigned)(b_row[i] + s0) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        ra[part * 2 + i] = ld16(a_rsrc, ok ? oa + (unsigned)(part * aps * 2) : OOBS);
+        rb[part * 2 + i] = ld16(w_rsrc, okb ? ob + (unsigned)(part * p.w_ps * 2) : OOBS);
+      }
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        As[lds_off(part, srow + 64 * i, schunk)] = ra[part * 2 + i];
+        Bs[lds_off(part, srow + 64 * i, schunk)] = rb[part * 2 + i];
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    issue(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      store();  // waits for the loads of chunk kc
+      __syncthreads();
+      issue(kc + 1);  // in flight under the MFMAs (past the end: zeros)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[2][3], fb[2][3];
+        const int chunk = 2 * s + lh;  // MFMA k = 16 s + 8 h + j
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            fa[t][part] = __builtin_bit_cast(bf16x8, As[lds_off(part, (wm * 2 + t) * 32 + li, chunk)]);
+            fb[t][part] = __builtin_bit_cast(bf16x8, Bs[lds_off(part, (wn * 2 + t) * 32 + li, chunk)]);
+          }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x16 c = acc[mt][nt];
+            // smallest terms first: (3,1) (2,2) (1,3) | (2,1) (1,2) | (1,1)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], c, 0, 0, 0);
+            acc[mt][nt] = c;
+          }
+      }
+      __syncthreads();  // every wave is done reading before the next chunk overwrites the buffer
+    }
+  }
+
+  // ---- epilogue (same semantics as rac_conv2d FWD) ----
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + (wn * 2 + nt) * 32 + li;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M || !nok) continue;
+        float v = acc[mt][nt][r];
+        if (slab) {
+          p.out0[(long)blockIdx.z * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        s1 += v;
+        s2 += v * v;
+        v = v * sc + sh;
+        if (p.act == RAC_ACT_LEAKY02)
+          v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == RAC_ACT_SIGMOID)
+          v = sigmoid_acc(v);
+        p.out0[(long)m * p.N + n] = v;
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0 && nok) {
+        atomicAdd(p.stats + n, (double)s1);
+        atomicAdd(p.stats + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+__global__ void split_bf16x3_kernel(const float* x, unsigned short* parts, long n, long ps) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float a = x[i];
+    const __bf16 p1 = (__bf16)a;
+    const float r1 = a - (float)p1;
+    const __bf16 p2 = (__bf16)r1;
+    const float r2 = r1 - (float)p2;
+    const __bf16 p3 = (__bf16)r2;
+    parts[i] = __builtin_bit_cast(unsigned short, p1);
+    parts[ps + i] = __builtin_bit_cast(unsigned short, p2);
+    parts[2 * ps + i] = __builtin_bit_cast(unsigned short, p3);
+  }
+}
+
+}  // namespace rac
+
+using namespace rac;
+
+extern "C" int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream) {
+  RAC_REQUIRE(x && parts && n > 0 && part_stride >= n, "rac_split_bf16x3: bad args");
+  long nb = (n + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, parts,
+                     (long)n, (long)part_stride);
+  return check_launch("rac_split_bf16x3");
+}
+
+extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64_t a1_ps, int64_t w_ps,
+                                    void* stream) {
+  RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
+  RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0,
+              "rac_conv2d_fwd_split: bad args");
+  RAC_REQUIRE(a->ksize >= 1 && (a->ksize & 1) && a->ksize <= 7, "rac_conv2d_fwd_split: ksize must be odd");
+  SplitP p{};
+  p.B = a->B, p.H = a->H, p.W = a->W, p.ks = a->ksize, p.pad = a->ksize / 2;
+  p.Cin = a->Cin, p.Cout = a->Cout, p.act = a->act;
+  p.split_k = a->split_k > 1 ? a->split_k : 1;
+  p.slab_stride = a->slab_stride;
+  p.a0 = reinterpret_cast<const unsigned short*>(a->a0);
+  p.a1 = reinterpret_cast<const unsigned short*>(a->a1);
+  p.w = reinterpret_cast<const unsigned short*>(a->w);
+  p.a0_ps = a0_ps, p.a1_ps = a1_ps, p.w_ps = w_ps;
+  p.out0 = a->out0;
+  p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
+  p.HW = a->H * a->W;
+  p.P = a->B * p.HW;
+  p.M = p.P, p.N = a->Cout;
+  p.taps = a->ksize * a->ksize;
+  p.a_split = (a->a1 && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
+  RAC_REQUIRE(a->Cin % 8 == 0 && p.a_split % 8 == 0, "rac_conv2d_fwd_split: channel counts must be multiples of 8");
+  RAC_REQUIRE(p.a_split == a->Cin || p.a_split % SBK == 0, "rac_conv2d_fwd_split: a_split must be a multiple of 32");
+  RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
+  RAC_REQUIRE(a0_ps >= (long)p.P * p.a_split && w_ps >= (long)p.Cout * p.taps * p.Cin &&
+                  (p.a_split == a->Cin || a1_ps >= (long)p.P * (a->Cin - p.a_split)),
+              "rac_conv2d_fwd_split: part strides too small");
+  RAC_REQUIRE(3 * a0_ps * 2 < 0xFFFFFF00L && 3 * w_ps * 2 < 0xFFFFFF00L && 3 * a1_ps * 2 < 0xFFFFFF00L,
+              "rac_conv2d_fwd_split: operand larger than 4 GiB");
+  RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.N, "rac_conv2d_fwd_split: slab_stride too small");
+  p.cchunks = cdiv(a->Cin, SBK);
+  p.nchunks = p.taps * p.cchunks;
+  p.cps = cdiv(p.nchunks, p.split_k);
+  constexpr size_t lds = 2 * 3 * 128 * 4 * 16;  // 49,152 B
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return RAC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(cdiv(p.M, SBM), cdiv(p.N, SBN), p.split_k);
+  hipLaunchKernelGGL(igemm_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("rac_conv2d_fwd_split");
+}

@@ -60,26 +60,33 @@ def _cdiv(a, b):
 # convs: g + 5..15 (+ z)) run on a zero-padded copy of the weight ([Cout][k][k][Cpad], 16-byte rows) so that they
 # take the vector-load kernel; their inputs are produced already padded (rac_pack_input / rac_tilecat_fwd `pad`).
 PARAM_EPOCH = 0  # bumped by FusedAdam.step(): parameters changed behind torch's version counters
-_PAD_CACHE = {}
 
 
 def pad4(c: int) -> int:
     return (-c) % 4
 
 
-def padded_weight(weight: torch.Tensor) -> torch.Tensor:
-    """Zero-padded (Cout, Cin + pad, k, k) channels_last copy of `weight`, cached until the parameter changes."""
-    co, ci, k, _ = weight.shape
-    key = weight.data_ptr()
-    tag = (weight._version, PARAM_EPOCH, tuple(weight.shape))
-    hit = _PAD_CACHE.get(key)
+def _derived(weight: torch.Tensor, slot: str, build):
+    """Cache a tensor derived from a parameter ON the parameter object (dies with it; a data_ptr key could be
+    re-used by the allocator), invalidated by in-place updates (torch version counter or PARAM_EPOCH)."""
+    tag = (weight._version, PARAM_EPOCH, weight.data_ptr())
+    hit = getattr(weight, slot, None)
     if hit is not None and hit[0] == tag:
         return hit[1]
-    cp = ci + pad4(ci)
-    wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
-    call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
-    _PAD_CACHE[key] = (tag, wp)
-    return wp
+    val = build()
+    setattr(weight, slot, (tag, val))
+    return val
+
+
+def padded_weight(weight: torch.Tensor) -> torch.Tensor:
+    """Zero-padded (Cout, Cin + pad, k, k) channels_last copy of `weight`, cached until the parameter changes."""
+    def build():
+        co, ci, k, _ = weight.shape
+        cp = ci + pad4(ci)
+        wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
+        return wp
+    return _derived(weight, "_rac_padded", build)
 
 
 def wgrad_padded_acc(dy, x0, weight):
@@ -220,6 +227,47 @@ def conv_wgrad_acc(dy, x0, x1, weight):
 def bias_grad_acc(dy, bias):
     M = dy.numel() // dy.shape[-1]
     call("rac_colsum_acc", ptr(dy), ptr(grad_buffer(bias)), M, dy.shape[-1], stream_ptr())
+
+
+# --------------------------------------------------------------------------- #
+# split-precision (3 x bf16 per operand, 6 part-products) forward GEMMs for the frozen model
+# --------------------------------------------------------------------------- #
+SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "0") == "1"
+
+
+def split_parts(x: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor -> (3, numel) bf16 parts with x == p1 + p2 + p3 exactly (memory order of x is kept)."""
+    n = x.numel()
+    parts = torch.empty((3, n), device=x.device, dtype=torch.bfloat16)
+    call("rac_split_bf16x3", ptr(x), ptr(parts), n, n, stream_ptr())
+    return parts
+
+
+def split_weight(weight: torch.Tensor) -> torch.Tensor:
+    """bf16 parts of a channels_last conv weight, cached until the parameter changes."""
+    return _derived(weight, "_rac_split", lambda: split_parts(weight_mem(weight)))
+
+
+def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, want_slabs=False):
+    """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h)."""
+    _require_cuda(x0)
+    B, H, W, C0 = x0.shape
+    C1 = x1.shape[3] if x1 is not None else 0
+    Cout, Cin, k, _ = weight.shape
+    assert Cin == C0 + C1
+    M = B * H * W
+    p0 = split_parts(x0)
+    p1 = split_parts(x1) if x1 is not None else None
+    pw = split_weight(weight)
+    out = torch.empty((1, B, H, W, Cout) if want_slabs else (B, H, W, Cout), device=x0.device, dtype=torch.float32)
+    args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=1, accumulate=0,
+                    a_split=C0, o_split=0, slab_stride=0, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out), out1=None,
+                    bias=None if want_slabs else ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=None)
+    call("rac_conv2d_fwd_split", C.byref(args), p0.shape[1], p1.shape[1] if p1 is not None else 0, pw.shape[1],
+         stream_ptr())
+    if want_slabs:
+        return out, 1, M * Cout
+    return out
 
 
 # --------------------------------------------------------------------------- #
@@ -434,10 +482,13 @@ class LstmCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h_prev, c_prev, weight, bias):
         B, H, W, g = x.shape
-        slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
+        need_bwd = any(ctx.needs_input_grad)  # all False under torch.no_grad() (frozen rollouts)
+        if SPLIT_GEMM and not need_bwd and g % 32 == 0:
+            slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True)
+        else:
+            slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
         h = torch.empty_like(x)
         c = torch.empty_like(x)
-        need_bwd = any(ctx.needs_input_grad)  # all False under torch.no_grad() (frozen rollouts)
         act = torch.empty((B, H, W, 4 * g), device=x.device, dtype=torch.float32) if need_bwd else None
         call("rac_lstm_cell_fwd", ptr(slabs), n_slabs, stride, ptr(bias), ptr(c_prev), ptr(h), ptr(c), ptr(act),
              B * H * W, g, stream_ptr())

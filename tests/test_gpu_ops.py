@@ -319,3 +319,30 @@ def test_cem_step_tail(dev, golden_dir):
         torch.cuda.synchronize()
         assert torch.equal(nxt.cpu(), curr)
         np.testing.assert_allclose(cost.cpu().numpy(), g[key].astype(np.float64), rtol=2e-6)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3)])
+def test_conv_split_precision_bf16x6(dev, case):
+    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe."""
+    from robot_aware_control_amd import ops
+    B, H, W, C0, C1, Cout, k = case
+    Cin = C0 + C1
+    # exactness of the fragment layout: small integers live entirely in the first bf16 part
+    g = np.random.Generator(np.random.Philox(key=[9, 9]))
+    xi = torch.from_numpy(g.integers(-3, 4, (B, Cin, H, W)).astype(np.float32))
+    wi = torch.from_numpy(g.integers(-3, 4, (Cout, Cin, k, k)).astype(np.float32))
+    x0, x1 = to_map(xi[:, :C0], dev), (to_map(xi[:, C0:], dev) if C1 else None)
+    y = ops.conv_forward_split(x0, x1, cl_weight(wi).to(dev))
+    assert torch.equal(from_map(y), F.conv2d(xi, wi, None, 1, k // 2))
+    # accuracy on real-valued data: compare both GPU paths with an fp64 reference
+    x = rnd(1, B, Cin, H, W)
+    w = rnd(2, Cout, Cin, k, k) * (1.0 / np.sqrt(Cin * k * k))
+    b = rnd(3, Cout, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, k // 2)
+    x0, x1 = to_map(x[:, :C0], dev), (to_map(x[:, C0:], dev) if C1 else None)
+    wd, bd = cl_weight(w).to(dev), b.to(dev)
+    parts = ops.split_parts(x0)
+    assert torch.equal(parts.float().sum(0).view_as(x0), x0)  # p1 + p2 + p3 == x exactly
+    e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
+    e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
+    assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)
