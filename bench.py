@@ -32,6 +32,7 @@ from robot_aware_control_amd.state import DemoGoalState, State  # noqa: E402
 from robot_aware_control_amd.trainer import PredictionTrainer  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 matrix peak; the split path issues 6 bf16 MFMA products per fp32 product
 TRAIN_FWD_GFLOP_PER_SAMPLE_STEP = 36.26   # SURVEY.md 8d, hook-counted on the reference (g512/z64, 64x64, RA flags)
 CEM_FWD_GFLOP_PER_CAND_STEP = 24.46
 
@@ -108,7 +109,8 @@ def profile_summary(prof, flops_per_pixel_row):
     rows = prof["events"][0][2]
     avg_ms = float(np.mean(ms))
     flop = flops_per_pixel_row * rows
-    return {"launches": len(ms), "avg_ms": avg_ms, "tflops": flop / (avg_ms * 1e-3) / 1e12, "flop_per_launch": flop}
+    return {"launches": len(ms), "avg_ms": avg_ms, "tflops": flop / (avg_ms * 1e-3) / 1e12, "flop_per_launch": flop,
+            "split": bool(prof.get("split"))}
 
 
 def bench_train(args, dev, rank, world, distributed):
@@ -269,6 +271,13 @@ def main():
                            "step_frac": train["step_tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS}
     if cem is not None:
         k = cem["kernel"]
+        gate = {"avg_launch_ms": k["avg_ms"], "tflops": k["tflops"], "launches": k["launches"]}
+        if k["split"]:  # frozen-model gate GEMM on the bf16 pipe: 3 bf16 parts per operand, 6 part-products
+            gate.update(dtype="bf16x3-split (fp32-equivalent, 6 MFMA products per fp32 product)",
+                        peak=BF16_MFMA_PEAK_TFLOPS / 6, frac=k["tflops"] / (BF16_MFMA_PEAK_TFLOPS / 6),
+                        bf16_mfma_issue_frac=6 * k["tflops"] / BF16_MFMA_PEAK_TFLOPS)
+        else:
+            gate.update(dtype="fp32", peak=F32_MFMA_PEAK_TFLOPS, frac=k["tflops"] / F32_MFMA_PEAK_TFLOPS)
         cem_obj = {"value": cem["rollouts_per_s"], "unit": "candidate-rollouts/s", "s_per_iteration": cem["s_per_iter"],
                    "config": {"workload": "CEM rollouts, BASELINE configs[2]: 1000 candidates/GPU x horizon 15 "
                                           "(14 model steps), frozen g512/z64 model, 64x64, dense image cost",
@@ -276,14 +285,13 @@ def main():
                               "parallelism": f"candidate-shard{world}"},
                    "achieved_tflops_per_gpu": cem["tflops_per_gpu"],
                    "frac_of_f32_mfma_peak": cem["tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS,
-                   "gate_gemm": {"avg_launch_ms": k["avg_ms"], "tflops": k["tflops"],
-                                 "frac": k["tflops"] / F32_MFMA_PEAK_TFLOPS, "launches": k["launches"]}}
+                   "gate_gemm": gate}
         if train is None:
             out.update(value=cem["rollouts_per_s"], unit="candidate-rollouts/s", ms_per_step=cem["s_per_iter"] * 1e3,
                        config=cem_obj["config"],
                        roofline={"bound": "mfma", "kernel": "igemm FWD 5x5 ConvLSTM gate GEMM", "achieved": k["tflops"],
-                                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                 "frac": k["tflops"] / F32_MFMA_PEAK_TFLOPS, "traffic": None})
+                                 "peak": gate["peak"], "unit": "TFLOP/s", "frac": gate["frac"], "traffic": None,
+                                 "dtype": gate["dtype"]})
         out["cem"] = cem_obj
     if rank == 0 and world == 1 and not args.no_cpu_baseline and train is not None:
         out["cpu_baseline"] = cpu_baseline(sd_keep, args)

@@ -138,7 +138,7 @@ class _LstmCell(nn.Module):
         self.gates = _Conv(2 * g, 4 * g, k)
 
     def forward(self, x, state):
-        return ops.LstmCell.apply(x, state[0], state[1], self.gates.weight, self.gates.bias)
+        return ops.LstmCell.apply(x, state[0], state[1], self.gates.weight, self.gates.bias, torch.is_grad_enabled())
 
 
 class _GroupNorm(nn.Module):

@@ -232,7 +232,9 @@ def bias_grad_acc(dy, bias):
 # --------------------------------------------------------------------------- #
 # split-precision (3 x bf16 per operand, 6 part-products) forward GEMMs for the frozen model
 # --------------------------------------------------------------------------- #
-SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "0") == "1"
+# default on: the frozen-model (no-grad) gate GEMMs and wide vgg layers run split-precision; RAC_SPLIT_GEMM=0 keeps
+# everything on the exact-fp32 MFMA path
+SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 
 
 def split_parts(x: torch.Tensor) -> torch.Tensor:
@@ -263,8 +265,17 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=1, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=0, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out), out1=None,
                     bias=None if want_slabs else ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=None)
+    prof = PROFILE
+    timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     call("rac_conv2d_fwd_split", C.byref(args), p0.shape[1], p1.shape[1] if p1 is not None else 0, pw.shape[1],
          stream_ptr())
+    if timed:
+        e1.record()
+        prof["events"].append((e0, e1, M))
+        prof["split"] = True
     if want_slabs:
         return out, 1, M * Cout
     return out
@@ -363,7 +374,12 @@ class VggLayer(torch.autograd.Function):
         weight = weight_used
         if not training:
             scale, shift = folded
-            y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
+            c0 = x0.shape[3]
+            if (SPLIT_GEMM and Cout >= 128 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
+                    and (x1 is None or c0 % 32 == 0)):
+                y = conv_forward_split(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
+            else:
+                y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
             ctx.mark_non_differentiable(y)  # frozen-model path (CEM / eval): no backward through folded BatchNorm
             return y
         dev = x0.device
@@ -480,9 +496,11 @@ class LstmCell(torch.autograd.Function):
     c = f*c_prev + i*g; h = o*tanh(c).  The gate GEMM writes split-K slabs that the cell kernel sums."""
 
     @staticmethod
-    def forward(ctx, x, h_prev, c_prev, weight, bias):
+    def forward(ctx, x, h_prev, c_prev, weight, bias, grad_mode=True):
         B, H, W, g = x.shape
-        need_bwd = any(ctx.needs_input_grad)  # all False under torch.no_grad() (frozen rollouts)
+        # `grad_mode` = torch.is_grad_enabled() at the call site: needs_input_grad mirrors requires_grad even
+        # under torch.no_grad(), and grad mode is always off inside forward()
+        need_bwd = grad_mode and any(ctx.needs_input_grad)
         if SPLIT_GEMM and not need_bwd and g % 32 == 0:
             slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True)
         else:
@@ -513,7 +531,7 @@ class LstmCell(torch.autograd.Function):
             conv_wgrad_acc(dgates, x, h_prev, weight)
         if bias.requires_grad:
             bias_grad_acc(dgates, bias)
-        return dx, dh_prev, dc_prev, None, None
+        return dx, dh_prev, dc_prev, None, None, None
 
 
 class GroupNorm(torch.autograd.Function):
