@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
   const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
 
   u32x4 ra[6], rb[6];  // [part][row]
-  auto issue = [&](int kc) {
+  // byte offsets of one chunk's loads (part 0; parts 1, 2 add the part stride) and the A-side descriptor
+  auto offsets = [&](int kc, unsigned (&oa)[2], unsigned (&ob)[2], rsrc_t& a_rsrc, unsigned& a_pstride) {
     const bool live = kc < kc_end;
     const int tap = kc / p.cchunks;
     const int cc = kc - tap * p.cchunks;
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
     const int Cs = first ? p.a_split : p.Cin - p.a_split;
     const int cl = (first ? c0 : c0 - p.a_split) + schunk * 8;
     const long aps = first ? p.a0_ps : p.a1_ps;
-    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+    a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+    a_pstride = (unsigned)(aps * 2);
     const int shift = dy * p.W + dx;
     const int s0 = tap * p.Cin + c0 + schunk * 8;
     const bool cok = live & (c0 + schunk * 8 < p.Cin);
@@ -101,15 +103,20 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
     for (int i = 0; i < 2; ++i) {
       int yy = a_y[i] + dy, xx = a_x[i] + dx;
       bool ok = live & ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W) & (cl < Cs);
-      unsigned oa = (unsigned)((a_pix[i] + shift) * Cs + cl) * 2u;
-      bool okb = cok & (b_row[i] >= 0);
-      unsigned ob = (unsigned)(b_row[i] + s0) * 2u;
+      oa[i] = ok ? (unsigned)((a_pix[i] + shift) * Cs + cl) * 2u : OOBS;
+      ob[i] = (cok & (b_row[i] >= 0)) ? (unsigned)(b_row[i] + s0) * 2u : OOBS;
+    }
+  };
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  auto issue = [&](const unsigned (&oa)[2], const unsigned (&ob)[2], rsrc_t a_rsrc, unsigned a_pstride) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int part = 0; part < 3; ++part) {
-        ra[part * 2 + i] = ld16(a_rsrc, ok ? oa + (unsigned)(part * aps * 2) : OOBS);
-        rb[part * 2 + i] = ld16(w_rsrc, okb ? ob + (unsigned)(part * p.w_ps * 2) : OOBS);
+        // OOBS + part stride stays out of range: the descriptor covers 3 parts < 4 GiB, OOBS is 2^32 - 16
+        ra[part * 2 + i] = ld16(a_rsrc, oa[i] == OOBS ? OOBS : oa[i] + part * a_pstride);
+        rb[part * 2 + i] = ld16(w_rsrc, ob[i] == OOBS ? OOBS : ob[i] + part * w_pstride);
       }
-    }
   };
   auto store = [&]() {
 #pragma unroll
@@ -130,12 +137,17 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kc_begin < kc_end) {
-    issue(kc_begin);
+    unsigned oa[2], ob[2], na[2], nb[2], aps, naps;
+    rsrc_t ars, nrs;
+    offsets(kc_begin, oa, ob, ars, aps);
+    issue(oa, ob, ars, aps);
+    offsets(kc_begin + 1, oa, ob, ars, aps);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
       store();  // waits for the loads of chunk kc
       __syncthreads();
-      issue(kc + 1);  // in flight under the MFMAs (past the end: zeros)
+      issue(oa, ob, ars, aps);  // chunk kc+1 (offsets from one chunk ago): in flight under the MFMAs
       __builtin_amdgcn_sched_barrier(0);
+      offsets(kc + 2, na, nb, nrs, naps);  // address arithmetic interleaves with the MFMAs below
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 fa[2][3], fb[2][3];
@@ -163,6 +175,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
           }
       }
       __syncthreads();  // every wave is done reading before the next chunk overwrites the buffer
+#pragma unroll
+      for (int i = 0; i < 2; ++i) oa[i] = na[i], ob[i] = nb[i];
+      ars = nrs, aps = naps;
     }
   }
 
