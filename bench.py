@@ -121,6 +121,10 @@ def bench_train(args, dev, rank, world, distributed):
     B, T = cf.batch_size, cf.n_past + cf.n_future
     batches = [syn.synth_video(seed=100 + rank * 1000 + i, T=T, B=B) for i in range(2)]
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
+    for i in range(3):  # prime the caching allocator (new tensor sizes cost a hipMalloc + sync each); not a warmup step
+        tr._train_step(batches[i % 2])
+    torch.cuda.synchronize()
+    log("allocator primed")
     for i in range(args.warmup):
         tr._train_step(batches[i % 2])
         torch.cuda.synchronize()
@@ -160,6 +164,8 @@ def bench_cem(args, dev, rank, world, distributed, model=None):
     goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     g = cf.g_dim
     log(f"cem: model built, {N} candidates")
+    small = syn.synth_cem_problem(seed=0, N=N, T=2)
+    pol.traj_sampler.generate_model_rollouts(small["actions"], start, goal)  # allocator priming, 2 model steps
     for _ in range(args.cem_warmup):
         pol.traj_sampler.generate_model_rollouts(prob["actions"], start, goal)
         log("cem warmup iteration done")

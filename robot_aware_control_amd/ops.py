@@ -99,13 +99,16 @@ def wgrad_padded_acc(dy, x0, weight):
     call("rac_unpad_add", ptr(gp), cp, ptr(weight_mem(grad_buffer(weight))), ci, co * k * k, stream_ptr())
 
 
-def plan_split_k(M: int, N: int, nchunks: int) -> int:
+def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> int:
     """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
     choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
     forced = os.environ.get("RAC_SPLIT")
     if forced:
         return max(1, min(int(forced), nchunks))
     cap = max(1, nchunks // 8)  # keep >= 8 chunks per split: the pipeline prologue/epilogue must amortise
+    if tile128_only:  # the split-precision kernel has one tile shape
+        t128 = _cdiv(M, 128) * _cdiv(N, 128)
+        return 1 if t128 >= 384 else max(1, min(8, _cdiv(512, t128), cap))
     if N <= 32:
         tiles = _cdiv(M, 128)
         return 1 if tiles >= 384 else max(1, min(8, _cdiv(512, tiles), cap))
@@ -235,6 +238,9 @@ def bias_grad_acc(dy, bias):
 # default on: the frozen-model (no-grad) gate GEMMs and wide vgg layers run split-precision; RAC_SPLIT_GEMM=0 keeps
 # everything on the exact-fp32 MFMA path
 SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
+# the training step's ConvLSTM gate GEMMs: forward and data gradient on the split-precision pipe (the weight
+# gradient stays on exact-fp32 MFMA)
+SPLIT_GEMM_TRAIN = os.environ.get("RAC_SPLIT_GEMM_TRAIN", "1") == "1"
 
 
 def split_parts(x: torch.Tensor) -> torch.Tensor:
@@ -250,21 +256,11 @@ def split_weight(weight: torch.Tensor) -> torch.Tensor:
     return _derived(weight, "_rac_split", lambda: split_parts(weight_mem(weight)))
 
 
-def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, want_slabs=False):
-    """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h)."""
-    _require_cuda(x0)
-    B, H, W, C0 = x0.shape
-    C1 = x1.shape[3] if x1 is not None else 0
-    Cout, Cin, k, _ = weight.shape
-    assert Cin == C0 + C1
-    M = B * H * W
-    p0 = split_parts(x0)
-    p1 = split_parts(x1) if x1 is not None else None
-    pw = split_weight(weight)
-    out = torch.empty((1, B, H, W, Cout) if want_slabs else (B, H, W, Cout), device=x0.device, dtype=torch.float32)
-    args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=1, accumulate=0,
-                    a_split=C0, o_split=0, slab_stride=0, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out), out1=None,
-                    bias=None if want_slabs else ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=None)
+def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
+                  split_k=1, slab_stride=0):
+    args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
+                    a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out),
+                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=None)
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -274,11 +270,62 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
          stream_ptr())
     if timed:
         e1.record()
-        prof["events"].append((e0, e1, M))
+        prof["events"].append((e0, e1, B * H * W))
         prof["split"] = True
+
+
+def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, want_slabs=False):
+    """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
+    `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel."""
+    _require_cuda(x0)
+    B, H, W, C0 = x0.shape
+    C1 = x1.shape[3] if x1 is not None else 0
+    Cout, Cin, k, _ = weight.shape
+    assert Cin == C0 + C1
+    M = B * H * W
+    p0 = split_parts(x0)
+    p1 = split_parts(x1) if x1 is not None else None
+    pw = split_weight(weight)
     if want_slabs:
-        return out, 1, M * Cout
+        split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
+        out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
+        _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
+                      slab_stride=M * Cout)
+        return out, split, M * Cout
+    out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
+    _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
+                  shift=shift)
     return out
+
+
+def transposed_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(Cin, Cout, k, k) channels_last tensor with taps flipped: the weight of the conv that IS the data gradient
+    (dgrad(dy, W) == fwd(dy, Wt)); cached until the parameter changes."""
+    def build():
+        return weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous(memory_format=torch.channels_last)
+    return _derived(weight, "_rac_transposed", build)
+
+
+def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
+    """Data gradient on the split-precision pipe: forward conv of dy with the transposed, tap-flipped weight."""
+    B, H, W, Cout = dy.shape
+    Co, Cin, k, _ = weight.shape
+    assert Co == Cout and Cin == C0 + C1
+    M = B * H * W
+    wt = transposed_weight(weight)  # (Cin, Cout, k, k)
+    pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(wt)))
+    pd = split_parts(dy)
+    split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
+    slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
+    _split_launch(pd, None, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout, split_k=split,
+                  slab_stride=M * Cin)
+    dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
+    if C1:
+        dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
+        call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
+        return dx0, dx1
+    call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
+    return dx0, None
 
 
 # --------------------------------------------------------------------------- #
@@ -501,7 +548,7 @@ class LstmCell(torch.autograd.Function):
         # `grad_mode` = torch.is_grad_enabled() at the call site: needs_input_grad mirrors requires_grad even
         # under torch.no_grad(), and grad mode is always off inside forward()
         need_bwd = grad_mode and any(ctx.needs_input_grad)
-        if SPLIT_GEMM and not need_bwd and g % 32 == 0:
+        if g % 32 == 0 and ((SPLIT_GEMM and not need_bwd) or (SPLIT_GEMM_TRAIN and need_bwd)):
             slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True)
         else:
             slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
@@ -526,7 +573,10 @@ class LstmCell(torch.autograd.Function):
              ptr(dc_prev), M, g, stream_ptr())
         dx = dh_prev = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dx, dh_prev = conv_dgrad(dgates, weight, g, g)
+            if SPLIT_GEMM_TRAIN and g % 32 == 0:
+                dx, dh_prev = conv_dgrad_split(dgates, weight, g, g)
+            else:
+                dx, dh_prev = conv_dgrad(dgates, weight, g, g)
         if weight.requires_grad:
             conv_wgrad_acc(dgates, x, h_prev, weight)
         if bias.requires_grad:
