@@ -48,6 +48,38 @@ __device__ __forceinline__ int lds_off(int part, int row, int chunk) {  // in 16
   return (part * 128 + row) * 4 + (chunk ^ ((row >> 2) & 3));
 }
 
+
+// The 48 MFMAs of one 32-deep K chunk for a wave's 2x2 accumulators: both operands from the swizzled LDS image.
+__device__ __forceinline__ void split_mma_chunk(const u32x4* As, const u32x4* Bs, f32x16 (&acc)[2][2], int wm, int wn,
+                                                int li, int lh) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 fa[2][3], fb[2][3];
+    const int chunk = 2 * s + lh;  // MFMA k = 16 s + 8 h + j
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        fa[t][part] = __builtin_bit_cast(bf16x8, As[lds_off(part, (wm * 2 + t) * 32 + li, chunk)]);
+        fb[t][part] = __builtin_bit_cast(bf16x8, Bs[lds_off(part, (wn * 2 + t) * 32 + li, chunk)]);
+      }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x16 c = acc[mt][nt];
+        // smallest terms first: (3,1) (2,2) (1,3) | (2,1) (1,2) | (1,1)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], c, 0, 0, 0);
+        acc[mt][nt] = c;
+      }
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
   extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2 operands][3][128][4] x 16 B = 48 KB
   u32x4* As = lds;
@@ -148,32 +180,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
       issue(oa, ob, ars, aps);  // chunk kc+1 (offsets from one chunk ago): in flight under the MFMAs
       __builtin_amdgcn_sched_barrier(0);
       offsets(kc + 2, na, nb, nrs, naps);  // address arithmetic interleaves with the MFMAs below
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        bf16x8 fa[2][3], fb[2][3];
-        const int chunk = 2 * s + lh;  // MFMA k = 16 s + 8 h + j
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int part = 0; part < 3; ++part) {
-            fa[t][part] = __builtin_bit_cast(bf16x8, As[lds_off(part, (wm * 2 + t) * 32 + li, chunk)]);
-            fb[t][part] = __builtin_bit_cast(bf16x8, Bs[lds_off(part, (wn * 2 + t) * 32 + li, chunk)]);
-          }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            f32x16 c = acc[mt][nt];
-            // smallest terms first: (3,1) (2,2) (1,3) | (2,1) (1,2) | (1,1)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], c, 0, 0, 0);
-            acc[mt][nt] = c;
-          }
-      }
+      split_mma_chunk(As, Bs, acc, wm, wn, li, lh);
       __syncthreads();  // every wave is done reading before the next chunk overwrites the buffer
 #pragma unroll
       for (int i = 0; i < 2; ++i) oa[i] = na[i], ob[i] = nb[i];
@@ -225,6 +232,173 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
         atomicAdd(p.stats + n, (double)s1);
         atomicAdd(p.stats + p.N + n, (double)s2);
       }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient on the split-precision pipe.
+//   dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]
+// The bf16 MFMA wants 8 consecutive k (= pixels) per lane for both operands, so both are consumed TRANSPOSED:
+//   A = dyT[co][p] parts, B = xT_dx[ci][p] parts, where xT_dx is x shifted by dx along the image row with the
+//   out-of-row pixels zeroed (one copy per kernel column; rac_transpose_split builds them).  The row shift dy is a
+//   multiple of W >= 8 pixels, i.e. a whole number of 16-byte vectors, applied in the load offset with the
+//   rows that leave the image returned as zeros by the buffer range check.
+// One workgroup = (128 output channels) x (128 input channels of one tap); K = pixels in chunks of 32.
+// ---------------------------------------------------------------------------------------------------------
+struct WgradSplitP {
+  int H, W, ks, pad, Cin, Cout, a_split, split_k, P, HW, taps, nchunks, cps, ntile_per_tap;
+  const unsigned short *x0t, *x1t, *dyt;  // [ks][3][C0][P], [ks][3][C1][P], [3][Cout][P]
+  float* dw;
+  unsigned long long magic_hw, magic_w;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitP p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+  u32x4* As = lds;
+  u32x4* Bs = lds + 3 * 128 * 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * SBM;
+  const int tap = blockIdx.y / p.ntile_per_tap;
+  const int n0 = (blockIdx.y - tap * p.ntile_per_tap) * SBN;
+  const int ky = tap / p.ks, kx = tap - ky * p.ks;
+  const int dy = ky - p.pad;
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  const int srow = tid >> 2, schunk = tid & 3;
+
+  // block-uniform source of this channel range (virtual concat [x0 | x1])
+  const bool first = n0 < p.a_split;
+  const int Cs = first ? p.a_split : p.Cin - p.a_split;
+  const int nl0 = first ? n0 : n0 - p.a_split;
+  const long xps = (long)Cs * p.P;  // part stride of the chosen source
+  const unsigned short* xbase = (first ? p.x0t : p.x1t) + (long)kx * 3 * xps;
+  const rsrc_t x_rsrc = mk_rsrc(xbase, (unsigned)(3 * xps * 2));
+  const long dps = (long)p.Cout * p.P;
+  const rsrc_t d_rsrc = mk_rsrc(p.dyt, (unsigned)(3 * dps * 2));
+
+  int a_base[2], b_base[2];  // row * P, or -1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int co = m0 + srow + 64 * i;
+    a_base[i] = co < p.Cout ? co * p.P : -1;
+    int cl = nl0 + srow + 64 * i;
+    b_base[i] = (n0 + srow + 64 * i < p.Cin && cl < Cs) ? cl * p.P : -1;
+  }
+
+  u32x4 ra[6], rb[6];
+  auto issue = [&](int kc) {
+    const bool live = kc < kc_end;
+    const int px = kc * SBK + schunk * 8;  // first pixel of this lane's 8-pixel vector (never straddles an image row)
+    const bool pok = live & (px < p.P);
+    const int b = (int)(((unsigned long long)(unsigned)px * p.magic_hw) >> 40);
+    const int r = px - b * p.HW;
+    const int y = (int)(((unsigned long long)(unsigned)r * p.magic_w) >> 40);
+    const bool yok = pok & ((unsigned)(y + dy) < (unsigned)p.H);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool oka = pok & (a_base[i] >= 0);
+      const bool okb = yok & (b_base[i] >= 0);
+      const unsigned oa = (unsigned)(a_base[i] + px) * 2u;
+      const unsigned ob = (unsigned)(b_base[i] + px + dy * p.W) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) {
+        ra[part * 2 + i] = ld16(d_rsrc, oka ? oa + (unsigned)(part * dps * 2) : OOBS);
+        rb[part * 2 + i] = ld16(x_rsrc, okb ? ob + (unsigned)(part * xps * 2) : OOBS);
+      }
+    }
+  };
+  auto store = [&]() {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        As[lds_off(part, srow + 64 * i, schunk)] = ra[part * 2 + i];
+        Bs[lds_off(part, srow + 64 * i, schunk)] = rb[part * 2 + i];
+      }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    issue(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      store();
+      __syncthreads();
+      issue(kc + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      split_mma_chunk(As, Bs, acc, wm, wn, li, lh);
+      __syncthreads();
+    }
+  }
+
+  // dw[co][tap][ci] += acc   (C/D layout: col = lane & 31 -> ci, row -> co)
+  const long wrow = (long)p.taps * p.Cin;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + (wn * 2 + nt) * 32 + li;
+    if (n >= p.Cin || (first ? n >= p.a_split : false)) continue;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.Cout) continue;
+        float* dst = p.dw + m * wrow + (long)tap * p.Cin + n;
+        if (p.split_k > 1)
+          atomicAdd(dst, acc[mt][nt][r]);
+        else
+          *dst += acc[mt][nt][r];
+      }
+  }
+}
+
+// out[dxi][part][c][p] = part-th bf16 part of (x in-row ? in[p + dx][c] : 0), dx = dxi - pad, dxi < ndx
+// (ndx = 1: plain transpose + split).  32x32 tiles through LDS: coalesced on both sides.
+__global__ void transpose_split_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad) {
+  __shared__ float tile[32][33];
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int dxi = blockIdx.z;
+  const int dx = dxi - pad;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pr = p0 + ty + 8 * i;  // output pixel
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (pr < P && c < C) {
+      const int x = pr % W;
+      if ((unsigned)(x + dx) < (unsigned)W) v = in[(long)(pr + dx) * C + c];
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+  const long ps = (long)C * P;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + 8 * i;
+    const int pr = p0 + tx;
+    if (c < C && pr < P) {
+      const float a = tile[tx][ty + 8 * i];
+      const __bf16 q1 = (__bf16)a;
+      const float r1 = a - (float)q1;
+      const __bf16 q2 = (__bf16)r1;
+      const __bf16 q3 = (__bf16)(r1 - (float)q2);
+      unsigned short* o = out + (long)dxi * 3 * ps + (long)c * P + pr;
+      o[0] = __builtin_bit_cast(unsigned short, q1);
+      o[ps] = __builtin_bit_cast(unsigned short, q2);
+      o[2 * ps] = __builtin_bit_cast(unsigned short, q3);
     }
   }
 }
@@ -304,4 +478,64 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   dim3 grid(cdiv(p.M, SBM), cdiv(p.N, SBN), p.split_k);
   hipLaunchKernelGGL(igemm_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split");
+}
+
+extern "C" int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx,
+                                   void* stream) {
+  RAC_REQUIRE(x && out && P > 0 && C > 0 && W > 0 && ndx >= 1 && (ndx & 1), "rac_transpose_split: bad args");
+  hipLaunchKernelGGL(transpose_split_kernel, dim3(cdiv(P, 32), cdiv(C, 32), ndx), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2);
+  return check_launch("rac_transpose_split");
+}
+
+extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, void* stream) {
+  RAC_REQUIRE(a && a->mode == RAC_CONV_WGRAD, "rac_conv2d_wgrad_split: weight-gradient mode only");
+  RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0,
+              "rac_conv2d_wgrad_split: bad args");
+  RAC_REQUIRE(a->ksize >= 1 && (a->ksize & 1) && a->ksize <= 7, "rac_conv2d_wgrad_split: ksize must be odd");
+  RAC_REQUIRE(a->W % 8 == 0, "rac_conv2d_wgrad_split: image width must be a multiple of 8 (16-byte pixel vectors)");
+  WgradSplitP p{};
+  p.H = a->H, p.W = a->W, p.ks = a->ksize, p.pad = a->ksize / 2;
+  p.Cin = a->Cin, p.Cout = a->Cout;
+  p.HW = a->H * a->W;
+  p.P = a->B * p.HW;
+  p.taps = a->ksize * a->ksize;
+  p.a_split = (a->a1 && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
+  RAC_REQUIRE(p.a_split == a->Cin || p.a_split % SBN == 0,
+              "rac_conv2d_wgrad_split: a_split must be a multiple of 128 (block-uniform source)");
+  p.x0t = reinterpret_cast<const unsigned short*>(a->a0);
+  p.x1t = reinterpret_cast<const unsigned short*>(a->a1);
+  p.dyt = reinterpret_cast<const unsigned short*>(a->w);
+  p.dw = a->out0;
+  RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_wgrad_split: alignment");
+  const long big = (long)3 * p.P * (a->Cout > a->Cin ? a->Cout : a->Cin) * 2;
+  RAC_REQUIRE(big < 0xFFFFFF00L, "rac_conv2d_wgrad_split: operand larger than 4 GiB");
+  p.magic_hw = ((1ULL << 40) + p.HW - 1) / p.HW;
+  p.magic_w = ((1ULL << 40) + a->W - 1) / a->W;
+  p.nchunks = cdiv(p.P, SBK);
+  p.ntile_per_tap = cdiv(a->Cin, SBN);
+  const long tiles = (long)cdiv(a->Cout, SBM) * p.ntile_per_tap * p.taps;
+  int split = a->split_k;
+  if (split <= 0) {  // auto: atomics only when the tile count cannot fill the chip
+    split = 1;
+    if (tiles < 512) split = (int)((768 + tiles - 1) / tiles);
+    if (split > p.nchunks / 8) split = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;
+    if (split > 64) split = 64;
+  }
+  p.split_k = split;
+  p.cps = cdiv(p.nchunks, split);
+  constexpr size_t lds = 2 * 3 * 128 * 4 * 16;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return RAC_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(cdiv(a->Cout, SBM), p.ntile_per_tap * p.taps, split);
+  hipLaunchKernelGGL(wgrad_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("rac_conv2d_wgrad_split");
 }

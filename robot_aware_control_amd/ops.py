@@ -328,6 +328,34 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     return dx0, None
 
 
+def conv_wgrad_split_acc(dy, x0, x1, weight):
+    """weight.grad += dW on the split-precision pipe (transposed bf16 parts of dy and of the dx-shifted inputs)."""
+    B, H, W, Cout = dy.shape
+    Co, Cin, k, _ = weight.shape
+    C0 = x0.shape[3]
+    C1 = x1.shape[3] if x1 is not None else 0
+    P = B * H * W
+    dev = dy.device
+    dyt = torch.empty((3, Cout, P), device=dev, dtype=torch.bfloat16)
+    call("rac_transpose_split", ptr(dy), ptr(dyt), P, Cout, W, 1, stream_ptr())
+    x0t = torch.empty((k, 3, C0, P), device=dev, dtype=torch.bfloat16)
+    call("rac_transpose_split", ptr(x0), ptr(x0t), P, C0, W, k, stream_ptr())
+    x1t = None
+    if C1:
+        x1t = torch.empty((k, 3, C1, P), device=dev, dtype=torch.bfloat16)
+        call("rac_transpose_split", ptr(x1), ptr(x1t), P, C1, W, k, stream_ptr())
+    g = weight_mem(grad_buffer(weight))
+    args = ConvArgs(mode=WGRAD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
+                    a_split=C0, o_split=0, slab_stride=0, a0=ptr(x0t), a1=ptr(x1t), w=ptr(dyt), out0=ptr(g), out1=None,
+                    bias=None, scale=None, shift=None, stats=None)
+    call("rac_conv2d_wgrad_split", C.byref(args), stream_ptr())
+
+
+def wgrad_split_ok(x0, x1, W: int) -> bool:
+    c0 = x0.shape[3]
+    return SPLIT_GEMM_TRAIN and W % 8 == 0 and c0 % 8 == 0 and (x1 is None or (c0 % 128 == 0 and x1.shape[3] % 8 == 0))
+
+
 # --------------------------------------------------------------------------- #
 # autograd functions
 # --------------------------------------------------------------------------- #
@@ -578,7 +606,10 @@ class LstmCell(torch.autograd.Function):
             else:
                 dx, dh_prev = conv_dgrad(dgates, weight, g, g)
         if weight.requires_grad:
-            conv_wgrad_acc(dgates, x, h_prev, weight)
+            if wgrad_split_ok(x, h_prev, W):
+                conv_wgrad_split_acc(dgates, x, h_prev, weight)
+            else:
+                conv_wgrad_acc(dgates, x, h_prev, weight)
         if bias.requires_grad:
             bias_grad_acc(dgates, bias)
         return dx, dh_prev, dc_prev, None, None, None

@@ -346,3 +346,26 @@ def test_conv_split_precision_bf16x6(dev, case):
     e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
     e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
     assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3)])
+def test_wgrad_split_precision(dev, case):
+    """Weight gradient from transposed bf16 parts (dx-shifted input copies, dy as whole-vector offsets)."""
+    from robot_aware_control_amd import ops
+    B, H, W, C0, C1, Cout, k = case
+    Cin = C0 + C1
+    x = rnd(1, B, Cin, H, W)
+    w = (rnd(2, Cout, Cin, k, k) * 0.02).requires_grad_(True)
+    gy = rnd(4, B, Cout, H, W)
+    F.conv2d(x.double(), w.double(), None, 1, k // 2).backward(gy.double())  # fp64 reference... via float weight
+    ref = w.grad.double()
+    x0, x1 = to_map(x[:, :C0], dev), (to_map(x[:, C0:], dev) if C1 else None)
+    wd = cl_weight(w.detach()).to(dev).requires_grad_(True)
+    ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)
+    e_split = relerr(wd.grad.cpu(), ref)
+    wd2 = cl_weight(w.detach()).to(dev).requires_grad_(True)
+    ops.conv_wgrad_acc(to_map(gy, dev), x0, x1, wd2)
+    e_fp32 = relerr(wd2.grad.cpu(), ref)
+    assert e_split < 3e-6 and e_split < 4 * e_fp32 + 3e-7, (e_split, e_fp32)
+    ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)  # accumulates
+    assert relerr(wd.grad.cpu(), 2 * ref) < 3e-6

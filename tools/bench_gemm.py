@@ -70,3 +70,17 @@ if mode == "fwd" and os.environ.get("RAC_BENCH_SPLIT"):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"  kernel only: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective", flush=True)
+
+if mode == "wgrad" and os.environ.get("RAC_BENCH_SPLIT"):
+    def run3():
+        return ops.conv_wgrad_split_acc(dy, x, h, w)
+    for _ in range(3):
+        run3()
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        run3()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"wgrad-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective (incl. transposes)", flush=True)
