@@ -241,6 +241,9 @@ SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 # the training step's ConvLSTM gate GEMMs: forward and data gradient on the split-precision pipe (the weight
 # gradient stays on exact-fp32 MFMA)
 SPLIT_GEMM_TRAIN = os.environ.get("RAC_SPLIT_GEMM_TRAIN", "1") == "1"
+# the vgg layers of the training step on the same pipe: measured slower at cfg2 (76.1 vs 72.2 ms/step: small M at
+# the 8x8/16x16 layers, 128x128-only tile, per-call operand splitting), so off by default
+SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "0") == "1"
 
 
 def split_parts(x: torch.Tensor) -> torch.Tensor:
@@ -257,10 +260,10 @@ def split_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
-                  split_k=1, slab_stride=0):
+                  stats=None, split_k=1, slab_stride=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out),
-                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=None)
+                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats))
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -274,7 +277,8 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
         prof["split"] = True
 
 
-def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, want_slabs=False):
+def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
+                       want_slabs=False):
     """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel."""
     _require_cuda(x0)
@@ -293,8 +297,18 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
                       slab_stride=M * Cout)
         return out, split, M * Cout
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
-    _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
-                  shift=shift)
+    fused = act != ACT_NONE or scale is not None
+    split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
+    if split == 1:
+        _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
+                      shift=shift, stats=stats)
+    else:
+        slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
+        _split_launch(p0, p1, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
+                      slab_stride=M * Cout)
+        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
+        if stats is not None:
+            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, stream_ptr())
     return out
 
 
@@ -459,7 +473,13 @@ class VggLayer(torch.autograd.Function):
             return y
         dev = x0.device
         stats = torch.zeros((2, Cout), device=dev, dtype=torch.float64)
-        raw = conv_forward(x0, x1, weight, None, stats=stats)
+        c0 = x0.shape[3]
+        ctx.split = (SPLIT_VGG_TRAIN and Cout >= 128 and c0 >= 64 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
+                     and (x1 is None or c0 % 128 == 0) and x0.shape[2] % 8 == 0)
+        if ctx.split:
+            raw = conv_forward_split(x0, x1, weight, None, stats=stats)
+        else:
+            raw = conv_forward(x0, x1, weight, None, stats=stats)
         M = raw.numel() // Cout
         aff = torch.empty((4, Cout), device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
         call("rac_bn_finalize", ptr(stats), M, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
@@ -487,10 +507,15 @@ class VggLayer(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dx0, dx1 = conv_dgrad(draw, padded_weight(weight) if ctx.padded else weight, C0, C1)
+            if ctx.split:
+                dx0, dx1 = conv_dgrad_split(draw, weight, C0, C1)
+            else:
+                dx0, dx1 = conv_dgrad(draw, padded_weight(weight) if ctx.padded else weight, C0, C1)
         if weight.requires_grad:
             if ctx.padded:
                 wgrad_padded_acc(draw, x0, weight)
+            elif ctx.split and wgrad_split_ok(x0, x1, x0.shape[2]):
+                conv_wgrad_split_acc(draw, x0, x1, weight)
             else:
                 conv_wgrad_acc(draw, x0, x1, weight)
         return dx0, dx1, None, None, None, None, None, None, None, None
