@@ -24,6 +24,7 @@ struct SplitP {
   const float *bias, *scale, *shift;
   double* stats;
   int M, N, HW, P, taps, cchunks, nchunks, cps;
+  int w_chunk_major;  // weights stored [Cout][Cin/32][taps][32] (tap-inner streaming order) instead of [Cout][taps][Cin]
 };
 
 constexpr unsigned OOBS = 0xFFFFFFF0u;
@@ -238,6 +239,209 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------
+// Tap-inner forward kernel for latent-resolution convs (H*W divides 128: the 8x8 ConvLSTM maps).
+// A 128-pixel M-tile then holds WHOLE images, so every tap of the k x k window reads pixels of the same tile:
+// the activation chunk (128 pixels x 32 channels x 3 parts) is staged in LDS ONCE per channel chunk and all
+// k*k taps reuse it through shifted fragment reads (rows that leave the image read a zero line), instead of
+// being re-fetched from L2 / Infinity Cache per tap.  Only the weight chunk streams per tap (double-buffered):
+// half the CU <- L2 bytes of the tap-outer kernel and 1/25 of its activation traffic at k = 5; PMC had
+// shown that kernel pulling ~10 TB/s through the fabric (80x the unique bytes).
+// K order is (channel chunk, tap) instead of (tap, channel chunk): only the summation order changes.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+  u32x4* As = lds;                      // [3][128][4]
+  u32x4* Bs = lds + 3 * 128 * 4;        // [2 buffers][3][128][4]
+  u32x4* Zs = lds + 3 * 3 * 128 * 4;    // 4 x 16 B of zeros
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int m0 = blockIdx.x * SBM, n0 = blockIdx.y * SBN;
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  if (tid < 4) Zs[tid] = u32x4{0u, 0u, 0u, 0u};
+
+  const int srow = tid >> 2, schunk = tid & 3;
+  int b_row[2];
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    a_ok[i] = m0 + srow + 64 * i < p.M;
+    int n = n0 + srow + 64 * i;
+    b_row[i] = (n < p.N) ? n * p.taps * p.Cin : -1;
+  }
+  // fragment rows of this lane: position inside its image, for the tap shift
+  int f_img[2], f_y[2], f_x[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int r = (wm * 2 + t) * 32 + li;
+    const int im = r / p.HW;
+    const int q = r - im * p.HW;
+    f_img[t] = im * p.HW;
+    f_y[t] = q / p.W;
+    f_x[t] = q - f_y[t] * p.W;
+  }
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+
+  u32x4 ra[6], rb[6];
+  auto issue_a = [&](int cc, bool live) {  // activation chunk `cc`, unshifted pixels of this tile
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = (first ? c0 : c0 - p.a_split) + schunk * 8;
+    const long aps = first ? p.a0_ps : p.a1_ps;
+    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = live & a_ok[i] & (cl < Cs);
+      const unsigned oa = (unsigned)((m0 + srow + 64 * i) * Cs + cl) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        ra[part * 2 + i] = ld16(a_rsrc, ok ? oa + (unsigned)(part * aps * 2) : OOBS);
+    }
+  };
+  auto issue_b = [&](int kc) {  // weight chunk of (cc, tap) = (kc / taps, kc % taps)
+    const bool live = kc < kc_end;
+    const int cc = kc / p.taps;
+    const int tap = kc - cc * p.taps;
+    const int c0 = cc * SBK;
+    const int s0 = p.w_chunk_major ? (cc * p.taps + tap) * SBK + schunk * 8 : tap * p.Cin + c0 + schunk * 8;
+    const bool cok = live & (c0 + schunk * 8 < p.Cin);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = cok & (b_row[i] >= 0);
+      const unsigned ob = (unsigned)(b_row[i] + s0) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) rb[part * 2 + i] = ld16(w_rsrc, ok ? ob + part * w_pstride : OOBS);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    issue_a(kc_begin / p.taps, true);
+    issue_b(kc_begin);
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
+      const int cc = kc / p.taps;
+      const int tap = kc - cc * p.taps;
+      const int buf = (kc - kc_begin) & 1;
+      u32x4* Bb = Bs + buf * (3 * 128 * 4);
+      const bool new_a = (kc == kc_begin) | (tap == 0);
+      if (new_a) {
+        __syncthreads();  // every wave has finished the previous channel chunk's fragment reads
+#pragma unroll
+        for (int part = 0; part < 3; ++part)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) As[lds_off(part, srow + 64 * i, schunk)] = ra[part * 2 + i];
+      }
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) Bb[lds_off(part, srow + 64 * i, schunk)] = rb[part * 2 + i];
+      __syncthreads();
+      issue_b(kc + 1);  // weights of the next tap: in flight under the MFMAs
+      if (tap == p.taps - 1) issue_a(cc + 1, kc + 1 < kc_end);  // next channel chunk's activations
+      __builtin_amdgcn_sched_barrier(0);
+
+      // tap shift on the A fragment rows: rows that leave their image read the zero line
+      const int ky = tap / p.ks, kx = tap - ky * p.ks;
+      const int dy = ky - p.pad, dx = kx - p.pad;
+      int arow[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int yy = f_y[t] + dy, xx = f_x[t] + dx;
+        const bool ok = ((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W);
+        arow[t] = ok ? f_img[t] + yy * p.W + xx : -1;
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[2][3], fb[2][3];
+        const int chunk = 2 * s + lh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            const u32x4* src = arow[t] >= 0 ? As + lds_off(part, arow[t], chunk) : Zs + chunk;
+            fa[t][part] = __builtin_bit_cast(bf16x8, *src);
+            fb[t][part] = __builtin_bit_cast(bf16x8, Bb[lds_off(part, (wn * 2 + t) * 32 + li, chunk)]);
+          }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            f32x16 c = acc[mt][nt];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], c, 0, 0, 0);
+            acc[mt][nt] = c;
+          }
+      }
+    }
+  }
+
+  // ---- epilogue (same semantics as rac_conv2d FWD) ----
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = n0 + (wn * 2 + nt) * 32 + li;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (wm * 2 + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M || !nok) continue;
+        float v = acc[mt][nt][r];
+        if (slab) {
+          p.out0[(long)blockIdx.z * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        s1 += v;
+        s2 += v * v;
+        v = v * sc + sh;
+        if (p.act == RAC_ACT_LEAKY02)
+          v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == RAC_ACT_SIGMOID)
+          v = sigmoid_acc(v);
+        p.out0[(long)m * p.N + n] = v;
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0 && nok) {
+        atomicAdd(p.stats + n, (double)s1);
+        atomicAdd(p.stats + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient on the split-precision pipe.
 //   dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]
 // The bf16 MFMA wants 8 consecutive k (= pixels) per lane for both operands, so both are consumed TRANSPOSED:
@@ -431,7 +635,7 @@ extern "C" int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int6
 }
 
 extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64_t a1_ps, int64_t w_ps,
-                                    void* stream) {
+                                    int32_t w_chunk_major, void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0,
               "rac_conv2d_fwd_split: bad args");
@@ -476,6 +680,27 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
     attr_done = true;
   }
   dim3 grid(cdiv(p.M, SBM), cdiv(p.N, SBN), p.split_k);
+  static const bool no_tapinner = getenv("RAC_SPLIT_TAPOUTER") != nullptr;  // A/B switch for benchmarks
+  p.w_chunk_major = 0;
+  RAC_REQUIRE(!w_chunk_major || (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0),
+              "rac_conv2d_fwd_split: chunk-major weights need Cin % 32 == 0 and whole images per 128-pixel tile");
+  if ((w_chunk_major || !no_tapinner) && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1) {
+    p.w_chunk_major = w_chunk_major;
+    // whole images per M-tile: activations staged once per channel chunk, taps inner
+    constexpr size_t lds_ti = (3 * 3 * 128 * 4 + 4) * 16;  // A + 2 x B + zero line = 73,792 B
+    static bool ti_attr = false;
+    if (!ti_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_tapinner_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ti);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      ti_attr = true;
+    }
+    hipLaunchKernelGGL(igemm_split_tapinner_kernel, grid, dim3(256), lds_ti, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_fwd_split(tap-inner)");
+  }
   hipLaunchKernelGGL(igemm_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split");
 }

@@ -321,11 +321,16 @@ def test_cem_step_tail(dev, golden_dir):
         np.testing.assert_allclose(cost.cpu().numpy(), g[key].astype(np.float64), rtol=2e-6)
 
 
-@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3)])
-def test_conv_split_precision_bf16x6(dev, case):
-    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe."""
+@pytest.mark.parametrize("tapinner", [False, True])
+@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3),
+                                  (5, 4, 8, 32, 64, 160, 3)])
+def test_conv_split_precision_bf16x6(dev, case, tapinner, monkeypatch):
+    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe.  Both
+    kernels: tap-outer (any shape) and tap-inner (whole images per 128-row tile, chunk-major weights)."""
     from robot_aware_control_amd import ops
+    monkeypatch.setattr(ops, "TAPINNER_MIN_TILES", 0 if tapinner else 1 << 30)
     B, H, W, C0, C1, Cout, k = case
+    assert ops.tapinner_ok(H, W, C0 + C1, k, B * H * W, Cout) == tapinner
     Cin = C0 + C1
     # exactness of the fragment layout: small integers live entirely in the first bf16 part
     g = np.random.Generator(np.random.Philox(key=[9, 9]))
@@ -346,6 +351,14 @@ def test_conv_split_precision_bf16x6(dev, case):
     e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
     e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
     assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)
+    # data gradient = forward conv with the transposed, tap-flipped weight (same two kernels)
+    if Cout % 32 == 0:
+        gy = rnd(4, B, Cout, H, W)
+        xr = x.double().requires_grad_(True)
+        F.conv2d(xr, w.double(), None, 1, k // 2).backward(gy.double())
+        d0, d1 = ops.conv_dgrad_split(to_map(gy, dev), wd, C0, C1)
+        got = torch.cat([from_map(d0)] + ([from_map(d1)] if C1 else []), 1)
+        assert relerr(got, xr.grad) < 2e-6
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3)])
