@@ -84,6 +84,10 @@ def max_over_ranks(x, dev, distributed):
     return float(t.item())
 
 
+def _cdiv(a, b):
+    return (a + b - 1) // b
+
+
 def pmc_traffic(tag, kernel_substr, workgroups):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC profile
     (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)."""
@@ -278,8 +282,9 @@ def main():
                            "algorithmic_tflop_per_step_per_gpu": 8.70})
         k = train["kernel"]
         gr = gate_roofline(k)
-        kname = "igemm_split_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128"
-        traffic, traffic_src = pmc_traffic("train", kname, 512)
+        kname = "igemm_split_tapinner_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128"
+        # PMC pass over exactly this launch (tools/bench_gemm.py at the same shape; tools/run_profiles.sh)
+        traffic, traffic_src = pmc_traffic("gemm_train", kname, 512)
         out["roofline"] = {"bound": "mfma", "kernel": "FWD 5x5 ConvLSTM gate GEMM (M=1024,N=2048,K=25600), " + gr["dtype"],
                            "achieved": k["tflops"], "peak": gr["peak"], "unit": "TFLOP/s", "frac": gr["frac"],
                            "traffic": traffic, "traffic_source": traffic_src,
@@ -294,6 +299,9 @@ def main():
         k = cem["kernel"]
         gate = {"avg_launch_ms": k["avg_ms"], "tflops": k["tflops"], "launches": k["launches"]}
         gate.update(gate_roofline(k))
+        gate["traffic"], gate["traffic_source"] = pmc_traffic(
+            "gemm_cem", "igemm_split_tapinner_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128",
+            _cdiv(cem["candidates_batch_size"] * 64, 128) * 16)
         cem_obj = {"value": cem["rollouts_per_s"], "unit": "candidate-rollouts/s", "s_per_iteration": cem["s_per_iter"],
                    "config": {"workload": "CEM rollouts, BASELINE configs[2]: 1000 candidates/GPU x horizon 15 "
                                           "(14 model steps), frozen g512/z64 model, 64x64, dense image cost",
@@ -306,7 +314,7 @@ def main():
             out.update(value=cem["rollouts_per_s"], unit="candidate-rollouts/s", ms_per_step=cem["s_per_iter"] * 1e3,
                        config=cem_obj["config"],
                        roofline={"bound": "mfma", "kernel": "igemm FWD 5x5 ConvLSTM gate GEMM", "achieved": k["tflops"],
-                                 "peak": gate["peak"], "unit": "TFLOP/s", "frac": gate["frac"], "traffic": None,
+                                 "peak": gate["peak"], "unit": "TFLOP/s", "frac": gate["frac"], "traffic": gate["traffic"],
                                  "dtype": gate["dtype"]})
         out["cem"] = cem_obj
     if rank == 0 and world == 1 and not args.no_cpu_baseline and train is not None:

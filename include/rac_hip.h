@@ -94,10 +94,14 @@ int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_st
  * ([3][pixels][C] and [3][Cout][k][k][Cin]; *_part_stride in elements).  Needs Cin % 8 == 0, a_split % 32 == 0.
  * Epilogue fields (bias, scale/shift, act, stats, split_k slabs) behave as in rac_conv2d. */
 int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t a1_part_stride,
-                         int64_t w_part_stride, int32_t w_chunk_major, void* stream);
-/* w_chunk_major = 1: the weight parts are stored [Cout][Cin/32][k*k][32] (needs Cin % 32 == 0 and H*W dividing 128):
- * when a 128-pixel tile holds whole images the kernel stages each 32-channel activation chunk once and runs the
- * k*k taps against it ("tap-inner"), and this layout makes the per-tap weight reads sequential in memory. */
+                         int64_t w_part_stride, int32_t w_layout, void* stream);
+/* w_layout: 0 = [Cout][k][k][Cin].  1 and 2 need Cin % 32 == 0, k > 1 and H*W dividing 128: a 128-pixel tile then
+ * holds whole images, the kernel stages each 32-channel activation chunk once and runs the k*k taps against it
+ * ("tap-inner").
+ *   1 = chunk-major [Cout][Cin/32][k*k][32]: per-tap weight reads sequential in memory, staged through LDS;
+ *   2 = fragment order [Cout/32][Cin/32][k*k][s 2][lane 64][8] with lane = 32 h + (co mod 32) and
+ *       ci = 32 chunk + 16 s + 8 h + j (needs Cout % 32 == 0): the weight operand of every MFMA is one coalesced
+ *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps). */
 /* Transposed bf16 parts for the split-precision weight gradient:
  *   out[dxi][k][c][p] = k-th part of (0 <= x(p)+dx < W ? x[p+dx][c] : 0),  dx = dxi - ndx/2,
  * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy). */

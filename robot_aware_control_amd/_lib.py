@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librac_hip.so")
+# RAC_HIP_LIB: another build of the same library (A/B runs of kernel variants, tools/build_variant.sh)
+LIB_PATH = os.environ.get("RAC_HIP_LIB") or os.path.join(_HERE, "librac_hip.so")
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 

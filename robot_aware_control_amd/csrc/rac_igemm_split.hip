@@ -25,10 +25,13 @@ struct SplitP {
   double* stats;
   int M, N, HW, P, taps, cchunks, nchunks, cps;
   int w_chunk_major;  // weights stored [Cout][Cin/32][taps][32] (tap-inner streaming order) instead of [Cout][taps][Cin]
+  int xcd_group;      // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
 };
 
 constexpr unsigned OOBS = 0xFFFFFFF0u;
 constexpr int SBM = 128, SBN = 128, SBK = 32;
+// igemm_split_bdirect_kernel's LDS image: 80-byte rows, 129 rows per part plane (row 128 = zeros), 3 planes per buffer
+constexpr int BD_ROW = 80, BD_PLANE = 129 * BD_ROW, BD_ABUF = 3 * BD_PLANE;
 
 __device__ __forceinline__ const void* uniform_vptr(const void* p) {
   unsigned long long v = reinterpret_cast<unsigned long long>(p);
@@ -258,8 +261,21 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
-  const int m0 = blockIdx.x * SBM, n0 = blockIdx.y * SBN;
-  const int kc_begin = blockIdx.z * p.cps;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {
+    // Workgroups are dealt to the 8 XCDs round-robin in linear-id order, so the few M-tiles that read the same
+    // (N-tile, K-slab) weight bytes would land on 8 different L2s and each pull the slab from HBM.  Remap:
+    // XCD x takes groups x, x+8, ...; the M-tiles of a group are consecutive in that XCD's queue.
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int m0 = bx * SBM, n0 = by * SBN;
+  const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   if (tid < 4) Zs[tid] = u32x4{0u, 0u, 0u, 0u};
 
@@ -303,10 +319,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
         ra[part * 2 + i] = ld16(a_rsrc, ok ? oa + (unsigned)(part * aps * 2) : OOBS);
     }
   };
-  auto issue_b = [&](int kc) {  // weight chunk of (cc, tap) = (kc / taps, kc % taps)
+  auto issue_b = [&](int kc, int cc, int tap) {  // weight chunk kc = (cc, tap)
     const bool live = kc < kc_end;
-    const int cc = kc / p.taps;
-    const int tap = kc - cc * p.taps;
     const int c0 = cc * SBK;
     const int s0 = p.w_chunk_major ? (cc * p.taps + tap) * SBK + schunk * 8 : tap * p.Cin + c0 + schunk * 8;
     const bool cok = live & (c0 + schunk * 8 < p.Cin);
@@ -328,11 +342,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (kc_begin < kc_end) {
-    issue_a(kc_begin / p.taps, true);
-    issue_b(kc_begin);
+    // (cc, tap, ky, kx) of the current chunk are carried and stepped: no division in the loop
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    issue_a(cc, true);
+    issue_b(kc_begin, cc, tap);
     for (int kc = kc_begin; kc < kc_end; ++kc) {
-      const int cc = kc / p.taps;
-      const int tap = kc - cc * p.taps;
       const int buf = (kc - kc_begin) & 1;
       u32x4* Bb = Bs + buf * (3 * 128 * 4);
       const bool new_a = (kc == kc_begin) | (tap == 0);
@@ -348,12 +364,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
 #pragma unroll
         for (int i = 0; i < 2; ++i) Bb[lds_off(part, srow + 64 * i, schunk)] = rb[part * 2 + i];
       __syncthreads();
-      issue_b(kc + 1);  // weights of the next tap: in flight under the MFMAs
-      if (tap == p.taps - 1) issue_a(cc + 1, kc + 1 < kc_end);  // next channel chunk's activations
+      const bool last_tap = tap == p.taps - 1;
+      const int ncc = last_tap ? cc + 1 : cc, ntap = last_tap ? 0 : tap + 1;
+      issue_b(kc + 1, ncc, ntap);  // weights of the next tap: in flight under the MFMAs
+      if (last_tap) issue_a(cc + 1, kc + 1 < kc_end);  // next channel chunk's activations
       __builtin_amdgcn_sched_barrier(0);
 
       // tap shift on the A fragment rows: rows that leave their image read the zero line
-      const int ky = tap / p.ks, kx = tap - ky * p.ks;
       const int dy = ky - p.pad, dx = kx - p.pad;
       int arow[2];
 #pragma unroll
@@ -388,6 +405,10 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
             acc[mt][nt] = c;
           }
       }
+      cc = ncc;
+      tap = ntap;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
     }
   }
 
@@ -414,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
         if (m >= p.M || !nok) continue;
         float v = acc[mt][nt][r];
         if (slab) {
-          p.out0[(long)blockIdx.z * p.slab_stride + (long)m * p.N + n] = v;
+          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
           continue;
         }
         v += bias;
@@ -439,6 +460,241 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
   }
 }
 
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Tap-inner forward kernel with the WEIGHT operand streamed straight into MFMA registers (no LDS, no barrier).
+// Timing knock-outs on the kernel above showed where its time went at M = 32000: MFMAs alone 10.6 ms (the pipe's
+// floor at the 1.9 GHz it holds), + weight loads 1.7 ms, + their ds_write_b128 staging 1.4 ms (a store moves its
+// VGPRs to the LDS at 13 cycles per wave-instruction and nothing hides it), + the per-chunk barrier 0.7 ms.
+// Here the weights are stored once (cached copy) in FRAGMENT ORDER,
+//     w[part][Cout/32][Cin/32][tap][s 0..1][lane 0..63][8 bf16],   lane = 32 h + (n mod 32), k = 16 s + 8 h + j,
+// so the B operand of every MFMA is ONE fully coalesced 1 KB buffer_load_dwordx4 per wave, held two chunks
+// ahead in registers.  The four waves of a workgroup split the 128-column tile by columns (32 each) and all read
+// the whole 128-pixel activation image from LDS (staged once per channel chunk, double-buffered: one barrier
+// per k*k taps instead of one per tap).  Same arithmetic and summation order as the kernel above.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
+  // LDS: two activation buffers [part 3][row 0..128][80 B]; a row is 64 B of data (32 channels) + 16 B of pad, so
+  // that any 16 consecutive rows fall on distinct 4-bank slots (80 r / 4 mod 64 has period 16) and a tap shift is
+  // ONE wave-uniform byte offset; row 128 of every part plane is a zero line for the pixels that leave the image.
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {  // see igemm_split_tapinner_kernel
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int m0 = bx * SBM, n0 = by * SBN;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  if (tid < 2 * 3 * 5) {  // zero lines (80 B = 5 x 16) of both buffers
+    const int b = tid / 15, r = tid - b * 15;
+    *reinterpret_cast<u32x4*>(lds_raw + b * BD_ABUF + (r / 5) * BD_PLANE + 128 * BD_ROW + (r % 5) * 16) =
+        u32x4{0u, 0u, 0u, 0u};
+  }
+
+  const int srow = tid >> 2, schunk = tid & 3;
+  bool a_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) a_ok[i] = m0 + srow + 64 * i < p.M;
+  // fragment rows of this lane (the four 32-row blocks of the tile): LDS byte offset of the unshifted row, and
+  // one bit per tap telling whether the shifted pixel stays inside its image
+  int abase[4];
+  unsigned amask[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = t * 32 + li;
+    const int im = r / p.HW;
+    const int q = r - im * p.HW;
+    const int y = q / p.W, x = q - y * p.W;
+    abase[t] = r * BD_ROW + lh * 16;
+    unsigned mk = 0;
+    for (int tp = 0; tp < p.taps; ++tp) {
+      const int yy = y + tp / p.ks - p.pad, xx = x + tp % p.ks - p.pad;
+      mk |= (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) ? (1u << tp) : 0u;
+    }
+    amask[t] = mk;
+  }
+  const int zrow = 128 * BD_ROW + lh * 16;
+  // this wave's 32 weight columns: a contiguous stream of 2 KB per (channel chunk, tap) and part.  Reads past the
+  // K range or of a dead column tile stay inside the buffer's range check and are never used.
+  const int ntile = (n0 >> 5) + wid;
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part)
+    b_off[part] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u +
+                  part * w_pstride;
+
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+    const int so = kc * 2048;  // wave-uniform: goes to the instruction's scalar offset
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        rb[part * 2 + s] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + s * 1024u), so, 0));
+  };
+  u32x4 ra[6];
+  auto issue_a = [&](int cc) {  // activation chunk `cc`, unshifted pixels of this tile
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = (first ? c0 : c0 - p.a_split) + schunk * 8;
+    const long aps = first ? p.a0_ps : p.a1_ps;
+    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned oa = (unsigned)((m0 + srow + 64 * i) * Cs + cl) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        ra[part * 2 + i] = ld16(a_rsrc, a_ok[i] ? oa + (unsigned)(part * aps * 2) : OOBS);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * BD_ABUF + part * BD_PLANE + (srow + 64 * i) * BD_ROW + schunk * 16) =
+            ra[part * 2 + i];
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    int cur = 0;
+    bool fresh = true;  // first chunk of a channel chunk inside this K range
+    u32x4 b0[6], b1[6], b2[6];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    load_b(b1, kc_begin + 1);
+    store_a(0);
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);  // next channel chunk: in flight for k*k taps
+      fresh = false;
+      // tap shift: one uniform byte offset on the fragment rows; rows that leave their image read the zero line
+      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * BD_ROW + cur * BD_ABUF;
+      const int zr = zrow + cur * BD_ABUF;
+      const unsigned bit = 1u << tap;
+      int aoff[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) aoff[t] = (amask[t] & bit) ? abase[t] + shift : zr;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[4][3], fb[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[part] = __builtin_bit_cast(bf16x8, rb[part * 2 + s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part) {
+            fa[t][part] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + aoff[t] + part * BD_PLANE + s * 32));
+          }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x16 c = acc[mt];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[0], c, 0, 0, 0);
+          acc[mt] = c;
+        }
+      }
+      if (last_tap && more) {  // the other buffer was last read before the previous such barrier
+        store_a(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 3) {
+      load_b(b2, kc + 2);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 3);
+        step(b1, kc + 1);
+      }
+      if (kc + 2 < kc_end) {
+        load_b(b1, kc + 4);
+        step(b2, kc + 2);
+      }
+    }
+  }
+
+  // ---- epilogue (same semantics as rac_conv2d FWD): this wave owns columns n0 + 32 wid .. + 31 ----
+  const bool slab = p.split_k > 1;
+  const int n = n0 + wid * 32 + li;
+  const bool nok = n < p.N;
+  float bias = 0.f, sc = 1.f, sh = 0.f;
+  if (!slab && nok) {
+    if (p.bias) bias = p.bias[n];
+    if (p.scale) {
+      sc = p.scale[n];
+      sh = p.shift[n];
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M || !nok) continue;
+      float v = acc[mt][r];
+      if (slab) {
+        p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+        continue;
+      }
+      v += bias;
+      s1 += v;
+      s2 += v * v;
+      v = v * sc + sh;
+      if (p.act == RAC_ACT_LEAKY02)
+        v = v > 0.f ? v : 0.2f * v;
+      else if (p.act == RAC_ACT_SIGMOID)
+        v = sigmoid_acc(v);
+      p.out0[(long)m * p.N + n] = v;
+    }
+  }
+  if (p.stats && !slab) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lh == 0 && nok) {
+      atomicAdd(p.stats + n, (double)s1);
+      atomicAdd(p.stats + p.N + n, (double)s2);
+    }
+  }
+}
 
 
 // ---------------------------------------------------------------------------------------------------------
@@ -635,7 +891,7 @@ extern "C" int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int6
 }
 
 extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64_t a1_ps, int64_t w_ps,
-                                    int32_t w_chunk_major, void* stream) {
+                                    int32_t w_layout, void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0,
               "rac_conv2d_fwd_split: bad args");
@@ -682,8 +938,32 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   dim3 grid(cdiv(p.M, SBM), cdiv(p.N, SBN), p.split_k);
   static const bool no_tapinner = getenv("RAC_SPLIT_TAPOUTER") != nullptr;  // A/B switch for benchmarks
   p.w_chunk_major = 0;
-  RAC_REQUIRE(!w_chunk_major || (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0),
-              "rac_conv2d_fwd_split: chunk-major weights need Cin % 32 == 0 and whole images per 128-pixel tile");
+  RAC_REQUIRE(w_layout >= 0 && w_layout <= 2, "rac_conv2d_fwd_split: w_layout must be 0, 1 or 2");
+  const bool w_chunk_major = w_layout == 1;
+  RAC_REQUIRE(w_layout == 0 || (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1),
+              "rac_conv2d_fwd_split: chunk-major / fragment-order weights need Cin % 32 == 0, k > 1 and whole images "
+              "per 128-pixel tile");
+  // few M-tiles (training batch): the launch is bound by weight re-reads across XCDs unless they are grouped
+  static const char* xg = getenv("RAC_XCD_GROUP");
+  p.xcd_group = (xg ? atoi(xg) != 0 : (int)grid.x <= 32) && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+  if (w_layout == 2) {
+    RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,
+                "rac_conv2d_fwd_split: fragment-order weights need Cout % 32 == 0 and k <= 5");
+    RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+    constexpr size_t lds_bd = 2 * BD_ABUF;  // two activation buffers incl. their zero lines = 61,920 B
+    static bool bd_attr = false;
+    if (!bd_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bd);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      bd_attr = true;
+    }
+    hipLaunchKernelGGL(igemm_split_bdirect_kernel, grid, dim3(256), lds_bd, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_fwd_split(weights direct)");
+  }
   if ((w_chunk_major || !no_tapinner) && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1) {
     p.w_chunk_major = w_chunk_major;
     // whole images per M-tile: activations staged once per channel chunk, taps inner

@@ -260,10 +260,18 @@ def split_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 def chunk_major(w: torch.Tensor) -> torch.Tensor:
-    """[Cout][k][k][Cin] memory -> contiguous [Cout][Cin/32][k*k][32] (the tap-inner kernel's streaming order)."""
+    """[Cout][k][k][Cin] memory -> contiguous [Cout][Cin/32][k*k][32] (weight layout 1 of rac_conv2d_fwd_split)."""
     co, ci, k, _ = w.shape
     mem = w.permute(0, 2, 3, 1).reshape(co, k * k, ci // 32, 32)
     return mem.permute(0, 2, 1, 3).contiguous()
+
+
+def frag_order(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][k][k][Cin] memory -> contiguous [Cout/32][Cin/32][k*k][s][h][co mod 32][8] (weight layout 2: the
+    operand registers of v_mfma_f32_32x32x16_bf16, lane = 32 h + co mod 32, ci = 32 chunk + 16 s + 8 h + j)."""
+    co, ci, k, _ = w.shape
+    mem = w.permute(0, 2, 3, 1).reshape(co // 32, 32, k * k, ci // 32, 2, 2, 8)  # nt, li, tap, cc, s, h, j
+    return mem.permute(0, 3, 2, 4, 5, 1, 6).contiguous()
 
 
 # the tap-inner kernel (chunk-major weights) wins at every size measured on one box, back to back: 223 vs 184
@@ -272,13 +280,27 @@ def chunk_major(w: torch.Tensor) -> torch.Tensor:
 TAPINNER_MIN_TILES = int(os.environ.get("RAC_TAPINNER_MIN_TILES", "0"))
 
 
+# weight layout 2 (fragment order, weights loaded straight into MFMA registers) instead of 1 where Cout allows
+W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
+
+
 def tapinner_ok(H: int, W: int, Cin: int, k: int, M: int, N: int) -> bool:
     return (k > 1 and Cin % 32 == 0 and H * W <= 128 and 128 % (H * W) == 0
             and _cdiv(M, 128) * _cdiv(N, 128) >= TAPINNER_MIN_TILES)
 
 
+def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int:
+    """Weight layout (w_layout of rac_conv2d_fwd_split) for a conv of this shape."""
+    if not tapinner_ok(H, W, Cin, k, M, N):
+        return 0
+    return 2 if (W_DIRECT and N % 32 == 0) else 1
+
+
+_W_LAYOUT_FN = {1: chunk_major, 2: frag_order}
+
+
 def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
-                  stats=None, split_k=1, slab_stride=0, chunk_major_w=False):
+                  stats=None, split_k=1, slab_stride=0, w_layout=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats))
@@ -288,7 +310,7 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     call("rac_conv2d_fwd_split", C.byref(args), p0.shape[1], p1.shape[1] if p1 is not None else 0, pw.shape[1],
-         1 if chunk_major_w else 0, stream_ptr())
+         w_layout, stream_ptr())
     if timed:
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
@@ -307,27 +329,27 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     M = B * H * W
     p0 = split_parts(x0)
     p1 = split_parts(x1) if x1 is not None else None
-    cm = tapinner_ok(H, W, Cin, k, M, Cout)
+    cm = split_weight_layout(H, W, Cin, k, M, Cout)
     if cm:
-        pw = _derived(weight, "_rac_split_cm", lambda: split_parts(chunk_major(weight.detach())))
+        pw = _derived(weight, f"_rac_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](weight.detach())))
     else:
         pw = split_weight(weight)
     if want_slabs:
         split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
         out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
         _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
-                      slab_stride=M * Cout, chunk_major_w=cm)
+                      slab_stride=M * Cout, w_layout=cm)
         return out, split, M * Cout
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
     fused = act != ACT_NONE or scale is not None
     split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
     if split == 1:
         _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
-                      shift=shift, stats=stats, chunk_major_w=cm)
+                      shift=shift, stats=stats, w_layout=cm)
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         _split_launch(p0, p1, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
-                      slab_stride=M * Cout, chunk_major_w=cm)
+                      slab_stride=M * Cout, w_layout=cm)
         call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
         if stats is not None:
             call("rac_col_stats", ptr(out), ptr(stats), M, Cout, stream_ptr())
@@ -349,16 +371,16 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     assert Co == Cout and Cin == C0 + C1
     M = B * H * W
     wt = transposed_weight(weight)  # (Cin, Cout, k, k)
-    cm = tapinner_ok(H, W, Cout, k, M, Cin)
+    cm = split_weight_layout(H, W, Cout, k, M, Cin)
     if cm:
-        pw = _derived(weight, "_rac_transposed_split_cm", lambda: split_parts(chunk_major(wt)))
+        pw = _derived(weight, f"_rac_transposed_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](wt)))
     else:
         pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(wt)))
     pd = split_parts(dy)
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
     _split_launch(pd, None, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout, split_k=split,
-                  slab_stride=M * Cin, chunk_major_w=cm)
+                  slab_stride=M * Cin, w_layout=cm)
     dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
     if C1:
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)

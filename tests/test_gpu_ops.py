@@ -321,16 +321,18 @@ def test_cem_step_tail(dev, golden_dir):
         np.testing.assert_allclose(cost.cpu().numpy(), g[key].astype(np.float64), rtol=2e-6)
 
 
-@pytest.mark.parametrize("tapinner", [False, True])
+@pytest.mark.parametrize("layout", [0, 1, 2])
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3),
-                                  (5, 4, 8, 32, 64, 160, 3)])
-def test_conv_split_precision_bf16x6(dev, case, tapinner, monkeypatch):
-    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe.  Both
-    kernels: tap-outer (any shape) and tap-inner (whole images per 128-row tile, chunk-major weights)."""
+                                  (5, 4, 8, 32, 64, 160, 3), (4, 8, 8, 64, 64, 1024, 3)])
+def test_conv_split_precision_bf16x6(dev, case, layout, monkeypatch):
+    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe.  All three
+    kernels: tap-outer (layout 0, any shape), tap-inner with chunk-major weights through LDS (1) and tap-inner
+    with fragment-order weights loaded straight into the MFMA registers (2)."""
     from robot_aware_control_amd import ops
-    monkeypatch.setattr(ops, "TAPINNER_MIN_TILES", 0 if tapinner else 1 << 30)
+    monkeypatch.setattr(ops, "TAPINNER_MIN_TILES", 0 if layout else 1 << 30)
+    monkeypatch.setattr(ops, "W_DIRECT", layout == 2)
     B, H, W, C0, C1, Cout, k = case
-    assert ops.tapinner_ok(H, W, C0 + C1, k, B * H * W, Cout) == tapinner
+    assert ops.split_weight_layout(H, W, C0 + C1, k, B * H * W, Cout) == layout
     Cin = C0 + C1
     # exactness of the fragment layout: small integers live entirely in the first bf16 part
     g = np.random.Generator(np.random.Philox(key=[9, 9]))
