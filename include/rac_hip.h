@@ -104,8 +104,11 @@ int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t
  *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps). */
 /* Transposed bf16 parts for the split-precision weight gradient:
  *   out[dxi][k][c][p] = k-th part of (0 <= x(p)+dx < W ? x[p+dx][c] : 0),  dx = dxi - ndx/2,
- * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy). */
-int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx, void* stream);
+ * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy).
+ * ld = row stride of `out` in elements (0 = P): with ld = T*P and `out` advanced by t*P, T calls lay T time steps
+ * side by side along the pixel axis, and ONE rac_conv2d_wgrad_split over B*T images sums their weight gradients. */
+int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx, int64_t ld,
+                        void* stream);
 /* Weight gradient dw[co][tap][ci] += sum_p dy[p][co] x[p+tap][ci] on the split-precision pipe.
  * a->a0 / a->a1 = rac_transpose_split(x0 / x1, ndx = ksize) parts, a->w = rac_transpose_split(dy, ndx = 1) parts,
  * a->out0 = dw (fp32, accumulated in place), a->a_split = channels of x0 (multiple of 128 when a1 is given),

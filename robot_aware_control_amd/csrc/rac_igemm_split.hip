@@ -826,7 +826,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitP p) {
 
 // out[dxi][part][c][p] = part-th bf16 part of (x in-row ? in[p + dx][c] : 0), dx = dxi - pad, dxi < ndx
 // (ndx = 1: plain transpose + split).  32x32 tiles through LDS: coalesced on both sides.
-__global__ void transpose_split_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad) {
+__global__ void transpose_split_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad,
+                                       long ld) {
   __shared__ float tile[32][33];
   const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
   const int dxi = blockIdx.z;
@@ -844,7 +845,7 @@ __global__ void transpose_split_kernel(const float* in, unsigned short* out, int
     tile[ty + 8 * i][tx] = v;
   }
   __syncthreads();
-  const long ps = (long)C * P;
+  const long ps = (long)C * ld;  // ld >= P: row stride of the (possibly wider, time-batched) output
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = c0 + ty + 8 * i;
@@ -855,7 +856,7 @@ __global__ void transpose_split_kernel(const float* in, unsigned short* out, int
       const float r1 = a - (float)q1;
       const __bf16 q2 = (__bf16)r1;
       const __bf16 q3 = (__bf16)(r1 - (float)q2);
-      unsigned short* o = out + (long)dxi * 3 * ps + (long)c * P + pr;
+      unsigned short* o = out + (long)dxi * 3 * ps + (long)c * ld + pr;
       o[0] = __builtin_bit_cast(unsigned short, q1);
       o[ps] = __builtin_bit_cast(unsigned short, q2);
       o[2 * ps] = __builtin_bit_cast(unsigned short, q3);
@@ -986,10 +987,11 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
 }
 
 extern "C" int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx,
-                                   void* stream) {
-  RAC_REQUIRE(x && out && P > 0 && C > 0 && W > 0 && ndx >= 1 && (ndx & 1), "rac_transpose_split: bad args");
+                                   int64_t ld, void* stream) {
+  RAC_REQUIRE(x && out && P > 0 && C > 0 && W > 0 && ndx >= 1 && (ndx & 1) && (ld == 0 || ld >= P),
+              "rac_transpose_split: bad args");
   hipLaunchKernelGGL(transpose_split_kernel, dim3(cdiv(P, 32), cdiv(C, 32), ndx), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2);
+                     reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2, ld ? (long)ld : (long)P);
   return check_launch("rac_transpose_split");
 }
 

@@ -17,6 +17,7 @@ weights.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 from typing import Optional, Tuple
@@ -390,27 +391,65 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     return dx0, None
 
 
-def conv_wgrad_split_acc(dy, x0, x1, weight):
-    """weight.grad += dW on the split-precision pipe (transposed bf16 parts of dy and of the dx-shifted inputs)."""
+# Deferred, time-batched weight gradients: inside `deferred_wgrad()` the split-precision wgrad of a weight that is
+# applied at every time step (the ConvLSTM gate convs) is not launched per step; its (dy, x0, x1) triples are kept and
+# ONE launch over all steps' pixels runs when the context exits (K = T*B*H*W instead of B*H*W per launch: one
+# read-modify-write of the gradient instead of T, longer K loops).  Same sum, different association across steps.
+_DEFERRED = None
+DEFER_WGRAD = os.environ.get("RAC_DEFER_WGRAD", "1") == "1"
+
+
+@contextlib.contextmanager
+def deferred_wgrad():
+    global _DEFERRED
+    if not DEFER_WGRAD or _DEFERRED is not None:
+        yield
+        return
+    _DEFERRED = {}
+    try:
+        yield
+        pending, _DEFERRED = _DEFERRED, None
+        for weight, items in pending.values():
+            _wgrad_split_batch(items, weight)
+    finally:
+        _DEFERRED = None
+
+
+def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
+    """weight.grad += dW on the split-precision pipe (transposed bf16 parts of dy and of the dx-shifted inputs).
+    `defer`: inside `deferred_wgrad()` only record the operands (the caller must not modify them afterwards)."""
+    if defer and _DEFERRED is not None:
+        _DEFERRED.setdefault(id(weight), (weight, []))[1].append((dy, x0, x1))
+        return
+    _wgrad_split_batch([(dy, x0, x1)], weight)
+
+
+def _wgrad_split_batch(items, weight):
+    dy, x0, x1 = items[0]
+    T = len(items)
     B, H, W, Cout = dy.shape
     Co, Cin, k, _ = weight.shape
     C0 = x0.shape[3]
     C1 = x1.shape[3] if x1 is not None else 0
     P = B * H * W
+    ld = T * P
     dev = dy.device
-    dyt = torch.empty((3, Cout, P), device=dev, dtype=torch.bfloat16)
-    call("rac_transpose_split", ptr(dy), ptr(dyt), P, Cout, W, 1, stream_ptr())
-    x0t = torch.empty((k, 3, C0, P), device=dev, dtype=torch.bfloat16)
-    call("rac_transpose_split", ptr(x0), ptr(x0t), P, C0, W, k, stream_ptr())
-    x1t = None
-    if C1:
-        x1t = torch.empty((k, 3, C1, P), device=dev, dtype=torch.bfloat16)
-        call("rac_transpose_split", ptr(x1), ptr(x1t), P, C1, W, k, stream_ptr())
+    dyt = torch.empty((3, Cout, ld), device=dev, dtype=torch.bfloat16)
+    x0t = torch.empty((k, 3, C0, ld), device=dev, dtype=torch.bfloat16)
+    x1t = torch.empty((k, 3, C1, ld), device=dev, dtype=torch.bfloat16) if C1 else None
+    sp = stream_ptr()
+    for t, (dy_t, x0_t, x1_t) in enumerate(items):
+        assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
+        off = 2 * t * P  # bytes: bf16 columns t*P .. (t+1)*P of every row
+        call("rac_transpose_split", ptr(dy_t), dyt.data_ptr() + off, P, Cout, W, 1, ld, sp)
+        call("rac_transpose_split", ptr(x0_t), x0t.data_ptr() + off, P, C0, W, k, ld, sp)
+        if C1:
+            call("rac_transpose_split", ptr(x1_t), x1t.data_ptr() + off, P, C1, W, k, ld, sp)
     g = weight_mem(grad_buffer(weight))
-    args = ConvArgs(mode=WGRAD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
+    args = ConvArgs(mode=WGRAD, B=B * T, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
                     a_split=C0, o_split=0, slab_stride=0, a0=ptr(x0t), a1=ptr(x1t), w=ptr(dyt), out0=ptr(g), out1=None,
                     bias=None, scale=None, shift=None, stats=None)
-    call("rac_conv2d_wgrad_split", C.byref(args), stream_ptr())
+    call("rac_conv2d_wgrad_split", C.byref(args), sp)
 
 
 def wgrad_split_ok(x0, x1, W: int) -> bool:
@@ -680,7 +719,7 @@ class LstmCell(torch.autograd.Function):
                 dx, dh_prev = conv_dgrad(dgates, weight, g, g)
         if weight.requires_grad:
             if wgrad_split_ok(x, h_prev, W):
-                conv_wgrad_split_acc(dgates, x, h_prev, weight)
+                conv_wgrad_split_acc(dgates, x, h_prev, weight, defer=True)
             else:
                 conv_wgrad_acc(dgates, x, h_prev, weight)
         if bias.requires_grad:

@@ -208,7 +208,8 @@ class PredictionTrainer(object):
             seeds.append(self._seed(float(cf.beta)))
             log.append(("kld", kl, 0))
         # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
-        torch.autograd.backward(roots, seeds)
+        with ops.deferred_wgrad():  # ConvLSTM weight gradients: one time-batched launch per weight
+            torch.autograd.backward(roots, seeds)
         allreduce_flat_grad(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
         self.optimizer.step()
 

@@ -384,3 +384,11 @@ def test_wgrad_split_precision(dev, case):
     assert e_split < 3e-6 and e_split < 4 * e_fp32 + 3e-7, (e_split, e_fp32)
     ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)  # accumulates
     assert relerr(wd.grad.cpu(), 2 * ref) < 3e-6
+    # deferred: the time steps' operands laid side by side along the pixel axis, ONE launch when the context exits
+    wd3 = cl_weight(w.detach()).to(dev).requires_grad_(True)
+    with ops.deferred_wgrad():
+        ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd3, defer=True)
+        ops.conv_wgrad_split_acc(to_map(2 * gy, dev), x0, x1, wd3, defer=True)
+        ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd3, defer=True)
+        assert wd3.grad is None or float(wd3.grad.abs().max()) == 0.0
+    assert relerr(wd3.grad.cpu(), 4 * ref) < 3e-6

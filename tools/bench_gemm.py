@@ -85,3 +85,17 @@ if mode == "wgrad" and os.environ.get("RAC_BENCH_SPLIT"):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
     print(f"wgrad-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective (incl. transposes)", flush=True)
+
+if mode == "wgrad" and os.environ.get("RAC_BENCH_SPLIT"):
+    T = int(os.environ.get("RAC_BENCH_T", "1"))
+    items = [(dy, x, h)] * T
+    for _ in range(2):
+        ops._wgrad_split_batch(items, w)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        ops._wgrad_split_batch(items, w)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f"wgrad-split(bf16x6) B={B} x T={T} g={g} k={k}: {ms:.3f} ms  {T * flop / ms / 1e9:.1f} TFLOP/s effective incl. transposes", flush=True)
