@@ -712,6 +712,7 @@ struct WgradSplitP {
   const unsigned short *x0t, *x1t, *dyt;  // [ks][3][C0][P], [ks][3][C1][P], [3][Cout][P]
   float* dw;
   unsigned long long magic_hw, magic_w;
+  int wr, wr_shift;  // 8-pixel vectors per image row (W / 8, a power of two) and its log2: fragment-order kernel
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitP p) {
@@ -824,6 +825,174 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WgradSplitP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient with the INPUT operand streamed straight into MFMA registers.
+// x^T is stored in fragment order (rac_transpose_split layout 1): [dx][part][ci/32][r = p/8][ci mod 32][8 pixels],
+// so the B operand of an MFMA (lane = 32 h + ci mod 32 holds pixels 16 s + 8 h .. +7 of the K chunk) is ONE
+// coalesced 1 KB load, and the row shift dy of a tap is a constant offset of dy*W/8 vectors with the rows that
+// leave the image selected to zero.  The four waves split the 128 input channels of the tile (32 each); dy^T
+// (A operand, [part][Cout][P]) is staged through a double-buffered padded LDS image: one barrier per K chunk,
+// no LDS traffic for the inputs.  Same arithmetic and summation order as wgrad_split_kernel.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_split_bdirect_kernel(WgradSplitP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // 2 x [part 3][128 rows][80 B]
+  constexpr int PLANE = 128 * BD_ROW, ABUF = 3 * PLANE;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.x * SBM;
+  const int tap = blockIdx.y / p.ntile_per_tap;
+  const int n0 = (blockIdx.y - tap * p.ntile_per_tap) * SBN;
+  const int ky = tap / p.ks, kx = tap - ky * p.ks;
+  const int dy = ky - p.pad;
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  const int srow = tid >> 2, schunk = tid & 3;
+
+  // block-uniform source of this channel range (virtual concat [x0 | x1])
+  const bool first = n0 < p.a_split;
+  const int Cs = first ? p.a_split : p.Cin - p.a_split;
+  const int nl0 = first ? n0 : n0 - p.a_split;
+  const long xps = (long)Cs * p.P;  // part stride of the chosen source
+  const unsigned short* xbase = (first ? p.x0t : p.x1t) + (long)kx * 3 * xps;
+  const rsrc_t x_rsrc = mk_rsrc(xbase, (unsigned)(3 * xps * 2));
+  const long dps = (long)p.Cout * p.P;
+  const rsrc_t d_rsrc = mk_rsrc(p.dyt, (unsigned)(3 * dps * 2));
+
+  // B stream of this wave: channel tile ct of the source, vectors r = p / 8 (512 B each), shifted by dy rows
+  const int ct = (nl0 >> 5) + wid;
+  const bool n_live = (n0 + wid * 32 < p.Cin) & (ct * 32 < Cs);
+  const int R = p.P >> 3;
+  const int rshift = dy * p.wr;
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part)
+    b_off[part] = (unsigned)(((long)ct * R * 32 + li) * 16 + part * xps * 2);
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int r = kc * 4 + 2 * s + lh;  // this lane's 8-pixel vector of the chunk
+      const int irow = r >> p.wr_shift;                                                    // image row, all images
+      const int img = (int)(((unsigned long long)(unsigned)irow * p.magic_hw) >> 40);      // irow / H
+      const int y = irow - img * p.H;
+      const bool ok = n_live & (kc < kc_end) & (r < R) & ((unsigned)(y + dy) < (unsigned)p.H);
+      const unsigned o = (unsigned)(r + rshift) * 512u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) rb[part * 2 + s] = ld16(x_rsrc, ok ? b_off[part] + o : OOBS);
+    }
+  };
+
+  int a_base[2];  // row * P, or -1
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int co = m0 + srow + 64 * i;
+    a_base[i] = co < p.Cout ? co * p.P : -1;
+  }
+  u32x4 ra[6];
+  auto issue_a = [&](int kc) {
+    const int px = kc * SBK + schunk * 8;
+    const bool pok = (kc < kc_end) & (px < p.P);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool oka = pok & (a_base[i] >= 0);
+      const unsigned oa = (unsigned)(a_base[i] + px) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part) ra[part * 2 + i] = ld16(d_rsrc, oka ? oa + (unsigned)(part * dps * 2) : OOBS);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * ABUF + part * PLANE + (srow + 64 * i) * BD_ROW + schunk * 16) =
+            ra[part * 2 + i];
+  };
+  int abase[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) abase[t] = (t * 32 + li) * BD_ROW + lh * 16;
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    u32x4 b0[6], b1[6], b2[6];
+    issue_a(kc_begin);
+    load_b(b0, kc_begin);
+    load_b(b1, kc_begin + 1);
+    store_a(0);
+    issue_a(kc_begin + 1);
+    __syncthreads();
+
+    // chunk kc: dy^T from LDS buffer (kc - kc_begin) & 1, inputs from `rb`; `ra` holds chunk kc + 1 on entry
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const int cur = (kc - kc_begin) & 1;
+      store_a(cur ^ 1);   // chunk kc + 1 (its buffer was last read in chunk kc - 1, before the previous barrier)
+      issue_a(kc + 2);
+      const int aoff = cur * ABUF;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[4][3], fb[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[part] = __builtin_bit_cast(bf16x8, rb[part * 2 + s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            fa[t][part] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + aoff + abase[t] + part * PLANE + s * 32));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x16 c = acc[mt];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[0], c, 0, 0, 0);
+          acc[mt] = c;
+        }
+      }
+      __syncthreads();
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 3) {
+      load_b(b2, kc + 2);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 3);
+        step(b1, kc + 1);
+      }
+      if (kc + 2 < kc_end) {
+        load_b(b1, kc + 4);
+        step(b2, kc + 2);
+      }
+    }
+  }
+
+  // dw[co][tap][ci] += acc   (C/D layout: col = lane & 31 -> ci, row -> co): this wave owns ci n0 + 32 wid .. + 31
+  const long wrow = (long)p.taps * p.Cin;
+  const int n = n0 + wid * 32 + li;
+  if (n < p.Cin && !(first && n >= p.a_split)) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.Cout) continue;
+        float* dst = p.dw + m * wrow + (long)tap * p.Cin + n;
+        if (p.split_k > 1)
+          atomicAdd(dst, acc[mt][r]);
+        else
+          *dst += acc[mt][r];
+      }
+  }
+}
+
 // out[dxi][part][c][p] = part-th bf16 part of (x in-row ? in[p + dx][c] : 0), dx = dxi - pad, dxi < ndx
 // (ndx = 1: plain transpose + split).  32x32 tiles through LDS: coalesced on both sides.
 __global__ void transpose_split_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad,
@@ -861,6 +1030,48 @@ __global__ void transpose_split_kernel(const float* in, unsigned short* out, int
       o[ps] = __builtin_bit_cast(unsigned short, q2);
       o[2 * ps] = __builtin_bit_cast(unsigned short, q3);
     }
+  }
+}
+
+// Fragment-order variant: out[dxi][part][c / 32][r = (p_off + p) / 8][c mod 32][8 pixels], ld = pixels per row of the
+// whole (time-batched) operand.  One 32 x 32 tile = four 512-byte runs [c mod 32][8 pixels], written 2 B per lane
+// with the 256 threads covering one run contiguously.
+__global__ void transpose_split_frag_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad,
+                                            long ld, long p_off) {
+  __shared__ float tile[32][33];
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int dxi = blockIdx.z;
+  const int dx = dxi - pad;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pr = p0 + ty + 8 * i;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (pr < P && c < C) {
+      const int x = pr % W;
+      if ((unsigned)(x + dx) < (unsigned)W) v = in[(long)(pr + dx) * C + c];
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+  const long ps = (long)C * ld;
+  const int j = threadIdx.x & 7, cl = threadIdx.x >> 3;  // pixel within the vector, channel within the tile
+  if (c0 + cl >= C) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pr = p0 + 8 * i + j;
+    if (pr >= P) continue;
+    const float a = tile[8 * i + j][cl];
+    const __bf16 q1 = (__bf16)a;
+    const float r1 = a - (float)q1;
+    const __bf16 q2 = (__bf16)r1;
+    const __bf16 q3 = (__bf16)(r1 - (float)q2);
+    const long r = (p_off + pr) >> 3;
+    unsigned short* o = out + (long)dxi * 3 * ps + (long)(c0 >> 5) * (ld * 32) + r * 256 + cl * 8 + j;
+    o[0] = __builtin_bit_cast(unsigned short, q1);
+    o[ps] = __builtin_bit_cast(unsigned short, q2);
+    o[2 * ps] = __builtin_bit_cast(unsigned short, q3);
   }
 }
 
@@ -987,15 +1198,24 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
 }
 
 extern "C" int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx,
-                                   int64_t ld, void* stream) {
-  RAC_REQUIRE(x && out && P > 0 && C > 0 && W > 0 && ndx >= 1 && (ndx & 1) && (ld == 0 || ld >= P),
+                                   int64_t ld, int32_t layout, int64_t p_off, void* stream) {
+  RAC_REQUIRE(x && out && P > 0 && C > 0 && W > 0 && ndx >= 1 && (ndx & 1) && (ld == 0 || ld >= P) && p_off >= 0,
               "rac_transpose_split: bad args");
+  const long ldl = ld ? (long)ld : (long)P;
+  if (layout == 1) {
+    RAC_REQUIRE(C % 32 == 0 && W % 8 == 0 && P % 8 == 0 && ldl % 8 == 0 && p_off % 8 == 0 && p_off + P <= ldl,
+                "rac_transpose_split: fragment order needs C % 32 == 0 and 8-pixel aligned rows");
+    hipLaunchKernelGGL(transpose_split_frag_kernel, dim3(cdiv(P, 32), cdiv(C, 32), ndx), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2, ldl, (long)p_off);
+    return check_launch("rac_transpose_split(fragment order)");
+  }
+  RAC_REQUIRE(layout == 0, "rac_transpose_split: layout must be 0 or 1");
   hipLaunchKernelGGL(transpose_split_kernel, dim3(cdiv(P, 32), cdiv(C, 32), ndx), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2, ld ? (long)ld : (long)P);
+                     reinterpret_cast<hipStream_t>(stream), x, out + p_off, P, C, W, ndx, ndx / 2, ldl);
   return check_launch("rac_transpose_split");
 }
 
-extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, void* stream) {
+extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_WGRAD, "rac_conv2d_wgrad_split: weight-gradient mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0,
               "rac_conv2d_wgrad_split: bad args");
@@ -1023,11 +1243,24 @@ extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, void* stream) {
   p.ntile_per_tap = cdiv(a->Cin, SBN);
   const long tiles = (long)cdiv(a->Cout, SBM) * p.ntile_per_tap * p.taps;
   int split = a->split_k;
-  if (split <= 0) {  // auto: atomics only when the tile count cannot fill the chip
+  if (split <= 0) {  // auto: atomics when the tile count cannot fill the chip, or to even out the last round
     split = 1;
-    if (tiles < 512) split = (int)((768 + tiles - 1) / tiles);
+    if (tiles < 512) {
+      split = (int)((768 + tiles - 1) / tiles);
+    } else {
+      // 512 workgroups run at a time (2 per CU): pick the K split whose last round is fullest, while every
+      // workgroup keeps >= 32 chunks to amortise its read-modify-write of the 64 KB output tile
+      double best = 0.;
+      for (int sk = 1; sk <= 4 && p.nchunks / sk >= 32; ++sk) {
+        const double rounds = (double)tiles * sk / 512.;
+        const double eff = rounds / (double)(long)(rounds + 0.999999) - 0.04 * (sk - 1);
+        if (eff > best) best = eff, split = sk;
+      }
+    }
     if (split > p.nchunks / 8) split = p.nchunks / 8 > 0 ? p.nchunks / 8 : 1;
     if (split > 64) split = 64;
+    static const char* fk = getenv("RAC_WGRAD_SPLITK");  // experiments
+    if (fk && atoi(fk) > 0) split = atoi(fk);
   }
   p.split_k = split;
   p.cps = cdiv(p.nchunks, split);
@@ -1043,6 +1276,29 @@ extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, void* stream) {
     attr_done = true;
   }
   dim3 grid(cdiv(a->Cout, SBM), p.ntile_per_tap * p.taps, split);
+  if (x_layout == 1) {
+    const int c1 = a->Cin - p.a_split;
+    RAC_REQUIRE(p.a_split % 32 == 0 && c1 % 32 == 0 && p.P % 8 == 0,
+                "rac_conv2d_wgrad_split: fragment-order inputs need channel counts % 32 == 0");
+    p.wr = a->W / 8;
+    RAC_REQUIRE((p.wr & (p.wr - 1)) == 0, "rac_conv2d_wgrad_split: fragment-order inputs need W / 8 a power of two");
+    p.wr_shift = __builtin_ctz((unsigned)p.wr);
+    p.magic_hw = ((1ULL << 40) + a->H - 1) / a->H;  // here: division by H of an image-row index
+    constexpr size_t lds_bd = 2 * 3 * 128 * BD_ROW;  // 61,440 B
+    static bool bd_attr = false;
+    if (!bd_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_bdirect_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bd);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      bd_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_split_bdirect_kernel, grid, dim3(256), lds_bd, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_wgrad_split(inputs direct)");
+  }
+  RAC_REQUIRE(x_layout == 0, "rac_conv2d_wgrad_split: x_layout must be 0 or 1");
   hipLaunchKernelGGL(wgrad_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_wgrad_split");
 }

@@ -397,6 +397,7 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
 # read-modify-write of the gradient instead of T, longer K loops).  Same sum, different association across steps.
 _DEFERRED = None
 DEFER_WGRAD = os.environ.get("RAC_DEFER_WGRAD", "1") == "1"
+WGRAD_DIRECT = os.environ.get("RAC_WGRAD_DIRECT", "1") == "1"
 
 
 @contextlib.contextmanager
@@ -438,18 +439,19 @@ def _wgrad_split_batch(items, weight):
     x0t = torch.empty((k, 3, C0, ld), device=dev, dtype=torch.bfloat16)
     x1t = torch.empty((k, 3, C1, ld), device=dev, dtype=torch.bfloat16) if C1 else None
     sp = stream_ptr()
+    # inputs in MFMA fragment order (loaded straight into registers by the kernel) where the channel counts allow
+    xl = 1 if (WGRAD_DIRECT and C0 % 32 == 0 and C1 % 32 == 0 and W % 8 == 0 and (W // 8) & (W // 8 - 1) == 0) else 0
     for t, (dy_t, x0_t, x1_t) in enumerate(items):
         assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
-        off = 2 * t * P  # bytes: bf16 columns t*P .. (t+1)*P of every row
-        call("rac_transpose_split", ptr(dy_t), dyt.data_ptr() + off, P, Cout, W, 1, ld, sp)
-        call("rac_transpose_split", ptr(x0_t), x0t.data_ptr() + off, P, C0, W, k, ld, sp)
+        call("rac_transpose_split", ptr(dy_t), ptr(dyt), P, Cout, W, 1, ld, 0, t * P, sp)
+        call("rac_transpose_split", ptr(x0_t), ptr(x0t), P, C0, W, k, ld, xl, t * P, sp)
         if C1:
-            call("rac_transpose_split", ptr(x1_t), x1t.data_ptr() + off, P, C1, W, k, ld, sp)
+            call("rac_transpose_split", ptr(x1_t), ptr(x1t), P, C1, W, k, ld, xl, t * P, sp)
     g = weight_mem(grad_buffer(weight))
     args = ConvArgs(mode=WGRAD, B=B * T, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
                     a_split=C0, o_split=0, slab_stride=0, a0=ptr(x0t), a1=ptr(x1t), w=ptr(dyt), out0=ptr(g), out1=None,
                     bias=None, scale=None, shift=None, stats=None)
-    call("rac_conv2d_wgrad_split", C.byref(args), sp)
+    call("rac_conv2d_wgrad_split", C.byref(args), xl, sp)
 
 
 def wgrad_split_ok(x0, x1, W: int) -> bool:

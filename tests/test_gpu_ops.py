@@ -363,10 +363,14 @@ def test_conv_split_precision_bf16x6(dev, case, layout, monkeypatch):
         assert relerr(got, xr.grad) < 2e-6
 
 
-@pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3)])
-def test_wgrad_split_precision(dev, case):
-    """Weight gradient from transposed bf16 parts (dx-shifted input copies, dy as whole-vector offsets)."""
+@pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
+                                  (5, 4, 8, 32, 0, 64, 3)])
+@pytest.mark.parametrize("direct", [False, True])
+def test_wgrad_split_precision(dev, case, direct, monkeypatch):
+    """Weight gradient from transposed bf16 parts (dx-shifted input copies, dy as whole-vector offsets); both
+    kernels: inputs through LDS, and inputs in fragment order loaded straight into the MFMA registers."""
     from robot_aware_control_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_DIRECT", direct)
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
     x = rnd(1, B, Cin, H, W)
