@@ -90,6 +90,11 @@ int rac_conv2d(const rac_conv_args* a, void* stream);
  * ------------------------------------------------------------------------ */
 /* parts[k*part_stride + i] = k-th bf16 part of x[i], k = 0..2 (round-to-nearest-even at every level) */
 int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream);
+/* Conv weight (fp32, [Cout][k][k][Cin] memory) -> bf16 parts in MFMA fragment order (w_layout 2 below), in one pass.
+ * transposed = 0: rows = Cout, K = Cin (forward).  transposed = 1: rows = Cin, K = Cout, taps flipped: the weight of
+ * the forward conv that IS the data gradient (dgrad(dy, W) == fwd(dy, Wt)).  Channel counts % 32 == 0. */
+int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Cout, int32_t Cin, int32_t ksize, int32_t transposed,
+                          int64_t part_stride, void* stream);
 /* FWD conv (as rac_conv2d mode RAC_CONV_FWD) on split operands: a0 / a1 / w point to bf16 part arrays
  * ([3][pixels][C] and [3][Cout][k][k][Cin]; *_part_stride in elements).  Needs Cin % 8 == 0, a_split % 32 == 0.
  * Epilogue fields (bias, scale/shift, act, stats, split_k slabs) behave as in rac_conv2d. */

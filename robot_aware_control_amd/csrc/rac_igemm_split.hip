@@ -1075,17 +1075,81 @@ __global__ void transpose_split_frag_kernel(const float* in, unsigned short* out
   }
 }
 
+__device__ __forceinline__ void split3(float a, unsigned short& q1, unsigned short& q2, unsigned short& q3) {
+  const __bf16 p1 = (__bf16)a;
+  const float r1 = a - (float)p1;
+  const __bf16 p2 = (__bf16)r1;
+  const __bf16 p3 = (__bf16)(r1 - (float)p2);
+  q1 = __builtin_bit_cast(unsigned short, p1);
+  q2 = __builtin_bit_cast(unsigned short, p2);
+  q3 = __builtin_bit_cast(unsigned short, p3);
+}
+
 __global__ void split_bf16x3_kernel(const float* x, unsigned short* parts, long n, long ps) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float a = x[i];
-    const __bf16 p1 = (__bf16)a;
-    const float r1 = a - (float)p1;
-    const __bf16 p2 = (__bf16)r1;
-    const float r2 = r1 - (float)p2;
-    const __bf16 p3 = (__bf16)r2;
-    parts[i] = __builtin_bit_cast(unsigned short, p1);
-    parts[ps + i] = __builtin_bit_cast(unsigned short, p2);
-    parts[2 * ps + i] = __builtin_bit_cast(unsigned short, p3);
+    unsigned short q1, q2, q3;
+    split3(x[i], q1, q2, q3);
+    parts[i] = q1;
+    parts[ps + i] = q2;
+    parts[2 * ps + i] = q3;
+  }
+}
+
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+// n % 4 == 0, ps % 4 == 0, 16-byte aligned x / 8-byte aligned parts: four values per lane
+__global__ void split_bf16x3_vec4_kernel(const float4* x, u16x4* parts, long n4, long ps4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 a = x[i];
+    u16x4 o1, o2, o3;
+    unsigned short q1, q2, q3;
+    split3(a.x, q1, q2, q3); o1.x = q1; o2.x = q2; o3.x = q3;
+    split3(a.y, q1, q2, q3); o1.y = q1; o2.y = q2; o3.y = q3;
+    split3(a.z, q1, q2, q3); o1.z = q1; o2.z = q2; o3.z = q3;
+    split3(a.w, q1, q2, q3); o1.w = q1; o2.w = q2; o3.w = q3;
+    parts[i] = o1;
+    parts[ps4 + i] = o2;
+    parts[2 * ps4 + i] = o3;
+  }
+}
+
+// Conv weight [Cout][taps][Cin] fp32 -> bf16 parts in MFMA fragment order (weight layout 2 of rac_conv2d_fwd_split):
+//   out[part][R/32][Kc/32][tap][s][lane = 32 h + r mod 32][j],  k = 32 chunk + 16 s + 8 h + j
+// forward:    rows r = co, k = ci, value w[r][tap][k]
+// transposed: rows r = ci, k = co, value w[k][taps-1-tap][r]   (the conv that IS the data gradient)
+// One workgroup = two (row tile, k chunk, tap) cells: every wave writes 1 KB contiguous per part.
+__global__ void weight_frag_split_kernel(const float* w, unsigned short* out, int Cout, int Cin, int taps, int transposed,
+                                         long ps) {
+  const int R = transposed ? Cin : Cout, Kc = transposed ? Cout : Cin;
+  const int cch = Kc >> 5;
+  const long cell = (long)blockIdx.x * 2 + (threadIdx.x >> 7);  // ((nt * cch + cc) * taps + tap)
+  if (cell >= (long)(R >> 5) * cch * taps) return;
+  const int tap = (int)(cell % taps);
+  const int cc = (int)((cell / taps) % cch);
+  const int nt = (int)(cell / ((long)taps * cch));
+  const int s = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int r = nt * 32 + li, k0 = cc * 32 + 16 * s + 8 * lh;
+  float v[8];
+  if (!transposed) {
+    const float4* src = reinterpret_cast<const float4*>(w + ((long)r * taps + tap) * Cin + k0);
+    const float4 a = src[0], b = src[1];
+    v[0] = a.x, v[1] = a.y, v[2] = a.z, v[3] = a.w, v[4] = b.x, v[5] = b.y, v[6] = b.z, v[7] = b.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = w[((long)(k0 + j) * taps + (taps - 1 - tap)) * Cin + r];
+  }
+  unsigned short q[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(v[j], q[0][j], q[1][j], q[2][j]);
+  const long o = (cell * 2 + s) * 512 + lane * 8;
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    u32x4 pk;
+    pk.x = q[part][0] | ((unsigned)q[part][1] << 16);
+    pk.y = q[part][2] | ((unsigned)q[part][3] << 16);
+    pk.z = q[part][4] | ((unsigned)q[part][5] << 16);
+    pk.w = q[part][6] | ((unsigned)q[part][7] << 16);
+    *reinterpret_cast<u32x4*>(out + part * ps + o) = pk;
   }
 }
 
@@ -1095,11 +1159,33 @@ using namespace rac;
 
 extern "C" int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream) {
   RAC_REQUIRE(x && parts && n > 0 && part_stride >= n, "rac_split_bf16x3: bad args");
+  if (n % 4 == 0 && part_stride % 4 == 0 && aligned16(x) && (reinterpret_cast<uintptr_t>(parts) & 7) == 0) {
+    long nb = (n / 4 + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(split_bf16x3_vec4_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(x), reinterpret_cast<u16x4*>(parts), (long)(n / 4),
+                       (long)(part_stride / 4));
+    return check_launch("rac_split_bf16x3");
+  }
   long nb = (n + 255) / 256;
   if (nb > 2048) nb = 2048;
   hipLaunchKernelGGL(split_bf16x3_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, parts,
                      (long)n, (long)part_stride);
   return check_launch("rac_split_bf16x3");
+}
+
+extern "C" int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Cout, int32_t Cin, int32_t ksize,
+                                     int32_t transposed, int64_t part_stride, void* stream) {
+  RAC_REQUIRE(w && parts && Cout > 0 && Cin > 0 && ksize >= 1 && (ksize & 1), "rac_weight_frag_split: bad args");
+  RAC_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "rac_weight_frag_split: channel counts must be multiples of 32");
+  const long n = (long)Cout * Cin * ksize * ksize;
+  RAC_REQUIRE(part_stride >= n && part_stride % 8 == 0 && aligned16(w) && aligned16(parts),
+              "rac_weight_frag_split: part stride / alignment");
+  const long cells = n / 1024;  // (row tile, k chunk, tap) cells of 32 x 32 weights
+  hipLaunchKernelGGL(weight_frag_split_kernel, dim3((unsigned)((cells + 1) / 2)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, parts, Cout, Cin, ksize * ksize, transposed,
+                     (long)part_stride);
+  return check_launch("rac_weight_frag_split");
 }
 
 extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64_t a1_ps, int64_t w_ps,

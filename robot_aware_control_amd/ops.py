@@ -300,6 +300,18 @@ def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int
 _W_LAYOUT_FN = {1: chunk_major, 2: frag_order}
 
 
+def weight_frag_parts(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+    """bf16 parts of a channels_last conv weight in MFMA fragment order (w_layout 2), one pass over the weight;
+    `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient.
+    Equals split_parts(frag_order(w)) resp. split_parts(frag_order(transposed_weight(w)))."""
+    co, ci, k, _ = weight.shape
+    w = weight_mem(weight.detach())
+    n = w.numel()
+    parts = torch.empty((3, n), device=w.device, dtype=torch.bfloat16)
+    call("rac_weight_frag_split", ptr(w), ptr(parts), co, ci, k, 1 if transposed else 0, n, stream_ptr())
+    return parts
+
+
 def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
                   stats=None, split_k=1, slab_stride=0, w_layout=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
@@ -331,7 +343,9 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     p0 = split_parts(x0)
     p1 = split_parts(x1) if x1 is not None else None
     cm = split_weight_layout(H, W, Cin, k, M, Cout)
-    if cm:
+    if cm == 2:
+        pw = _derived(weight, "_rac_split_l2", lambda: weight_frag_parts(weight))
+    elif cm:
         pw = _derived(weight, f"_rac_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](weight.detach())))
     else:
         pw = split_weight(weight)
@@ -371,12 +385,14 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     Co, Cin, k, _ = weight.shape
     assert Co == Cout and Cin == C0 + C1
     M = B * H * W
-    wt = transposed_weight(weight)  # (Cin, Cout, k, k)
     cm = split_weight_layout(H, W, Cout, k, M, Cin)
-    if cm:
-        pw = _derived(weight, f"_rac_transposed_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](wt)))
+    if cm == 2:
+        pw = _derived(weight, "_rac_transposed_split_l2", lambda: weight_frag_parts(weight, transposed=True))
+    elif cm:
+        pw = _derived(weight, f"_rac_transposed_split_l{cm}",
+                      lambda: split_parts(_W_LAYOUT_FN[cm](transposed_weight(weight))))  # (Cin, Cout, k, k)
     else:
-        pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(wt)))
+        pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(transposed_weight(weight))))
     pd = split_parts(dy)
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)

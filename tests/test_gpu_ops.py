@@ -363,6 +363,21 @@ def test_conv_split_precision_bf16x6(dev, case, layout, monkeypatch):
         assert relerr(got, xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(64, 96, 3), (128, 64, 5), (32, 64, 3)])
+def test_weight_frag_split(dev, shape):
+    """One-pass fragment-order split of a weight == permute + split, for the forward and the data-gradient weight;
+    vectorised rac_split_bf16x3 == scalar one."""
+    from robot_aware_control_amd import ops
+    co, ci, k = shape
+    w = cl_weight(rnd(5, co, ci, k, k)).to(dev)
+    assert torch.equal(ops.weight_frag_parts(w), ops.split_parts(ops.frag_order(w)))
+    assert torch.equal(ops.weight_frag_parts(w, transposed=True), ops.split_parts(ops.frag_order(ops.transposed_weight(w))))
+    x = rnd(6, 4099, scale=3.0).to(dev)  # odd length: scalar kernel; first 4096: vector kernel
+    pa, pb = ops.split_parts(x), ops.split_parts(x[:4096].clone())
+    assert torch.equal(pa[:, :4096], pb)
+    assert torch.equal(pb.float().sum(0), x[:4096])
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3)])
 @pytest.mark.parametrize("direct", [False, True])
