@@ -244,7 +244,7 @@ SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = os.environ.get("RAC_SPLIT_GEMM_TRAIN", "1") == "1"
 # the vgg layers of the training step on the same pipe: measured slower at cfg2 (76.1 vs 72.2 ms/step: small M at
 # the 8x8/16x16 layers, 128x128-only tile, per-call operand splitting), so off by default
-SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "0") == "1"
+SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "0")
 
 
 def split_parts(x: torch.Tensor) -> torch.Tensor:
@@ -476,6 +476,35 @@ def wgrad_split_ok(x0, x1, W: int) -> bool:
 
 
 # --------------------------------------------------------------------------- #
+# zeroed fp64 scratch for the per-channel reductions (BatchNorm statistics and their backward sums)
+# --------------------------------------------------------------------------- #
+# ~190 tiny zero-fill launches per train step otherwise: `begin_step()` zeroes one arena with one launch and
+# `zeros64()` hands out slices of it until the next `begin_step()`.
+_ARENA = {"buf": None, "used": 0}
+_ARENA_DOUBLES = 1 << 20
+
+
+def begin_step(device) -> None:
+    """Call once per train step before the first kernel: every slice handed out since the last call is recycled."""
+    buf = _ARENA["buf"]
+    if buf is None or buf.device != torch.device(device):
+        buf = _ARENA["buf"] = torch.empty(_ARENA_DOUBLES, device=device, dtype=torch.float64)
+    buf.zero_()
+    _ARENA["used"] = 0
+
+
+def zeros64(shape, device) -> torch.Tensor:
+    n = 1
+    for d in shape:
+        n *= d
+    buf, used = _ARENA["buf"], _ARENA["used"]
+    if buf is None or buf.device != torch.device(device) or used + n > _ARENA_DOUBLES:
+        return torch.zeros(shape, device=device, dtype=torch.float64)
+    _ARENA["used"] = used + (n + 1) // 2 * 2  # keep slices 16-byte aligned
+    return buf[used:used + n].view(shape)
+
+
+# --------------------------------------------------------------------------- #
 # autograd functions
 # --------------------------------------------------------------------------- #
 class ConvBias(torch.autograd.Function):
@@ -577,10 +606,13 @@ class VggLayer(torch.autograd.Function):
             ctx.mark_non_differentiable(y)  # frozen-model path (CEM / eval): no backward through folded BatchNorm
             return y
         dev = x0.device
-        stats = torch.zeros((2, Cout), device=dev, dtype=torch.float64)
+        stats = zeros64((2, Cout), dev)
         c0 = x0.shape[3]
-        ctx.split = (SPLIT_VGG_TRAIN and Cout >= 128 and c0 >= 64 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
-                     and (x1 is None or c0 % 128 == 0) and x0.shape[2] % 8 == 0)
+        # "1": every wide layer; "latent": only the layers whose maps fit the tap-inner kernels (H*W divides 128)
+        ctx.split = (SPLIT_VGG_TRAIN != "0" and Cout >= 128 and c0 >= 64 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
+                     and (x1 is None or c0 % 128 == 0) and x0.shape[2] % 8 == 0
+                     and (SPLIT_VGG_TRAIN == "1" or (weight.shape[1] % 32 == 0 and Cout % 32 == 0
+                                                     and 128 % (x0.shape[1] * x0.shape[2]) == 0)))
         if ctx.split:
             raw = conv_forward_split(x0, x1, weight, None, stats=stats)
         else:
@@ -600,7 +632,7 @@ class VggLayer(torch.autograd.Function):
         dy = dy.contiguous()
         Cout = weight.shape[0]
         M = raw.numel() // Cout
-        sums = torch.zeros((2, Cout), device=dy.device, dtype=torch.float64)
+        sums = zeros64((2, Cout), dy.device)
         call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M,
              Cout, stream_ptr())
         draw = torch.empty_like(raw)

@@ -166,6 +166,7 @@ class PredictionTrainer(object):
             batch_weight = (cf.movement_weight * mv).to(f32)
             batch_weight[~mv.bool()] = 1.0
 
+        ops.begin_step(x.device)
         self.model.zero_grad()
         bs = min(cf.batch_size, x.shape[1])
         self.model.init_hidden(bs)
