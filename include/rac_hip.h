@@ -71,7 +71,9 @@ typedef struct rac_conv_args {
   const float* bias;  /* [N] added first, or NULL */
   const float* scale; /* [N] v = v*scale + shift (folded eval BatchNorm), or NULL */
   const float* shift;
-  double* stats;      /* [2][N] fp64 sum / sum of squares of the raw conv output (train BatchNorm), or NULL */
+  double* stats;      /* [G][2][N] fp64 sum / sum of squares of the raw conv output (train BatchNorm), or NULL */
+  int64_t stats_rows; /* rows (pixels) per statistics group: G = B*H*W / stats_rows groups (time steps batched along
+                         the batch axis keep per-step statistics); 0 = one group.  Multiple of 128. */
 } rac_conv_args;
 
 /* Replaces aten::conv2d / conv_transpose2d and their backward on the hot path:
@@ -128,24 +130,27 @@ int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, void* strea
  * BatchNorm2d (training statistics) + LeakyReLU(0.2)
  *   src/prediction/models/vgg_64.py:12-14 (nn.BatchNorm2d, nn.LeakyReLU(0.2))
  * ------------------------------------------------------------------------ */
-/* stats = fp64 [2][C] (sum, sum of squares over `count` = B*H*W values, from rac_conv2d).
+/* `groups` (G >= 1) in this section: the M rows are G equal row ranges, each ONE BatchNorm call of the reference
+ * (time steps batched along the row axis keep their per-call batch statistics).  stats / sums are [G][2][C],
+ * scale / shift / mean / invstd are [G][C].
+ * stats = fp64 [G][2][C] (sum, sum of squares over `count` = B*H*W values per group, from rac_conv2d).
  * Writes mean/invstd (biased variance, eps), scale = gamma*invstd, shift = beta - mean*scale,
- * and applies the running-stat momentum update `n_updates` times (the reference encodes the
- * same frame twice per train step: dynamics.py:584,619). */
+ * and applies the groups' running-stat momentum updates in order, `n_updates` times each (the reference
+ * encodes the same frame twice per train step: dynamics.py:584,619). */
 int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, int32_t n_updates, float* scale, float* shift,
-                    float* mean, float* invstd, int32_t C, void* stream);
+                    float* mean, float* invstd, int32_t C, int32_t groups, void* stream);
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c]) */
 int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
-                   int32_t C, void* stream);
+                   int32_t C, int32_t groups, void* stream);
 /* sums = fp64 [2][C]: sum dz, sum dz*xhat  with z = x*scale+shift, dz = dy*(z>0?1:0.2), xhat=(x-mean)*invstd.
  * `sums` must be zero on entry. */
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                      const float* invstd, double* sums, int64_t M, int32_t C, void* stream);
+                      const float* invstd, double* sums, int64_t M, int32_t C, int32_t groups, void* stream);
 /* dx = scale*(dz - sum_dz/M - xhat*sum_dzx/M); dgamma += sum_dzx; dbeta += sum_dz */
 int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                      const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
-                     int32_t C, void* stream);
+                     int32_t C, int32_t groups, void* stream);
 
 /* MaxPool2d(2,2) / nearest x2 upsample on NHWC maps: vgg_64.py:120,126-128 / :221,235-240 */
 int rac_maxpool2_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -177,7 +182,7 @@ int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, co
 int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
                      int32_t N, int32_t o_split, void* stream);
 /* stats[c] += sum_m x[m][c]; stats[C+c] += sum_m x[m][c]^2  (fp64; BatchNorm statistics after a split-K combine) */
-int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream);
+int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, int32_t groups, void* stream);
 /* dx = dy * act'(.) expressed through the activation OUTPUT y (sigmoid: y(1-y); leaky: y>0 ? 1 : 0.2) */
 int rac_act_bwd(const float* dy, const float* y, int32_t act, float* dx, int64_t n, void* stream);
 

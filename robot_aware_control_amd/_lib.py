@@ -26,6 +26,7 @@ class ConvArgs(C.Structure):
         ("slab_stride", i64),
         ("a0", vp), ("a1", vp), ("w", vp), ("out0", vp), ("out1", vp),
         ("bias", vp), ("scale", vp), ("shift", vp), ("stats", vp),
+        ("stats_rows", i64),
     ]
 
 
@@ -37,10 +38,10 @@ _SIGS = {
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), i64, i64, i64, i32, vp],
     "rac_transpose_split": [vp, vp, i32, i32, i32, i32, i64, i32, i64, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(ConvArgs), i32, vp],
-    "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, vp],
-    "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, vp],
-    "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
-    "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
+    "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp],
+    "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "rac_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "rac_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_fwd": [vp, vp, i32, i32, i32, i32, vp],
@@ -52,7 +53,7 @@ _SIGS = {
     "rac_colsum_acc": [vp, vp, i64, i32, vp],
     "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp],
     "rac_slab_reduce2": [vp, i32, i64, vp, vp, i64, i32, i32, vp],
-    "rac_col_stats": [vp, vp, i64, i32, vp],
+    "rac_col_stats": [vp, vp, i64, i32, i32, vp],
     "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],

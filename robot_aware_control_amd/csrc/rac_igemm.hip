@@ -33,6 +33,7 @@ struct ConvP {
   float *out0, *out1;
   const float *bias, *scale, *shift;
   double* stats;
+  long stats_rows;  // rows per statistics group (0: one group); tiles never straddle groups
   int M, N, HW, P, taps, cchunks, nchunks, cps, ntile_per_tap;
   unsigned long long magic_hw, magic_w;  // ceil(2^40 / d): n / d == (n * magic) >> 40 for n * d < 2^40
 };
@@ -151,8 +152,9 @@ __device__ __forceinline__ void epilogue(const ConvP& p, f32x16 (&acc)[MT][NT], 
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lh == 0 && nok) {
-        atomicAdd(p.stats + n, (double)s1);
-        atomicAdd(p.stats + p.N + n, (double)s2);
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
       }
     }
   }
@@ -803,6 +805,10 @@ extern "C" int rac_conv2d(const rac_conv_args* a, void* stream) {
   p.slab_stride = a->slab_stride;
   p.a0 = a->a0, p.a1 = a->a1, p.w = a->w, p.out0 = a->out0, p.out1 = a->out1;
   p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
+  p.stats_rows = a->stats ? a->stats_rows : 0;
+  RAC_REQUIRE(p.stats_rows >= 0 && p.stats_rows % 128 == 0 &&
+                  (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
+              "rac_conv2d: stats_rows must be a multiple of 128 that divides B*H*W");
   p.HW = a->H * a->W;
   p.P = a->B * p.HW;
   p.taps = a->ksize * a->ksize;

@@ -23,6 +23,7 @@ struct SplitP {
   float* out0;
   const float *bias, *scale, *shift;
   double* stats;
+  long stats_rows;  // rows per statistics group (0: one group)
   int M, N, HW, P, taps, cchunks, nchunks, cps;
   int w_chunk_major;  // weights stored [Cout][Cin/32][taps][32] (tap-inner streaming order) instead of [Cout][taps][Cin]
   int xcd_group;      // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
@@ -233,8 +234,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_kernel(SplitP p) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lh == 0 && nok) {
-        atomicAdd(p.stats + n, (double)s1);
-        atomicAdd(p.stats + p.N + n, (double)s2);
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
       }
     }
   }
@@ -453,8 +455,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_tapinner_kernel(SplitP p) 
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lh == 0 && nok) {
-        atomicAdd(p.stats + n, (double)s1);
-        atomicAdd(p.stats + p.N + n, (double)s2);
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
       }
     }
   }
@@ -690,8 +693,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
     s1 += __shfl_xor(s1, 32);
     s2 += __shfl_xor(s2, 32);
     if (lh == 0 && nok) {
-      atomicAdd(p.stats + n, (double)s1);
-      atomicAdd(p.stats + p.N + n, (double)s2);
+      double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+      atomicAdd(sg + n, (double)s1);
+      atomicAdd(sg + p.N + n, (double)s2);
     }
   }
 }
@@ -1205,6 +1209,10 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   p.a0_ps = a0_ps, p.a1_ps = a1_ps, p.w_ps = w_ps;
   p.out0 = a->out0;
   p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
+  p.stats_rows = a->stats ? a->stats_rows : 0;
+  RAC_REQUIRE(p.stats_rows >= 0 && p.stats_rows % 128 == 0 &&
+                  (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
+              "rac_conv2d_fwd_split: stats_rows must be a multiple of 128 that divides B*H*W");
   p.HW = a->H * a->W;
   p.P = a->B * p.HW;
   p.M = p.P, p.N = a->Cout;

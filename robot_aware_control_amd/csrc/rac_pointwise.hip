@@ -21,28 +21,35 @@ static inline int grid_for(long work_items) {
 }
 
 // ------------------------------------------------------------------ BatchNorm
+// `G` groups of `count` rows each (time steps batched along the row axis: every group is one BatchNorm call of
+// the reference).  stats [G][2][C]; scale/shift/mean/invstd [G][C]; the running statistics take the groups' momentum
+// updates in order, `n_updates` times each.
 __global__ void bn_finalize_kernel(const double* stats, long count, const float* gamma, const float* beta,
                                    float* rmean, float* rvar, float momentum, float eps, int n_updates, float* scale,
-                                   float* shift, float* mean_o, float* invstd_o, int C) {
+                                   float* shift, float* mean_o, float* invstd_o, int C, int G) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double mean = stats[c] / (double)count;
-  double var = stats[C + c] / (double)count - mean * mean;
-  if (var < 0) var = 0;
-  float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  float meanf = (float)mean;
-  float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - meanf * sc;
-  mean_o[c] = meanf;
-  invstd_o[c] = invstd;
-  if (rmean) {
+  float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+  const float ga = gamma[c], be = beta[c];
+  for (int g = 0; g < G; ++g) {
+    const double* st = stats + (long)g * 2 * C;
+    double mean = st[c] / (double)count;
+    double var = st[C + c] / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    float meanf = (float)mean;
+    float sc = ga * invstd;
+    scale[g * C + c] = sc;
+    shift[g * C + c] = be - meanf * sc;
+    mean_o[g * C + c] = meanf;
+    invstd_o[g * C + c] = invstd;
     float unbiased = (float)(count > 1 ? var * (double)count / (double)(count - 1) : var);
-    float rm = rmean[c], rv = rvar[c];
     for (int i = 0; i < n_updates; ++i) {
       rm = (1.f - momentum) * rm + momentum * meanf;
       rv = (1.f - momentum) * rv + momentum * unbiased;
     }
+  }
+  if (rmean) {
     rmean[c] = rm;
     rvar[c] = rv;
   }
@@ -54,10 +61,11 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
+// scale / shift are [G][C]; `ge` = elements (vectors) per group
 __global__ void affine_act_kernel4(const f32x4* x, const f32x4* scale, const f32x4* shift, int act, f32x4* y, long n4,
-                                   int C4) {
+                                   int C4, long ge) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C4);
+    int c = (int)(i % C4) + (int)(i / ge) * C4;
     f32x4 v = x[i], s = scale[c], t = shift[c], o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] * s[e] + t[e], act);
@@ -65,26 +73,29 @@ __global__ void affine_act_kernel4(const f32x4* x, const f32x4* scale, const f32
   }
 }
 __global__ void affine_act_kernel1(const float* x, const float* scale, const float* shift, int act, float* y, long n,
-                                   int C) {
+                                   int C, long ge) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
+    int c = (int)(i % C) + (int)(i / ge) * C;
     y[i] = act_apply(x[i] * scale[c] + shift[c], act);
   }
 }
 
 // Per-channel reductions over M rows.  grid = (row blocks, 64-channel groups), block = 4 row lanes x 64 channel
 // lanes; partials combined through LDS, then one fp64 atomic per (block, channel).
+// grid.x = G groups x `bpg` row blocks; `Mg` rows per group; sums [G][2][C], scale.. [G][C]
 __global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const float* scale, const float* shift,
-                                     const float* mean, const float* invstd, double* sums, long M, int C,
-                                     int rows_per_block) {
+                                     const float* mean, const float* invstd, double* sums, long Mg, int C,
+                                     int rows_per_block, int bpg) {
   __shared__ float s1[256], s2[256];
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  const long r_begin = (long)blockIdx.x * rows_per_block;
-  const long r_end = min(r_begin + rows_per_block, M);
+  const int g = blockIdx.x / bpg;
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
   float a1 = 0.f, a2 = 0.f;
   if (c < C) {
-    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const int gc = g * C + c;
+    const float sc = scale[gc], sh = shift[gc], mu = mean[gc], is = invstd[gc];
     for (long r = r_begin + rl; r < r_end; r += 4) {
       float xv = x[r * C + c];
       float z = xv * sc + sh;
@@ -98,29 +109,37 @@ __global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const floa
   __syncthreads();
   if (threadIdx.x < 64 && c < C) {
     const int t = threadIdx.x;
-    atomicAdd(sums + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
-    atomicAdd(sums + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
+    double* sg = sums + (long)g * 2 * C;
+    atomicAdd(sg + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
+    atomicAdd(sg + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
   }
 }
 
 __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float* scale, const float* shift,
                                     const float* mean, const float* invstd, const double* sums, float* dx,
-                                    float* dgamma, float* dbeta, long M, int C) {
-  const long n = M * C;
-  const double invM = 1.0 / (double)M;
+                                    float* dgamma, float* dbeta, long Mg, int C, int G) {
+  const long ge = Mg * C, n = ge * G;
+  const double invM = 1.0 / (double)Mg;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    float xv = x[i], sc = scale[c];
-    float z = xv * sc + shift[c];
+    const int c = (int)(i % C), g = (int)(i / ge);
+    const int gc = g * C + c;
+    float xv = x[i], sc = scale[gc];
+    float z = xv * sc + shift[gc];
     float dz = dy[i] * (z > 0.f ? 1.f : 0.2f);
-    float xh = (xv - mean[c]) * invstd[c];
-    float m1 = (float)(sums[c] * invM), m2 = (float)(sums[C + c] * invM);
+    float xh = (xv - mean[gc]) * invstd[gc];
+    const double* sg = sums + (long)g * 2 * C;
+    float m1 = (float)(sg[c] * invM), m2 = (float)(sg[C + c] * invM);
     dx[i] = sc * (dz - m1 - xh * m2);
   }
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      dgamma[c] += (float)sums[C + c];
-      dbeta[c] += (float)sums[c];
+      double a = 0., b = 0.;
+      for (int g = 0; g < G; ++g) {
+        a += sums[(long)g * 2 * C + C + c];
+        b += sums[(long)g * 2 * C + c];
+      }
+      dgamma[c] += (float)a;
+      dbeta[c] += (float)b;
     }
   }
 }
@@ -285,12 +304,13 @@ __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_st
   }
 }
 
-__global__ void col_stats_kernel(const float* x, double* stats, long M, int C, int rows_per_block) {
+__global__ void col_stats_kernel(const float* x, double* stats, long Mg, int C, int rows_per_block, int bpg) {
   __shared__ float s1[256], s2[256];
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;
-  const long r_begin = (long)blockIdx.x * rows_per_block;
-  const long r_end = min(r_begin + rows_per_block, M);
+  const int g = blockIdx.x / bpg;  // stats [G][2][C], `Mg` rows per group
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
   float a1 = 0.f, a2 = 0.f;
   if (c < C)
     for (long r = r_begin + rl; r < r_end; r += 4) {
@@ -303,8 +323,9 @@ __global__ void col_stats_kernel(const float* x, double* stats, long M, int C, i
   __syncthreads();
   if (threadIdx.x < 64 && c < C) {
     const int t = threadIdx.x;
-    atomicAdd(stats + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
-    atomicAdd(stats + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
+    double* sg = stats + (long)g * 2 * C;
+    atomicAdd(sg + c, (double)((s1[t] + s1[t + 64]) + (s1[t + 128] + s1[t + 192])));
+    atomicAdd(sg + C + c, (double)((s2[t] + s2[t + 64]) + (s2[t + 128] + s2[t + 192])));
   }
 }
 
@@ -431,23 +452,24 @@ const char* rac_last_error(void) { return g_err; }
 
 int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, int32_t n_updates, float* scale, float* shift,
-                    float* mean, float* invstd, int32_t C, void* stream) {
-  RAC_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0,
+                    float* mean, float* invstd, int32_t C, int32_t groups, void* stream) {
+  RAC_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0 && groups >= 1,
               "rac_bn_finalize: bad args");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), stats, (long)count, gamma, beta,
-                     running_mean, running_var, momentum, eps, n_updates, scale, shift, mean, invstd, C);
+                     running_mean, running_var, momentum, eps, n_updates, scale, shift, mean, invstd, C, groups);
   return check_launch("rac_bn_finalize");
 }
 
 int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
-                   int32_t C, void* stream) {
-  RAC_REQUIRE(x && scale && shift && y && M > 0 && C > 0, "rac_affine_act: bad args");
+                   int32_t C, int32_t groups, void* stream) {
+  RAC_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && groups >= 1 && M % groups == 0, "rac_affine_act: bad args");
   long n = (long)M * C;
   if (C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift)) {
     hipLaunchKernelGGL(affine_act_kernel4, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)x,
-                       (const f32x4*)scale, (const f32x4*)shift, act, (f32x4*)y, n / 4, C / 4);
+                       (const f32x4*)scale, (const f32x4*)shift, act, (f32x4*)y, n / 4, C / 4, n / 4 / groups);
   } else {
-    hipLaunchKernelGGL(affine_act_kernel1, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, scale, shift, act, y, n, C);
+    hipLaunchKernelGGL(affine_act_kernel1, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, scale, shift, act, y, n, C,
+                       n / groups);
   }
   return check_launch("rac_affine_act");
 }
@@ -472,22 +494,28 @@ static int rows_per_block_for(long M, int* nblocks) {
 }
 
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
-                      const float* invstd, double* sums, int64_t M, int32_t C, void* stream) {
-  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0, "rac_bn_bwd_reduce: bad args");
+                      const float* invstd, double* sums, int64_t M, int32_t C, int32_t groups, void* stream) {
+  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
+              "rac_bn_bwd_reduce: bad args");
   int rpb;
-  dim3 grid = reduce_grid(M, C, &rpb);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, x, scale, shift, mean, invstd, sums,
-                     (long)M, C, rpb);
+  const long Mg = M / groups;
+  dim3 grid = reduce_grid(Mg, C, &rpb);
+  const int bpg = (int)grid.x;
+  grid.x *= groups;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, ST(stream), dy, x, scale, shift, mean, invstd, sums, Mg,
+                     C, rpb, bpg);
   return check_launch("rac_bn_bwd_reduce");
 }
 
 int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                      const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
-                     int32_t C, void* stream) {
-  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && M > 0 && C > 0, "rac_bn_bwd_apply: bad args");
+                     int32_t C, int32_t groups, void* stream) {
+  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && M > 0 && C > 0 && groups >= 1 &&
+                  M % groups == 0,
+              "rac_bn_bwd_apply: bad args");
   RAC_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rac_bn_bwd_apply: dgamma/dbeta must come together");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, ST(stream), dy, x, scale, shift,
-                     mean, invstd, sums, dx, dgamma, dbeta, (long)M, C);
+                     mean, invstd, sums, dx, dgamma, dbeta, (long)(M / groups), C, groups);
   return check_launch("rac_bn_bwd_apply");
 }
 
@@ -592,11 +620,14 @@ int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, f
   return check_launch("rac_slab_reduce2");
 }
 
-int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, void* stream) {
-  RAC_REQUIRE(x && stats && M > 0 && C > 0, "rac_col_stats: bad args");
+int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, int32_t groups, void* stream) {
+  RAC_REQUIRE(x && stats && M > 0 && C > 0 && groups >= 1 && M % groups == 0, "rac_col_stats: bad args");
   int rpb;
-  dim3 grid = reduce_grid(M, C, &rpb);
-  hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(stream), x, stats, (long)M, C, rpb);
+  const long Mg = M / groups;
+  dim3 grid = reduce_grid(Mg, C, &rpb);
+  const int bpg = (int)grid.x;
+  grid.x *= groups;
+  hipLaunchKernelGGL(col_stats_kernel, grid, dim3(256), 0, ST(stream), x, stats, Mg, C, rpb, bpg);
   return check_launch("rac_col_stats");
 }
 

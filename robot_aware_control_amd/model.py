@@ -69,10 +69,11 @@ class _VggLayer(nn.Module):
         self.main = nn.ModuleList([_Conv(cin, cout, 3, bias=False), _BatchNorm(cout)])
         self._folded = None
 
-    def forward(self, x0, x1=None, n_updates=1):
+    def forward(self, x0, x1=None, n_updates=1, groups=1):
+        """`groups` > 1: the batch holds that many time steps, each normalised with its own batch statistics."""
         conv, bn = self.main[0], self.main[1]
         if self.training:
-            bn.pending_updates += n_updates
+            bn.pending_updates += n_updates * groups
             folded = None
         else:
             if self._folded is None:  # eval: BatchNorm folded into the conv epilogue
@@ -81,7 +82,7 @@ class _VggLayer(nn.Module):
                     self._folded = (scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
             folded = self._folded
         return ops.VggLayer.apply(x0, x1, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                  self.training, n_updates, folded)
+                                  self.training, n_updates, folded, groups if self.training else 1)
 
 
 class _Encoder(nn.Module):
@@ -93,13 +94,13 @@ class _Encoder(nn.Module):
             chans = [nc if (c is None and i == 0) else (dim if c is None else c) for i, c in enumerate(chans)]
             setattr(self, name, nn.ModuleList([_VggLayer(chans[i], chans[i + 1]) for i in range(len(chans) - 1)]))
 
-    def forward(self, x, n_updates=1):
+    def forward(self, x, n_updates=1, groups=1):
         skips = []
         for i, name in enumerate(("c1", "c2", "c3", "c4")):
             if i:
                 x = ops.MaxPool2.apply(x)
             for layer in getattr(self, name):
-                x = layer(x, None, n_updates)
+                x = layer(x, None, n_updates, groups)
             skips.append(x)
         return x, skips
 
@@ -114,18 +115,18 @@ class _Decoder(nn.Module):
             setattr(self, name, nn.ModuleList([_VggLayer(chans[i], chans[i + 1]) for i in range(len(chans) - 1)]))
         self.upc5 = nn.ModuleList([_VggLayer(128, 64), _Conv(64, nc, 3, bias=True, transposed=True)])
 
-    def forward(self, vec, skip):
+    def forward(self, vec, skip, groups=1):
         d = vec
         for layer in self.upc2:
-            d = layer(d)
+            d = layer(d, None, 1, groups)
         for name, sk in (("upc3", skip[2]), ("upc4", skip[1])):
             up = ops.Upsample2.apply(d)
             layers = getattr(self, name)
-            d = layers[0](up, sk)
+            d = layers[0](up, sk, 1, groups)
             for layer in list(layers)[1:]:
-                d = layer(d)
+                d = layer(d, None, 1, groups)
         up = ops.Upsample2.apply(d)
-        d = self.upc5[0](up, skip[0])
+        d = self.upc5[0](up, skip[0], 1, groups)
         head = self.upc5[1]
         return ops.ConvTHead.apply(d, head.weight, head.bias)
 
@@ -362,6 +363,45 @@ class SVGConvModel(nn.Module):
                      force_use_prior=False, sample_mean=False, zero_mask=None):
         """`forward` on NHWC maps (no layout conversion of the results).  `zero_mask` fuses
         zero_robot_region(mask, image) (src/utils/image.py:5-19) into the input packing."""
+        h, curr_skip = self._encode(image, mask, heatmap, zero_mask, 2 if posterior else 1, 1)
+        if self._config.last_frame_skip or skip is None:
+            skip = curr_skip
+        h_pred, mu, logvar, mu_p, logvar_p = self._recur(h, robot, action, posterior, next_robot, force_use_prior,
+                                                         sample_mean)
+        x4 = self.decoder(h_pred, skip)
+        return x4, skip, mu, logvar, mu_p, logvar_p
+
+    def forward_sequence_maps(self, images, masks, robots, heatmaps, actions, next_robots, zero_masks=None):
+        """Teacher-forced training window in one pass (all `T` inputs are ground truth, `last_frame_skip`):
+        the encoder runs ONCE over the T*B input frames and the decoder ONCE over the T*B predicted latents, every
+        BatchNorm layer keeping one set of batch statistics per time step (and applying their running-stat updates
+        in time order), so each sample sees exactly the arithmetic of T calls of `forward_maps`; only the
+        recurrent part (input convs, prior / posterior / frame-predictor ConvLSTMs) is stepped.
+
+        images (T,B,3,H,W), masks (T,B,m,H,W) or None, heatmaps likewise, zero_masks (T,B,1,H,W) or None;
+        robots / actions / next_robots: per-step sequences (robots[t] may be a (r, r_next) tuple).
+        Returns (x4 (T*B,H,W,4), [mu_t], [logvar_t], [mu_p_t], [logvar_p_t])."""
+        T, B = images.shape[0], images.shape[1]
+        flat = lambda t: None if t is None else t.reshape((T * B,) + tuple(t.shape[2:]))
+        h_all, skips = self._encode(flat(images), flat(masks), flat(heatmaps), flat(zero_masks), 2, T)
+        h_steps = h_all.view((T, B) + tuple(h_all.shape[1:])).unbind(0)
+        h_preds, mus, logvars, mu_ps, logvar_ps = [], [], [], [], []
+        for t in range(T):
+            h_pred, mu, logvar, mu_p, logvar_p = self._recur(h_steps[t], robots[t], actions[t], True, next_robots[t],
+                                                             False, False)
+            h_preds.append(h_pred)
+            mus.append(mu)
+            logvars.append(logvar)
+            mu_ps.append(mu_p)
+            logvar_ps.append(logvar_p)
+        x4 = self.decoder(torch.cat(h_preds, 0), skips, T)
+        return x4, mus, logvars, mu_ps, logvar_ps
+
+    def sequence_ok(self, batch: int, height: int, width: int) -> bool:
+        """`forward_sequence_maps` needs per-step row ranges that are whole 128-row tiles at every resolution."""
+        return self.training and bool(self._config.last_frame_skip) and (batch * (height // 8) * (width // 8)) % 128 == 0
+
+    def _encode(self, image, mask, heatmap, zero_mask, n_updates, groups):
         cf = self._config
         image = image.contiguous()
         mask_planes = None
@@ -371,10 +411,12 @@ class SVGConvModel(nn.Module):
             mask_planes = mask if mask_planes is None else torch.cat([mask_planes, mask], 1)
         if mask_planes is not None:
             mask_planes = mask_planes.contiguous()
-        x_in = ops.PackInput.apply(image, zero_mask, mask_planes)
-        h, curr_skip = self.encoder(x_in, 2 if posterior else 1)
-        if cf.last_frame_skip or skip is None:
-            skip = curr_skip
+        x_in = ops.PackInput.apply(image, None if zero_mask is None else zero_mask.contiguous(), mask_planes)
+        return self.encoder(x_in, n_updates, groups)
+
+    def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean):
+        """The stepped part of `forward`: prior / posterior / frame predictor on one time step's latent."""
+        cf = self._config
         a = action.contiguous()
         r = r_next = None
         if cf.model_use_robot_state:
@@ -398,5 +440,4 @@ class SVGConvModel(nn.Module):
         f = self.frame_pred_input_conv
         frame_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, z), None, f.weight, f.bias, ACT_NONE)
         h_pred = self.frame_predictor(frame_in)
-        x4 = self.decoder(h_pred, skip)
-        return x4, skip, mu, logvar, mu_p, logvar_p
+        return h_pred, mu, logvar, mu_p, logvar_p

@@ -135,33 +135,35 @@ PROFILE = None
 
 
 def conv_raw(mode: int, a0, a1, w, out0, out1=None, *, B, H, W, ksize, Cin, Cout, act=ACT_NONE, split_k=1,
-             slab_stride=0, accumulate=0, a_split=0, o_split=0, bias=None, scale=None, shift=None, stats=None):
+             slab_stride=0, accumulate=0, a_split=0, o_split=0, bias=None, scale=None, shift=None, stats=None,
+             stats_rows=0):
     prof = PROFILE
     if prof is not None and prof["match"] == (mode, ksize, Cin, Cout):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
-                     a_split, o_split, bias, scale, shift, stats)
+                     a_split, o_split, bias, scale, shift, stats, stats_rows)
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
         return
     _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
-                 a_split, o_split, bias, scale, shift, stats)
+                 a_split, o_split, bias, scale, shift, stats, stats_rows)
 
 
 def _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, split_k, slab_stride, accumulate,
-                 a_split, o_split, bias, scale, shift, stats):
+                 a_split, o_split, bias, scale, shift, stats, stats_rows=0):
     args = ConvArgs(mode=mode, B=B, H=H, W=W, ksize=ksize, Cin=Cin, Cout=Cout, act=act, split_k=split_k,
                     accumulate=accumulate, a_split=a_split, o_split=o_split, slab_stride=slab_stride,
                     a0=ptr(a0), a1=ptr(a1), w=ptr(w), out0=ptr(out0), out1=ptr(out1), bias=ptr(bias),
-                    scale=ptr(scale), shift=ptr(shift), stats=ptr(stats))
+                    scale=ptr(scale), shift=ptr(shift), stats=ptr(stats), stats_rows=stats_rows)
     call("rac_conv2d", C.byref(args), stream_ptr())
 
 
 def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                 allow_split=True, want_slabs=False):
+                 allow_split=True, want_slabs=False, groups=1):
     """FWD conv over the virtual concat [x0 | x1].  Returns the (B,H,W,Cout) map, or
-    (slabs, n_slabs, slab_stride) when `want_slabs` (raw partial sums, no bias/epilogue)."""
+    (slabs, n_slabs, slab_stride) when `want_slabs` (raw partial sums, no bias/epilogue).
+    `groups`: `stats` is [groups][2][Cout], one statistics group per B/groups images."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
     C1 = x1.shape[3] if x1 is not None else 0
@@ -183,14 +185,15 @@ def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=N
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
     if split == 1:
         conv_raw(FWD, x0, x1, weight, out, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, act=act,
-                 bias=bias, scale=scale, shift=shift, stats=stats)
+                 bias=bias, scale=scale, shift=shift, stats=stats,
+                 stats_rows=(M // groups if (groups > 1 and stats is not None) else 0))
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         conv_raw(FWD, x0, x1, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0,
                  split_k=split, slab_stride=M * Cout)
         call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
         if stats is not None:
-            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, stream_ptr())
+            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, groups, stream_ptr())
     return out
 
 
@@ -242,9 +245,10 @@ SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 # the training step's ConvLSTM gate GEMMs: forward and data gradient on the split-precision pipe (the weight
 # gradient stays on exact-fp32 MFMA)
 SPLIT_GEMM_TRAIN = os.environ.get("RAC_SPLIT_GEMM_TRAIN", "1") == "1"
-# the vgg layers of the training step on the same pipe: measured slower at cfg2 (76.1 vs 72.2 ms/step: small M at
-# the 8x8/16x16 layers, 128x128-only tile, per-call operand splitting), so off by default
-SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "0")
+# the wide (>= 128 output channels) vgg layers of the training step on the same pipe: "1" all of them (default:
+# 56.7 vs 59.7 ms/step at cfg2 with the time-batched encoder / decoder, 60.7 vs 61.1 step by step), "latent" only
+# the layers whose maps fit the tap-inner kernels, "0" none (exact-fp32 MFMA)
+SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "1")
 
 
 def split_parts(x: torch.Tensor) -> torch.Tensor:
@@ -313,10 +317,11 @@ def weight_frag_parts(weight: torch.Tensor, transposed: bool = False) -> torch.T
 
 
 def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
-                  stats=None, split_k=1, slab_stride=0, w_layout=0):
+                  stats=None, split_k=1, slab_stride=0, w_layout=0, stats_rows=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out),
-                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats))
+                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
+                    stats_rows=stats_rows)
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -331,7 +336,7 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
 
 
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                       want_slabs=False):
+                       want_slabs=False, groups=1):
     """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel."""
     _require_cuda(x0)
@@ -360,14 +365,15 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
     if split == 1:
         _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
-                      shift=shift, stats=stats, w_layout=cm)
+                      shift=shift, stats=stats, w_layout=cm,
+                      stats_rows=(M // groups if (groups > 1 and stats is not None) else 0))
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         _split_launch(p0, p1, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
                       slab_stride=M * Cout, w_layout=cm)
         call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
         if stats is not None:
-            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, stream_ptr())
+            call("rac_col_stats", ptr(out), ptr(stats), M, Cout, groups, stream_ptr())
     return out
 
 
@@ -589,7 +595,7 @@ class VggLayer(torch.autograd.Function):
     eval: BatchNorm folded into the conv epilogue (`folded` = (scale, shift))."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, gamma, beta, rmean, rvar, training, n_updates, folded):
+    def forward(ctx, x0, x1, weight, gamma, beta, rmean, rvar, training, n_updates, folded, groups=1):
         Cout = weight.shape[0]
         padded = weight.shape[1] % 4 != 0 and x1 is None and x0.shape[3] == weight.shape[1] + pad4(weight.shape[1])
         ctx.padded = padded
@@ -606,7 +612,8 @@ class VggLayer(torch.autograd.Function):
             ctx.mark_non_differentiable(y)  # frozen-model path (CEM / eval): no backward through folded BatchNorm
             return y
         dev = x0.device
-        stats = zeros64((2, Cout), dev)
+        G = ctx.groups = int(groups)  # time steps batched along B: one BatchNorm call of the reference per group
+        stats = zeros64((G, 2, Cout), dev)
         c0 = x0.shape[3]
         # "1": every wide layer; "latent": only the layers whose maps fit the tap-inner kernels (H*W divides 128)
         ctx.split = (SPLIT_VGG_TRAIN != "0" and Cout >= 128 and c0 >= 64 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
@@ -614,15 +621,16 @@ class VggLayer(torch.autograd.Function):
                      and (SPLIT_VGG_TRAIN == "1" or (weight.shape[1] % 32 == 0 and Cout % 32 == 0
                                                      and 128 % (x0.shape[1] * x0.shape[2]) == 0)))
         if ctx.split:
-            raw = conv_forward_split(x0, x1, weight, None, stats=stats)
+            raw = conv_forward_split(x0, x1, weight, None, stats=stats, groups=G)
         else:
-            raw = conv_forward(x0, x1, weight, None, stats=stats)
+            raw = conv_forward(x0, x1, weight, None, stats=stats, groups=G)
         M = raw.numel() // Cout
-        aff = torch.empty((4, Cout), device=dev, dtype=torch.float32)  # scale, shift, mean, invstd
-        call("rac_bn_finalize", ptr(stats), M, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
-             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, stream_ptr())
+        assert M % G == 0 and (G == 1 or (M // G) % 128 == 0), (M, G)
+        aff = torch.empty((4, G, Cout), device=dev, dtype=torch.float32)  # scale, shift, mean, invstd per group
+        call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
+             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, G, stream_ptr())
         y = torch.empty_like(raw)
-        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, stream_ptr())
+        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, G, stream_ptr())
         ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
         return y
 
@@ -632,14 +640,15 @@ class VggLayer(torch.autograd.Function):
         dy = dy.contiguous()
         Cout = weight.shape[0]
         M = raw.numel() // Cout
-        sums = zeros64((2, Cout), dy.device)
+        G = ctx.groups
+        sums = zeros64((G, 2, Cout), dy.device)
         call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M,
-             Cout, stream_ptr())
+             Cout, G, stream_ptr())
         draw = torch.empty_like(raw)
         want_affine = gamma.requires_grad
         call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums),
              ptr(draw), ptr(grad_buffer(gamma)) if want_affine else None,
-             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, stream_ptr())
+             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, G, stream_ptr())
         C0 = x0.shape[3]
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
@@ -655,7 +664,7 @@ class VggLayer(torch.autograd.Function):
                 conv_wgrad_split_acc(draw, x0, x1, weight)
             else:
                 conv_wgrad_acc(draw, x0, x1, weight)
-        return dx0, dx1, None, None, None, None, None, None, None, None
+        return dx0, dx1, None, None, None, None, None, None, None, None, None
 
 
 class MaxPool2(torch.autograd.Function):

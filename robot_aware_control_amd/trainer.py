@@ -24,6 +24,9 @@ from . import ops
 from .model import SVGConvModel
 from .optim import FusedAdam
 
+# teacher-forced windows run the encoder / decoder once over all time steps (RAC_SEQUENCE_PATH=0: step by step)
+SEQUENCE_PATH = os.environ.get("RAC_SEQUENCE_PATH", "1") == "1"
+
 
 def _dist_on() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -172,42 +175,66 @@ class PredictionTrainer(object):
         self.model.init_hidden(bs)
         dontcare = "dontcare" in cf.reconstruction_loss or cf.black_robot_input
         roots, seeds, log = [], [], []  # autograd roots, their incoming grads, (name, tensor, index) for the readback
-        x_pred = None
-        skip = None
-        for i in range(1, cf.n_past + cf.n_future):
-            truth = True
-            if i > 1:
-                truth = self._use_true_token() if use_truth is None else bool(use_truth[i])
-            x_j = x[i - 1] if truth else x_pred  # scheduled sampling: gradients flow through the fed-back frame
-            m_j, r_j, a_j = mask[i - 1], states[i - 1], ac[i - 1]
-            x_i, m_i, r_i = x[i], mask[i], states[i]
-            if cf.last_frame_skip:
-                skip = None
-            m_in = torch.cat([m_j, m_i], 1) if cf.model_use_future_mask else m_j
-            r_in = (r_j, r_i) if cf.model_use_future_robot_state else r_j
-            hm_in = None
-            if heatmaps is not None:
-                hm_in = torch.cat([heatmaps[i - 1], heatmaps[i]], 1) if cf.model_use_future_heatmap else heatmaps[i - 1]
-            x4, curr_skip, mu, logvar, mu_p, logvar_p = self.model.forward_maps(
-                x_j, m_in, r_in, hm_in, a_j, True, r_i, skip, zero_mask=m_j if dontcare else None)
-            x_pred = ops.Composite.apply(x4, x_j.contiguous())  # un-blacked x_j (trainer.py:406-407)
-            if i <= cf.n_past:
-                skip = curr_skip
+        n_steps = cf.n_past + cf.n_future - 1
+
+        def add_losses(x_pred, i, mu, logvar, mu_p, logvar_p):
+            x_i, m_i = x[i], mask[i]
             rec = self._recon_loss(x_pred, x_i.contiguous(), m_i.contiguous(), batch_weight)
             roots.append(rec)
             seeds.append(self._seed(1.0, 3, first_only=True))
-            log += [("recon_loss", rec, 0), ("robot_loss", rec, 1), ("world_loss", rec, 2)]
+            log.extend([("recon_loss", rec, 0), ("robot_loss", rec, 1), ("world_loss", rec, 2)])
             if len(all_robots) > 1:  # per-robot logging metrics (trainer.py:442-452)
                 with torch.no_grad():
                     for r in all_robots:
                         idx = torch.from_numpy(np.nonzero(robot_name == r)[0]).to(dev)
                         sub = ops.ReconLoss.apply(x_pred.detach()[idx].contiguous(), x_i[idx].contiguous(),
                                                   m_i[idx].contiguous(), None, 0, 0.0)
-                        log += [(f"{r}_robot_loss", sub, 1), (f"{r}_world_loss", sub, 2)]
+                        log.extend([(f"{r}_robot_loss", sub, 1), (f"{r}_world_loss", sub, 2)])
             kl = ops.KLLoss.apply(mu, logvar, mu_p, logvar_p, bs)
             roots.append(kl)
             seeds.append(self._seed(float(cf.beta)))
             log.append(("kld", kl, 0))
+
+        # scheduled-sampling coins of the window, drawn in the reference's order (nothing else uses np.random here)
+        truths = [True] + [(self._use_true_token() if use_truth is None else bool(use_truth[i]))
+                           for i in range(2, n_steps + 1)]
+        H, W = x.shape[-2], x.shape[-1]
+        if SEQUENCE_PATH and all(truths) and self.model.sequence_ok(bs, H, W) and x.shape[1] == bs:
+            # every input frame is ground truth: encoder and decoder run once over the whole window
+            T = n_steps
+            m_all = torch.cat([mask[:T], mask[1:T + 1]], 2) if cf.model_use_future_mask else mask[:T]
+            hm_all = None
+            if heatmaps is not None:
+                hm_all = torch.cat([heatmaps[:T], heatmaps[1:T + 1]], 2) if cf.model_use_future_heatmap else heatmaps[:T]
+            robots = [((states[t], states[t + 1]) if cf.model_use_future_robot_state else states[t]) for t in range(T)]
+            x4, mus, logvars, mu_ps, logvar_ps = self.model.forward_sequence_maps(
+                x[:T], m_all, robots, hm_all, [ac[t] for t in range(T)], [states[t + 1] for t in range(T)],
+                mask[:T] if dontcare else None)
+            x_pred_all = ops.Composite.apply(x4, x[:T].reshape((T * bs,) + tuple(x.shape[2:])).contiguous())
+            x_preds = x_pred_all.view((T, bs) + tuple(x_pred_all.shape[1:])).unbind(0)
+            for t in range(T):
+                add_losses(x_preds[t], t + 1, mus[t], logvars[t], mu_ps[t], logvar_ps[t])
+        else:
+            x_pred = None
+            skip = None
+            for i in range(1, n_steps + 1):
+                x_j = x[i - 1] if truths[i - 1] else x_pred  # scheduled sampling: gradients flow through the fed-back frame
+                m_j, r_j, a_j = mask[i - 1], states[i - 1], ac[i - 1]
+                m_i, r_i = mask[i], states[i]
+                if cf.last_frame_skip:
+                    skip = None
+                m_in = torch.cat([m_j, m_i], 1) if cf.model_use_future_mask else m_j
+                r_in = (r_j, r_i) if cf.model_use_future_robot_state else r_j
+                hm_in = None
+                if heatmaps is not None:
+                    hm_in = (torch.cat([heatmaps[i - 1], heatmaps[i]], 1) if cf.model_use_future_heatmap
+                             else heatmaps[i - 1])
+                x4, curr_skip, mu, logvar, mu_p, logvar_p = self.model.forward_maps(
+                    x_j, m_in, r_in, hm_in, a_j, True, r_i, skip, zero_mask=m_j if dontcare else None)
+                x_pred = ops.Composite.apply(x4, x_j.contiguous())  # un-blacked x_j (trainer.py:406-407)
+                if i <= cf.n_past:
+                    skip = curr_skip
+                add_losses(x_pred, i, mu, logvar, mu_p, logvar_p)
         # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
         with ops.deferred_wgrad():  # ConvLSTM weight gradients: one time-batched launch per weight
             torch.autograd.backward(roots, seeds)

@@ -135,7 +135,17 @@ def make_trainer(cfg, sd, dev, **extra):
 
 @pytest.mark.parametrize("name,tag,sched", [("train_cfg1_vanilla", "vanilla", False), ("train_cfg1_ra", "ra", False),
                                             ("train_cfg1_ra_sched", "ra", True)])
-def test_train_steps_vs_reference_golden(dev, golden_dir, name, tag, sched):
+@pytest.mark.parametrize("seq", [True, False])
+def test_train_steps_vs_reference_golden(dev, golden_dir, name, tag, sched, seq, monkeypatch):
+    """Three optimiser steps against the reference's own trace.  `seq`: teacher-forced windows take the
+    sequence path (encoder / decoder once over all time steps, per-step BatchNorm groups) or go step by step;
+    the scheduled-sampling case feeds a predicted frame back, which always goes step by step."""
+    from robot_aware_control_amd import trainer as trainer_mod
+    from robot_aware_control_amd.model import SVGConvModel
+    monkeypatch.setattr(trainer_mod, "SEQUENCE_PATH", seq)
+    calls = []
+    orig = SVGConvModel.forward_sequence_maps
+    monkeypatch.setattr(SVGConvModel, "forward_sequence_maps", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
     g = load(golden_dir, name)
     cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, **FLAGSETS[tag])
     tr = make_trainer(cfg, orc.make_weights(cfg, seed=1, randomize_bn_stats=False), dev)
@@ -150,6 +160,7 @@ def test_train_steps_vs_reference_golden(dev, golden_dir, name, tag, sched):
             queue.extend(e)
         losses = tr._train_step(data, use_truth=[True, True, flips[step]] if sched else None)
         assert not queue
+        assert len(calls) == sum(1 for q in range(step + 1) if seq and (not sched or flips[q]))
         for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
             np.testing.assert_allclose(losses[k], float(g[f"step{step}_{k}"]), rtol=1e-4 if step == 0 else 1e-3)
         sd = tr.model.state_dict()
@@ -173,8 +184,11 @@ def test_train_steps_vs_reference_golden(dev, golden_dir, name, tag, sched):
         assert np.mean(dw <= 0.05 * cfg.lr * (1 + 3 * step)) >= 0.9
 
 
-def test_train_step_vs_oracle_g128(dev):
+@pytest.mark.parametrize("seq", [True, False])
+def test_train_step_vs_oracle_g128(dev, seq, monkeypatch):
     """A wider model (g=128, B=4, 3 predicted frames): exercises the split-K and 128x128-tile paths."""
+    from robot_aware_control_amd import trainer as trainer_mod
+    monkeypatch.setattr(trainer_mod, "SEQUENCE_PATH", seq)
     cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=3, lr=1e-4, **FLAGSETS["ra"])
     sd = orc.make_weights(cfg, seed=3, randomize_bn_stats=False)
     data = syn.synth_video(seed=9, T=4, B=4)
