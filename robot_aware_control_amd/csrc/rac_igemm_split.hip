@@ -702,6 +702,227 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------
+// The same kernel for maps LARGER than a tile (W = 16, 32 or 64 and 128 / W rows of one image per tile: the 16x16
+// and 32x32 vgg maps, the 16x16 ConvLSTM maps of a 128x128 model).  The tile's pixels plus `pad` image rows above
+// and below (the halo; zeros outside the image) are staged per channel chunk as (R + 2 pad) * W rows of the padded
+// LDS image, which is one CONTIGUOUS pixel range of the input.  A tap shift is again one wave-uniform byte offset;
+// only the x shift can leave the row (one bit per kernel column and lane selects the zero row), the y shift lands
+// in the halo.  One LDS buffer (up to 257 rows x 3 parts = 61.7 KB, two workgroups per CU), two barriers per
+// channel chunk; weights in fragment order straight into registers, one chunk ahead.
+// ---------------------------------------------------------------------------------------------------------
+template <int NV>  // 16-byte staging vectors per thread and part: ceil((R + 2 pad) * W * 4 / 256)
+__global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {  // see igemm_split_tapinner_kernel
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int m0 = bx * SBM, n0 = by * SBN;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  const int halo = p.pad * p.W;             // pixel rows of halo above (and below) the tile
+  const int nrows = SBM + 2 * halo;         // staged pixel rows; row `nrows` of every plane is the zero row
+  const int plane = (nrows + 1) * BD_ROW;
+  if (tid < 3 * 5) *reinterpret_cast<u32x4*>(lds_raw + (tid / 5) * plane + nrows * BD_ROW + (tid % 5) * 16) =
+      u32x4{0u, 0u, 0u, 0u};
+
+  // staging: vector v = tid + 256 i covers LDS row v / 4 (input pixel m0 - halo + row), 16-byte chunk v % 4
+  const int y_tile = (m0 % p.HW) / p.W;     // first image row of the tile
+  int s_off[NV];                            // LDS byte offset, or -1: nothing to stage
+  bool s_ok[NV];                            // inside the image (else zeros)
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i;
+    const int row = v >> 2;
+    s_off[i] = row < nrows ? row * BD_ROW + (v & 3) * 16 : -1;
+    const int y = y_tile - p.pad + row / p.W;
+    s_ok[i] = (row < nrows) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
+  }
+  // fragment rows of this lane: unshifted LDS byte offset, and one bit per kernel column for the x shift
+  int abase[4];
+  unsigned amask[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = t * 32 + li;
+    const int x = r % p.W;
+    abase[t] = (halo + r) * BD_ROW + lh * 16;
+    unsigned mk = 0;
+    for (int kx = 0; kx < p.ks; ++kx) mk |= ((unsigned)(x + kx - p.pad) < (unsigned)p.W) ? (1u << kx) : 0u;
+    amask[t] = mk;
+  }
+  const int zrow = nrows * BD_ROW + lh * 16;
+  const int ntile = (n0 >> 5) + wid;
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part)
+    b_off[part] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u +
+                  part * w_pstride;
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+        rb[part * 2 + s] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + s * 1024u), so, 0));
+  };
+  u32x4 ra[3 * NV];
+  auto issue_a = [&](int cc) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = (first ? c0 : c0 - p.a_split) + (tid & 3) * 8;
+    const long aps = first ? p.a0_ps : p.a1_ps;
+    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int pix = m0 - halo + ((tid + 256 * i) >> 2);
+      const unsigned oa = (unsigned)(pix * Cs + cl) * 2u;
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        ra[part * NV + i] = ld16(a_rsrc, s_ok[i] ? oa + (unsigned)(part * aps * 2) : OOBS);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (s_off[i] >= 0) *reinterpret_cast<u32x4*>(lds_raw + part * plane + s_off[i]) = ra[part * NV + i];
+  };
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    bool fresh = true;
+    u32x4 b0[6], b1[6];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    store_a();
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
+      fresh = false;
+      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * BD_ROW;
+      const unsigned bit = 1u << kx;
+      int aoff[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) aoff[t] = (amask[t] & bit) ? abase[t] + shift : zrow;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 fa[4][3], fb[3];
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[part] = __builtin_bit_cast(bf16x8, rb[part * 2 + s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            fa[t][part] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + aoff[t] + part * plane + s * 32));
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          f32x16 c = acc[mt];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[0], c, 0, 0, 0);
+          acc[mt] = c;
+        }
+      }
+      if (last_tap && more) {
+        __syncthreads();  // every wave has finished this channel chunk's fragment reads
+        store_a();
+        __syncthreads();
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 2) {
+      load_b(b1, kc + 1);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 2);
+        step(b1, kc + 1);
+      }
+    }
+  }
+
+  // ---- epilogue (same semantics as rac_conv2d FWD): this wave owns columns n0 + 32 wid .. + 31 ----
+  const bool slab = p.split_k > 1;
+  const int n = n0 + wid * 32 + li;
+  const bool nok = n < p.N;
+  float bias = 0.f, sc = 1.f, sh = 0.f;
+  if (!slab && nok) {
+    if (p.bias) bias = p.bias[n];
+    if (p.scale) {
+      sc = p.scale[n];
+      sh = p.shift[n];
+    }
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M || !nok) continue;
+      float v = acc[mt][r];
+      if (slab) {
+        p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+        continue;
+      }
+      v += bias;
+      s1 += v;
+      s2 += v * v;
+      v = v * sc + sh;
+      if (p.act == RAC_ACT_LEAKY02)
+        v = v > 0.f ? v : 0.2f * v;
+      else if (p.act == RAC_ACT_SIGMOID)
+        v = sigmoid_acc(v);
+      p.out0[(long)m * p.N + n] = v;
+    }
+  }
+  if (p.stats && !slab) {
+    s1 += __shfl_xor(s1, 32);
+    s2 += __shfl_xor(s2, 32);
+    if (lh == 0 && nok) {
+      double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+      atomicAdd(sg + n, (double)s1);
+      atomicAdd(sg + p.N + n, (double)s2);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient on the split-precision pipe.
 //   dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]
 // The bf16 MFMA wants 8 consecutive k (= pixels) per lane for both operands, so both are consumed TRANSPOSED:
@@ -1246,12 +1467,50 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   p.w_chunk_major = 0;
   RAC_REQUIRE(w_layout >= 0 && w_layout <= 2, "rac_conv2d_fwd_split: w_layout must be 0, 1 or 2");
   const bool w_chunk_major = w_layout == 1;
-  RAC_REQUIRE(w_layout == 0 || (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1),
+  RAC_REQUIRE(w_layout == 0 || (w_layout == 2 && p.HW > SBM) ||
+                  (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1),
               "rac_conv2d_fwd_split: chunk-major / fragment-order weights need Cin % 32 == 0, k > 1 and whole images "
               "per 128-pixel tile");
   // few M-tiles (training batch): the launch is bound by weight re-reads across XCDs unless they are grouped
   static const char* xg = getenv("RAC_XCD_GROUP");
   p.xcd_group = (xg ? atoi(xg) != 0 : (int)grid.x <= 32) && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+  if (w_layout == 2 && p.HW > SBM) {
+    // maps larger than a tile: whole image rows per tile plus a halo (igemm_split_bdirect_rows_kernel)
+    RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5 && a->Cin % SBK == 0 && p.taps > 1 && SBM % a->W == 0 &&
+                    a->H % (SBM / a->W) == 0,
+                "rac_conv2d_fwd_split: fragment-order weights on large maps need W dividing 128, H a multiple of "
+                "128 / W, channel counts % 32 == 0 and 1 < k <= 5");
+    RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+    const int nrows = SBM + 2 * p.pad * a->W;
+    const int nv = cdiv(nrows * 4, 256);
+    RAC_REQUIRE(nv >= 2 && nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
+    const size_t lds_rows = (size_t)3 * (nrows + 1) * BD_ROW;
+    static bool rows_attr = false;
+    if (!rows_attr) {
+      const int max_lds = 3 * (256 + 1) * BD_ROW;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<3>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<4>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      rows_attr = true;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nv == 2)
+      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<2>, grid, dim3(256), lds_rows, st, p);
+    else if (nv == 3)
+      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<3>, grid, dim3(256), lds_rows, st, p);
+    else
+      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<4>, grid, dim3(256), lds_rows, st, p);
+    return check_launch("rac_conv2d_fwd_split(weights direct, image rows)");
+  }
   if (w_layout == 2) {
     RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,
                 "rac_conv2d_fwd_split: fragment-order weights need Cout % 32 == 0 and k <= 5");

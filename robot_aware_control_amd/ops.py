@@ -287,6 +287,8 @@ TAPINNER_MIN_TILES = int(os.environ.get("RAC_TAPINNER_MIN_TILES", "0"))
 
 # weight layout 2 (fragment order, weights loaded straight into MFMA registers) instead of 1 where Cout allows
 W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
+# ... also on maps larger than a tile (16x16 / 32x32): the image-rows + halo variant of that kernel
+ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
 
 
 def tapinner_ok(H: int, W: int, Cin: int, k: int, M: int, N: int) -> bool:
@@ -296,9 +298,13 @@ def tapinner_ok(H: int, W: int, Cin: int, k: int, M: int, N: int) -> bool:
 
 def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int:
     """Weight layout (w_layout of rac_conv2d_fwd_split) for a conv of this shape."""
+    direct = W_DIRECT and N % 32 == 0 and Cin % 32 == 0 and 1 < k <= 5
+    if H * W > 128:  # maps larger than a tile: whole image rows per tile + halo, fragment-order weights only
+        rows_ok = 128 % W == 0 and H % (128 // W) == 0 and (128 + 2 * (k // 2) * W) * 4 <= 1024
+        return 2 if (direct and ROWS_KERNEL and rows_ok) else 0
     if not tapinner_ok(H, W, Cin, k, M, N):
         return 0
-    return 2 if (W_DIRECT and N % 32 == 0) else 1
+    return 2 if direct else 1
 
 
 _W_LAYOUT_FN = {1: chunk_major, 2: frag_order}

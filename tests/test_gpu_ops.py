@@ -378,6 +378,38 @@ def test_weight_frag_split(dev, shape):
     assert torch.equal(pb.float().sum(0), x[:4096])
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 96, 3), (1, 32, 32, 64, 0, 128, 3), (3, 16, 16, 32, 0, 64, 5),
+                                  (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3)])
+def test_conv_split_rows_kernel(dev, case):
+    """Weights-direct kernel on maps larger than a tile (whole image rows per tile + halo) against fp64, forward and
+    data gradient, and bit-identical sums with the tap-outer kernel's exactness test (small integers)."""
+    from robot_aware_control_amd import ops
+    B, H, W, C0, C1, Cout, k = case
+    Cin = C0 + C1
+    assert ops.split_weight_layout(H, W, Cin, k, B * H * W, Cout) == 2 and H * W > 128
+    g = np.random.Generator(np.random.Philox(key=[11, 9]))
+    xi = torch.from_numpy(g.integers(-3, 4, (B, Cin, H, W)).astype(np.float32))
+    wi = torch.from_numpy(g.integers(-3, 4, (Cout, Cin, k, k)).astype(np.float32))
+    x0, x1 = to_map(xi[:, :C0], dev), (to_map(xi[:, C0:], dev) if C1 else None)
+    y = ops.conv_forward_split(x0, x1, cl_weight(wi).to(dev))
+    assert torch.equal(from_map(y), F.conv2d(xi, wi, None, 1, k // 2))
+    x = rnd(1, B, Cin, H, W)
+    w = rnd(2, Cout, Cin, k, k) * (1.0 / np.sqrt(Cin * k * k))
+    b = rnd(3, Cout, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), 1, k // 2)
+    x0, x1 = to_map(x[:, :C0], dev), (to_map(x[:, C0:], dev) if C1 else None)
+    wd, bd = cl_weight(w).to(dev), b.to(dev)
+    e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
+    e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
+    assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)
+    gy = rnd(4, B, Cout, H, W)
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), None, 1, k // 2).backward(gy.double())
+    d0, d1 = ops.conv_dgrad_split(to_map(gy, dev), wd, C0, C1)
+    got = torch.cat([from_map(d0)] + ([from_map(d1)] if C1 else []), 1)
+    assert relerr(got, xr.grad) < 2e-6
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3)])
 @pytest.mark.parametrize("direct", [False, True])
