@@ -211,6 +211,32 @@ def test_train_step_vs_oracle_g128(dev, seq, monkeypatch):
     assert dot / np.sqrt(na * nb) > GRAD_COS
 
 
+def test_train_step_128x128_vs_oracle(dev):
+    """BASELINE configs[4] geometry (128x128 frames -> 16x16 latent maps, larger than a GEMM tile) at plumbing
+    width: the ConvLSTM gate convs take the image-rows + halo kernel, forward and data gradient."""
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, n_past=1, n_future=2, lr=1e-4, image_height=128, image_width=128,
+                  **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=4, randomize_bn_stats=False)
+    data = syn.synth_video(seed=12, T=3, B=2, H=128, W=128)
+    eps = syn.synth_eps(seed=13, steps=2, B=2, z=16, h=16, w=16)
+    ts = orc.TrainState.create(cfg, sd)
+    ref = orc.train_step(ts, data, eps, None, do_update=False)
+    tr = make_trainer(cfg, sd, dev)
+    queue = [e for pair in eps for e in pair]
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    tr.optimizer.step = lambda: None  # compare raw gradients
+    got = tr._train_step(data)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4)
+    grads = dict(tr.model.named_parameters())
+    dot = na = nb = 0.0
+    for k in ts.param_keys:
+        a, b = grads[k].grad.double().cpu(), ts.sd[k].grad.double()
+        assert float((a - b).norm() / (b.norm() + 1e-20)) < GRAD_TOL, k
+        dot, na, nb = dot + float((a * b).sum()), na + float((a * a).sum()), nb + float((b * b).sum())
+    assert dot / np.sqrt(na * nb) > GRAD_COS
+
+
 def cem_setup(tag, dev):
     ra = tag == "ra"
     cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=5, sample_mean=True,
