@@ -710,8 +710,13 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
 // in the halo.  One LDS buffer (up to 257 rows x 3 parts = 61.7 KB, two workgroups per CU), two barriers per
 // channel chunk; weights in fragment order straight into registers, one chunk ahead.
 // ---------------------------------------------------------------------------------------------------------
-template <int NV>  // 16-byte staging vectors per thread and part: ceil((R + 2 pad) * W * 4 / 256)
+// NV = 16-byte staging vectors per thread and part: ceil((R + 2 pad) * W * 4 / 256).
+// TN = 32-column groups per workgroup: 4 (128 columns, waves 1 x 4, each all 128 rows) or 2 (64 columns for the
+// 64-channel layers: waves 2 x 2, each 64 rows x 32 columns).
+template <int NV, int TN>
 __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP p) {
+  constexpr int MT = TN;           // 32-row blocks per wave
+  constexpr int BNW = TN * 32;     // columns per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -727,7 +732,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
     by = grp % nt;
     bz = grp / nt;
   }
-  const int m0 = bx * SBM, n0 = by * SBN;
+  const int wn = wid % TN, wm = wid / TN;
+  const int m0 = bx * SBM, n0 = by * BNW;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   const int halo = p.pad * p.W;             // pixel rows of halo above (and below) the tile
@@ -749,11 +755,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
     s_ok[i] = (row < nrows) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
   }
   // fragment rows of this lane: unshifted LDS byte offset, and one bit per kernel column for the x shift
-  int abase[4];
-  unsigned amask[4];
+  int abase[MT];
+  unsigned amask[MT];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int r = t * 32 + li;
+  for (int t = 0; t < MT; ++t) {
+    const int r = (wm * MT + t) * 32 + li;
     const int x = r % p.W;
     abase[t] = (halo + r) * BD_ROW + lh * 16;
     unsigned mk = 0;
@@ -761,7 +767,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
     amask[t] = mk;
   }
   const int zrow = nrows * BD_ROW + lh * 16;
-  const int ntile = (n0 >> 5) + wid;
+  const int ntile = (n0 >> 5) + wn;
   const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
   unsigned b_off[3];
@@ -803,9 +809,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
         if (s_off[i] >= 0) *reinterpret_cast<u32x4*>(lds_raw + part * plane + s_off[i]) = ra[part * NV + i];
   };
 
-  f32x16 acc[4];
+  f32x16 acc[MT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -827,22 +833,22 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
       fresh = false;
       const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * BD_ROW;
       const unsigned bit = 1u << kx;
-      int aoff[4];
+      int aoff[MT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) aoff[t] = (amask[t] & bit) ? abase[t] + shift : zrow;
+      for (int t = 0; t < MT; ++t) aoff[t] = (amask[t] & bit) ? abase[t] + shift : zrow;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        bf16x8 fa[4][3], fb[3];
+        bf16x8 fa[MT][3], fb[3];
 #pragma unroll
         for (int part = 0; part < 3; ++part) fb[part] = __builtin_bit_cast(bf16x8, rb[part * 2 + s]);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < MT; ++t)
 #pragma unroll
           for (int part = 0; part < 3; ++part)
             fa[t][part] = __builtin_bit_cast(
                 bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + aoff[t] + part * plane + s * 32));
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           f32x16 c = acc[mt];
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[0], c, 0, 0, 0);
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[1], c, 0, 0, 0);
@@ -875,9 +881,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
     }
   }
 
-  // ---- epilogue (same semantics as rac_conv2d FWD): this wave owns columns n0 + 32 wid .. + 31 ----
+  // ---- epilogue (same semantics as rac_conv2d FWD): this wave owns columns n0 + 32 wn .. + 31 ----
   const bool slab = p.split_k > 1;
-  const int n = n0 + wid * 32 + li;
+  const int n = n0 + wn * 32 + li;
   const bool nok = n < p.N;
   float bias = 0.f, sc = 1.f, sh = 0.f;
   if (!slab && nok) {
@@ -889,10 +895,10 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
   }
   float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + (wm * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= p.M || !nok) continue;
       float v = acc[mt][r];
       if (slab) {
@@ -1486,29 +1492,27 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
     RAC_REQUIRE(nv >= 2 && nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
     const size_t lds_rows = (size_t)3 * (nrows + 1) * BD_ROW;
     static bool rows_attr = false;
+    typedef void (*rows_fn)(SplitP);
+    static const rows_fn fns[2][3] = {
+        {igemm_split_bdirect_rows_kernel<2, 4>, igemm_split_bdirect_rows_kernel<3, 4>, igemm_split_bdirect_rows_kernel<4, 4>},
+        {igemm_split_bdirect_rows_kernel<2, 2>, igemm_split_bdirect_rows_kernel<3, 2>, igemm_split_bdirect_rows_kernel<4, 2>}};
     if (!rows_attr) {
       const int max_lds = 3 * (256 + 1) * BD_ROW;
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<3>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-      if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect_rows_kernel<4>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-      if (e != hipSuccess) {
-        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-        return RAC_ELAUNCH;
+      for (int i = 0; i < 6; ++i) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i / 3][i % 3]),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return RAC_ELAUNCH;
+        }
       }
       rows_attr = true;
     }
-    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nv == 2)
-      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<2>, grid, dim3(256), lds_rows, st, p);
-    else if (nv == 3)
-      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<3>, grid, dim3(256), lds_rows, st, p);
-    else
-      hipLaunchKernelGGL(igemm_split_bdirect_rows_kernel<4>, grid, dim3(256), lds_rows, st, p);
+    // 64-channel layers: 64-column workgroups (waves 2 x 2) instead of half-empty 128-column ones
+    const int narrow = p.N <= 64 ? 1 : 0;
+    if (narrow) grid.y = cdiv(p.N, 64);
+    p.xcd_group = p.xcd_group && (grid.y * grid.z) % 8 == 0;
+    hipLaunchKernelGGL(fns[narrow][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(weights direct, image rows)");
   }
   if (w_layout == 2) {

@@ -289,6 +289,9 @@ TAPINNER_MIN_TILES = int(os.environ.get("RAC_TAPINNER_MIN_TILES", "0"))
 W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
 # ... also on maps larger than a tile (16x16 / 32x32): the image-rows + halo variant of that kernel
 ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
+# narrowest layer (output channels) of the frozen model that runs split-precision
+SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
+SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
 
 
 def tapinner_ok(H: int, W: int, Cin: int, k: int, M: int, N: int) -> bool:
@@ -610,7 +613,7 @@ class VggLayer(torch.autograd.Function):
         if not training:
             scale, shift = folded
             c0 = x0.shape[3]
-            if (SPLIT_GEMM and Cout >= 128 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
+            if (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT and weight.shape[1] % 8 == 0 and c0 % 8 == 0
                     and (x1 is None or c0 % 32 == 0)):
                 y = conv_forward_split(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
             else:
@@ -622,7 +625,8 @@ class VggLayer(torch.autograd.Function):
         stats = zeros64((G, 2, Cout), dev)
         c0 = x0.shape[3]
         # "1": every wide layer; "latent": only the layers whose maps fit the tap-inner kernels (H*W divides 128)
-        ctx.split = (SPLIT_VGG_TRAIN != "0" and Cout >= 128 and c0 >= 64 and weight.shape[1] % 8 == 0 and c0 % 8 == 0
+        ctx.split = (SPLIT_VGG_TRAIN != "0" and Cout >= SPLIT_MIN_COUT_TRAIN and c0 >= 64 and weight.shape[1] % 8 == 0
+                     and c0 % 8 == 0
                      and (x1 is None or c0 % 128 == 0) and x0.shape[2] % 8 == 0
                      and (SPLIT_VGG_TRAIN == "1" or (weight.shape[1] % 32 == 0 and Cout % 32 == 0
                                                      and 128 % (x0.shape[1] * x0.shape[2]) == 0)))

@@ -379,7 +379,7 @@ def test_weight_frag_split(dev, shape):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 96, 3), (1, 32, 32, 64, 0, 128, 3), (3, 16, 16, 32, 0, 64, 5),
-                                  (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3)])
+                                  (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3), (1, 64, 64, 64, 64, 64, 3)])
 def test_conv_split_rows_kernel(dev, case):
     """Weights-direct kernel on maps larger than a tile (whole image rows per tile + halo) against fp64, forward and
     data gradient, and bit-identical sums with the tap-outer kernel's exactness test (small integers)."""
