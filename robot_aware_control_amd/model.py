@@ -426,18 +426,22 @@ class SVGConvModel(nn.Module):
             else:
                 r = robot.contiguous()
         p = self.prior_input_conv
-        prior_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, None), None, p.weight, p.bias, ACT_NONE)
+        frozen = not torch.is_grad_enabled()  # no tape: the input convs may take the split-precision pipe
+        prior_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, None, frozen), None, p.weight, p.bias,
+                                      ACT_NONE, frozen)
         z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean)
         z = mu_p if sample_mean else z_p
         mu = logvar = None
         if posterior:
             q = self.posterior_input_conv
-            post_x = ops.TileCat.apply(next_robot.contiguous(), None, None, h, None) if cf.model_use_robot_state else h
-            post_in = ops.ConvBias.apply(post_x, None, q.weight, q.bias, ACT_NONE)
+            post_x = (ops.TileCat.apply(next_robot.contiguous(), None, None, h, None, frozen)
+                      if cf.model_use_robot_state else h)
+            post_in = ops.ConvBias.apply(post_x, None, q.weight, q.bias, ACT_NONE, frozen)
             z_t, mu, logvar = self.posterior(post_in, self._eps)
             if not force_use_prior:
                 z = z_t
         f = self.frame_pred_input_conv
-        frame_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, z), None, f.weight, f.bias, ACT_NONE)
+        frame_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, z, frozen), None, f.weight, f.bias, ACT_NONE,
+                                      frozen)
         h_pred = self.frame_predictor(frame_in)
         return h_pred, mu, logvar, mu_p, logvar_p

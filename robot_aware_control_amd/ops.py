@@ -79,15 +79,17 @@ def _derived(weight: torch.Tensor, slot: str, build):
     return val
 
 
-def padded_weight(weight: torch.Tensor) -> torch.Tensor:
-    """Zero-padded (Cout, Cin + pad, k, k) channels_last copy of `weight`, cached until the parameter changes."""
+def padded_weight(weight: torch.Tensor, cp: Optional[int] = None) -> torch.Tensor:
+    """Zero-padded (Cout, cp, k, k) channels_last copy of `weight` (cp defaults to Cin rounded up to a multiple of 4),
+    cached until the parameter changes."""
+    co, ci, k, _ = weight.shape
+    cp = ci + pad4(ci) if cp is None else cp
+
     def build():
-        co, ci, k, _ = weight.shape
-        cp = ci + pad4(ci)
         wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
         call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
         return wp
-    return _derived(weight, "_rac_padded", build)
+    return _derived(weight, f"_rac_padded{cp}", build)
 
 
 def wgrad_padded_acc(dy, x0, weight):
@@ -291,6 +293,8 @@ W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
 ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
 # narrowest layer (output channels) of the frozen model that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
+# frozen model: pad the input convs' concatenated input to 32-channel chunks (split-precision pipe)
+PAD32_INPUT_CONVS = os.environ.get("RAC_PAD32_INPUT_CONVS", "1") == "1"
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
 
 
@@ -528,8 +532,13 @@ class ConvBias(torch.autograd.Function):
     carry the zero pad channels (see `padded_weight`)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, weight, bias, act):
-        padded = weight.shape[1] % 4 != 0 and x1 is None and x0.shape[3] == weight.shape[1] + pad4(weight.shape[1])
+    def forward(ctx, x0, x1, weight, bias, act, frozen=False):
+        ci = weight.shape[1]
+        # `frozen` = not torch.is_grad_enabled() at the call site (grad mode is always off inside forward())
+        if frozen and x1 is None and x0.shape[3] == ci + (-ci) % 32 and x0.shape[3] != ci + pad4(ci) and act == ACT_NONE:
+            # frozen model: TileCat padded the input to whole 32-channel chunks so that the conv runs split-precision
+            return conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias)
+        padded = ci % 4 != 0 and x1 is None and x0.shape[3] == ci + pad4(ci)
         w = padded_weight(weight) if padded else weight
         y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
         ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
@@ -556,7 +565,7 @@ class ConvBias(torch.autograd.Function):
                 conv_wgrad_acc(dy, x0, x1, weight)
         if bias is not None and bias.requires_grad:
             bias_grad_acc(dy, bias)
-        return dx0, dx1, None, None, None
+        return dx0, dx1, None, None, None, None
 
 
 class ConvTHead(torch.autograd.Function):
@@ -717,7 +726,7 @@ class TileCat(torch.autograd.Function):
     (dynamics.py:591-607,634-640).  Gradients flow to the maps only (actions / robot states are data)."""
 
     @staticmethod
-    def forward(ctx, v0, v1, v2, m0, m1):
+    def forward(ctx, v0, v1, v2, m0, m1, frozen=False):
         B, H, W, c0 = m0.shape
         vs = [v for v in (v0, v1, v2) if v is not None]
         vs += [None] * (3 - len(vs))
@@ -725,6 +734,8 @@ class TileCat(torch.autograd.Function):
         c1 = m1.shape[3] if m1 is not None else 0
         ct = sum(ns) + c0 + c1
         pad = pad4(ct)
+        if frozen and SPLIT_GEMM and PAD32_INPUT_CONVS and ct >= 128 and H * W <= 128:
+            pad = (-ct) % 32  # frozen model: whole 32-channel chunks, the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
              ptr(out), B, H * W, stream_ptr())
@@ -744,7 +755,7 @@ class TileCat(torch.autograd.Function):
         if c1 and ctx.needs_input_grad[4]:
             dm1 = torch.empty((B, H, W, c1), device=dout.device, dtype=torch.float32)
             call("rac_slice_channels", ptr(dout), Ct, nv + c0, c1, ptr(dm1), M, stream_ptr())
-        return None, None, None, dm0, dm1
+        return None, None, None, dm0, dm1, None
 
 
 class LstmCell(torch.autograd.Function):
