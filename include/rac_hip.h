@@ -108,7 +108,10 @@ int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t
  *   1 = chunk-major [Cout][Cin/32][k*k][32]: per-tap weight reads sequential in memory, staged through LDS;
  *   2 = fragment order [Cout/32][Cin/32][k*k][s 2][lane 64][8] with lane = 32 h + (co mod 32) and
  *       ci = 32 chunk + 16 s + 8 h + j (needs Cout % 32 == 0): the weight operand of every MFMA is one coalesced
- *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps). */
+ *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps).  With this layout a0 / a1
+ *       are plain fp32 [pixels][C] maps (a0_part_stride = a1_part_stride = 0): the kernel splits them on the way
+ *       into LDS, no rac_split_bf16x3 pass.  Also serves maps larger than a tile (H*W > 128) when W divides 128
+ *       and H is a multiple of 128 / W (image rows + halo per tile), and N <= 64 (64-column workgroups). */
 /* Transposed bf16 parts for the split-precision weight gradient:
  *   out[dxi][k][c][p] = k-th part of (0 <= x(p)+dx < W ? x[p+dx][c] : 0),  dx = dxi - ndx/2,
  * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy).

@@ -47,6 +47,33 @@ __device__ __forceinline__ u32x4 ld16(rsrc_t r, unsigned voff) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
 }
 
+__device__ __forceinline__ void split3(float a, unsigned short& q1, unsigned short& q2, unsigned short& q3) {
+  const __bf16 p1 = (__bf16)a;
+  const float r1 = a - (float)p1;
+  const __bf16 p2 = (__bf16)r1;
+  const __bf16 p3 = (__bf16)(r1 - (float)p2);
+  q1 = __builtin_bit_cast(unsigned short, p1);
+  q2 = __builtin_bit_cast(unsigned short, p2);
+  q3 = __builtin_bit_cast(unsigned short, p3);
+}
+
+// eight fp32 values (two 16-byte vectors) -> their three bf16 parts, packed as the 16-byte operand vectors
+__device__ __forceinline__ void split8(u32x4 lo, u32x4 hi, u32x4 (&q)[3]) {
+  const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  unsigned short a[3][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) split3(__builtin_bit_cast(float, w[j]), a[0][j], a[1][j], a[2][j]);
+#pragma unroll
+  for (int part = 0; part < 3; ++part) {
+    u32x4 o;
+    o.x = a[part][0] | ((unsigned)a[part][1] << 16);
+    o.y = a[part][2] | ((unsigned)a[part][3] << 16);
+    o.z = a[part][4] | ((unsigned)a[part][5] << 16);
+    o.w = a[part][6] | ((unsigned)a[part][7] << 16);
+    q[part] = o;
+  }
+}
+
 // LDS image of one operand: [part 3][row 128][4 chunks of 16 B], chunk index XOR-swizzled by (row >> 2) & 3 so that
 // the 16 lanes of a ds_read_b128 group (16 consecutive rows, same logical chunk) hit 16 distinct 4-bank slots.
 __device__ __forceinline__ int lds_off(int part, int row, int chunk) {  // in 16-byte units
@@ -548,29 +575,32 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
         rb[part * 2 + s] = __builtin_bit_cast(
             u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + s * 1024u), so, 0));
   };
-  u32x4 ra[6];
+  // activations are read as fp32 [pixel][channel] and split into their bf16 parts on the way into LDS (once per
+  // channel chunk = once per k*k taps: ~130 VALU instructions against 1200 MFMAs), so no split pass precedes the conv
+  u32x4 ra[4];
   auto issue_a = [&](int cc) {  // activation chunk `cc`, unshifted pixels of this tile
     const int c0 = cc * SBK;
     const bool first = c0 < p.a_split;
     const int Cs = first ? p.a_split : p.Cin - p.a_split;
     const int cl = (first ? c0 : c0 - p.a_split) + schunk * 8;
-    const long aps = first ? p.a0_ps : p.a1_ps;
-    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+    const rsrc_t a_rsrc = mk_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned oa = (unsigned)((m0 + srow + 64 * i) * Cs + cl) * 2u;
-#pragma unroll
-      for (int part = 0; part < 3; ++part)
-        ra[part * 2 + i] = ld16(a_rsrc, a_ok[i] ? oa + (unsigned)(part * aps * 2) : OOBS);
+      const unsigned oa = (unsigned)((m0 + srow + 64 * i) * Cs + cl) * 4u;
+      ra[2 * i] = ld16(a_rsrc, a_ok[i] ? oa : OOBS);
+      ra[2 * i + 1] = ld16(a_rsrc, a_ok[i] ? oa + 16u : OOBS);
     }
   };
   auto store_a = [&](int buf) {
 #pragma unroll
-    for (int part = 0; part < 3; ++part)
+    for (int i = 0; i < 2; ++i) {
+      u32x4 q[3];
+      split8(ra[2 * i], ra[2 * i + 1], q);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int part = 0; part < 3; ++part)
         *reinterpret_cast<u32x4*>(lds_raw + buf * BD_ABUF + part * BD_PLANE + (srow + 64 * i) * BD_ROW + schunk * 16) =
-            ra[part * 2 + i];
+            q[part];
+    }
   };
 
   f32x16 acc[4];
@@ -784,29 +814,30 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
         rb[part * 2 + s] = __builtin_bit_cast(
             u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + s * 1024u), so, 0));
   };
-  u32x4 ra[3 * NV];
+  u32x4 ra[2 * NV];  // fp32 activations, split into their bf16 parts on the way into LDS (see the kernel above)
   auto issue_a = [&](int cc) {
     const int c0 = cc * SBK;
     const bool first = c0 < p.a_split;
     const int Cs = first ? p.a_split : p.Cin - p.a_split;
     const int cl = (first ? c0 : c0 - p.a_split) + (tid & 3) * 8;
-    const long aps = first ? p.a0_ps : p.a1_ps;
-    const rsrc_t a_rsrc = mk_rsrc(first ? p.a0 : p.a1, (unsigned)(3 * aps * 2));
+    const rsrc_t a_rsrc = mk_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int pix = m0 - halo + ((tid + 256 * i) >> 2);
-      const unsigned oa = (unsigned)(pix * Cs + cl) * 2u;
-#pragma unroll
-      for (int part = 0; part < 3; ++part)
-        ra[part * NV + i] = ld16(a_rsrc, s_ok[i] ? oa + (unsigned)(part * aps * 2) : OOBS);
+      const unsigned oa = (unsigned)(pix * Cs + cl) * 4u;
+      ra[2 * i] = ld16(a_rsrc, s_ok[i] ? oa : OOBS);
+      ra[2 * i + 1] = ld16(a_rsrc, s_ok[i] ? oa + 16u : OOBS);
     }
   };
   auto store_a = [&]() {
 #pragma unroll
-    for (int part = 0; part < 3; ++part)
+    for (int i = 0; i < NV; ++i) {
+      if (s_off[i] < 0) continue;
+      u32x4 q[3];
+      split8(ra[2 * i], ra[2 * i + 1], q);
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (s_off[i] >= 0) *reinterpret_cast<u32x4*>(lds_raw + part * plane + s_off[i]) = ra[part * NV + i];
+      for (int part = 0; part < 3; ++part) *reinterpret_cast<u32x4*>(lds_raw + part * plane + s_off[i]) = q[part];
+    }
   };
 
   f32x16 acc[MT];
@@ -1306,16 +1337,6 @@ __global__ void transpose_split_frag_kernel(const float* in, unsigned short* out
   }
 }
 
-__device__ __forceinline__ void split3(float a, unsigned short& q1, unsigned short& q2, unsigned short& q3) {
-  const __bf16 p1 = (__bf16)a;
-  const float r1 = a - (float)p1;
-  const __bf16 p2 = (__bf16)r1;
-  const __bf16 p3 = (__bf16)(r1 - (float)p2);
-  q1 = __builtin_bit_cast(unsigned short, p1);
-  q2 = __builtin_bit_cast(unsigned short, p2);
-  q3 = __builtin_bit_cast(unsigned short, p3);
-}
-
 __global__ void split_bf16x3_kernel(const float* x, unsigned short* parts, long n, long ps) {
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     unsigned short q1, q2, q3;
@@ -1448,11 +1469,18 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   RAC_REQUIRE(a->Cin % 8 == 0 && p.a_split % 8 == 0, "rac_conv2d_fwd_split: channel counts must be multiples of 8");
   RAC_REQUIRE(p.a_split == a->Cin || p.a_split % SBK == 0, "rac_conv2d_fwd_split: a_split must be a multiple of 32");
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
-  RAC_REQUIRE(a0_ps >= (long)p.P * p.a_split && w_ps >= (long)p.Cout * p.taps * p.Cin &&
-                  (p.a_split == a->Cin || a1_ps >= (long)p.P * (a->Cin - p.a_split)),
-              "rac_conv2d_fwd_split: part strides too small");
-  RAC_REQUIRE(3 * a0_ps * 2 < 0xFFFFFF00L && 3 * w_ps * 2 < 0xFFFFFF00L && 3 * a1_ps * 2 < 0xFFFFFF00L,
-              "rac_conv2d_fwd_split: operand larger than 4 GiB");
+  if (w_layout == 2) {  // fragment-order weights: the activations are fp32 [pixel][channel], split inside the kernel
+    RAC_REQUIRE(a0_ps == 0 && a1_ps == 0, "rac_conv2d_fwd_split: w_layout 2 takes fp32 activations (part strides 0)");
+    RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
+                "rac_conv2d_fwd_split: operand larger than 4 GiB");
+  } else {
+    RAC_REQUIRE(a0_ps >= (long)p.P * p.a_split && (p.a_split == a->Cin || a1_ps >= (long)p.P * (a->Cin - p.a_split)),
+                "rac_conv2d_fwd_split: part strides too small");
+    RAC_REQUIRE(3 * a0_ps * 2 < 0xFFFFFF00L && 3 * a1_ps * 2 < 0xFFFFFF00L,
+                "rac_conv2d_fwd_split: operand larger than 4 GiB");
+  }
+  RAC_REQUIRE(w_ps >= (long)p.Cout * p.taps * p.Cin, "rac_conv2d_fwd_split: weight part stride too small");
+  RAC_REQUIRE(3 * w_ps * 2 < 0xFFFFFF00L, "rac_conv2d_fwd_split: operand larger than 4 GiB");
   RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.N, "rac_conv2d_fwd_split: slab_stride too small");
   p.cchunks = cdiv(a->Cin, SBK);
   p.nchunks = p.taps * p.cchunks;

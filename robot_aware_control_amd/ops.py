@@ -340,8 +340,9 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    call("rac_conv2d_fwd_split", C.byref(args), p0.shape[1], p1.shape[1] if p1 is not None else 0, pw.shape[1],
-         w_layout, stream_ptr())
+    a0_ps = 0 if w_layout == 2 else p0.shape[1]  # layout 2: p0 / p1 are the fp32 maps themselves
+    a1_ps = 0 if (w_layout == 2 or p1 is None) else p1.shape[1]
+    call("rac_conv2d_fwd_split", C.byref(args), a0_ps, a1_ps, pw.shape[1], w_layout, stream_ptr())
     if timed:
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
@@ -358,9 +359,12 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     Cout, Cin, k, _ = weight.shape
     assert Cin == C0 + C1
     M = B * H * W
-    p0 = split_parts(x0)
-    p1 = split_parts(x1) if x1 is not None else None
     cm = split_weight_layout(H, W, Cin, k, M, Cout)
+    if cm == 2:  # the weights-direct kernels read fp32 activations and split them on the way into LDS
+        p0, p1 = x0.contiguous(), (x1.contiguous() if x1 is not None else None)
+    else:
+        p0 = split_parts(x0)
+        p1 = split_parts(x1) if x1 is not None else None
     if cm == 2:
         pw = _derived(weight, "_rac_split_l2", lambda: weight_frag_parts(weight))
     elif cm:
@@ -412,7 +416,7 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
                       lambda: split_parts(_W_LAYOUT_FN[cm](transposed_weight(weight))))  # (Cin, Cout, k, k)
     else:
         pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(transposed_weight(weight))))
-    pd = split_parts(dy)
+    pd = dy.contiguous() if cm == 2 else split_parts(dy)  # layout 2: fp32 activations, split inside the kernel
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
     _split_launch(pd, None, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout, split_k=split,

@@ -55,18 +55,20 @@ if mode == "fwd" and os.environ.get("RAC_BENCH_SPLIT"):
     print(f"fwd-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective  "
           f"({flop / ms / 1e9 / 157.3 * 100:.1f}% of the fp32 MFMA peak, {6 * flop / ms / 1e9 / 2500 * 100:.1f}% of bf16 peak x6)", flush=True)
     wl = int(os.environ.get('RAC_W_LAYOUT', '2'))
-    pw = ops.split_parts({1: ops.chunk_major, 2: ops.frag_order}[wl](w)); px = ops.split_parts(x); ph = ops.split_parts(h)
+    pw = ops.split_parts({1: ops.chunk_major, 2: ops.frag_order}[wl](w))
+    px, ph = (x, h) if wl == 2 else (ops.split_parts(x), ops.split_parts(h))  # layout 2 reads fp32 activations
+    aps = 0 if wl == 2 else px.shape[1]
     import ctypes as C
     from robot_aware_control_amd._lib import ConvArgs, call, ptr, stream_ptr
     out = torch.empty((B, H, W, 4 * g), device=dev)
     args = ConvArgs(mode=0, B=B, H=H, W=W, ksize=k, Cin=2 * g, Cout=4 * g, act=0, split_k=1, accumulate=0, a_split=g, o_split=0, slab_stride=0,
                     a0=ptr(px), a1=ptr(ph), w=ptr(pw), out0=ptr(out), out1=None, bias=None, scale=None, shift=None, stats=None)
     for _ in range(2):
-        call("rac_conv2d_fwd_split", C.byref(args), px.shape[1], ph.shape[1], pw.shape[1], wl, stream_ptr())
+        call("rac_conv2d_fwd_split", C.byref(args), aps, aps, pw.shape[1], wl, stream_ptr())
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        call("rac_conv2d_fwd_split", C.byref(args), px.shape[1], ph.shape[1], pw.shape[1], wl, stream_ptr())
+        call("rac_conv2d_fwd_split", C.byref(args), aps, aps, pw.shape[1], wl, stream_ptr())
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
