@@ -128,7 +128,7 @@ def profile_summary(prof, flops_per_pixel_row):
 
 
 def bench_train(args, dev, rank, world, distributed):
-    cf = namespace(dev)
+    cf = namespace(dev, lstm_group_norm=args.group_norm)
     log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
     tr.model.train()
@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--cem-iters", type=int, default=2)
     ap.add_argument("--cem-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--group-norm", action="store_true",
+                    help="train workload with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -281,6 +283,8 @@ def main():
                            "global_batch": train["global_batch"], "parallelism": f"ddp{world}",
                            "algorithmic_tflop_per_step_per_gpu": 8.70})
         k = train["kernel"]
+        if k is None:  # no launch of the profiled shape (e.g. --group-norm: separate ih / hh gate convs)
+            k = {"split": False, "tflops": train["step_tflops_per_gpu"], "avg_ms": None, "launches": 0}
         gr = gate_roofline(k)
         kname = "igemm_split_bdirect_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128"
         # PMC pass over exactly this launch (tools/bench_gemm.py at the same shape; tools/run_profiles.sh)

@@ -295,6 +295,7 @@ ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 # frozen model: pad the input convs' concatenated input to 32-channel chunks (split-precision pipe)
 PAD32_INPUT_CONVS = os.environ.get("RAC_PAD32_INPUT_CONVS", "1") == "1"
+CONVBIAS_SPLIT = os.environ.get("RAC_CONVBIAS_SPLIT", "1") == "1"
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
 
 
@@ -544,7 +545,15 @@ class ConvBias(torch.autograd.Function):
             return conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias)
         padded = ci % 4 != 0 and x1 is None and x0.shape[3] == ci + pad4(ci)
         w = padded_weight(weight) if padded else weight
-        y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
+        B, H, W, _ = x0.shape
+        # the weights-direct split-precision kernels where the shape allows (the NormConvLSTM gate convs, the heads)
+        ctx.split = (CONVBIAS_SPLIT and act == ACT_NONE and not padded and (SPLIT_GEMM if frozen else SPLIT_GEMM_TRAIN)
+                     and x0.shape[3] % 32 == 0 and weight.shape[0] >= 128
+                     and split_weight_layout(H, W, ci, weight.shape[2], B * H * W, weight.shape[0]) == 2)
+        if ctx.split:
+            y = conv_forward_split(x0, x1, w, bias)
+        else:
+            y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
         ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
         ctx.act, ctx.padded = act, padded
         return y
@@ -561,10 +570,15 @@ class ConvBias(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
-            dx0, dx1 = conv_dgrad(dy, padded_weight(weight) if ctx.padded else weight, C0, C1)
+            if ctx.split:
+                dx0, dx1 = conv_dgrad_split(dy, weight, C0, C1)
+            else:
+                dx0, dx1 = conv_dgrad(dy, padded_weight(weight) if ctx.padded else weight, C0, C1)
         if weight.requires_grad:
             if ctx.padded:
                 wgrad_padded_acc(dy, x0, weight)
+            elif ctx.split and wgrad_split_ok(x0, x1, x0.shape[2]):
+                conv_wgrad_split_acc(dy, x0, x1, weight, defer=True)  # time-batched inside deferred_wgrad()
             else:
                 conv_wgrad_acc(dy, x0, x1, weight)
         if bias is not None and bias.requires_grad:
