@@ -266,6 +266,46 @@ def gen_train():
             save(f"train_cfg1_{tag}" + ("_sched" if sched else ""), **out)
 
 
+SWEEP = {
+    # future robot state + black_robot_input + dontcare_mse with a robot pixel weight, two context frames, skip
+    # connections frozen after the context (last_frame_skip False)
+    "a": dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True,
+              model_use_future_robot_state=True, black_robot_input=True, reconstruction_loss="dontcare_mse",
+              robot_pixel_weight=0.3, last_frame_skip=False, n_past=2, n_future=2),
+    # plain mse on a non-square 48x64 frame, three samples
+    "b": dict(reconstruction_loss="mse", image_height=48, image_width=64, batch_size=3),
+}
+
+
+def gen_sweep():
+    """One PredictionTrainer._train_step of the real reference for flag / shape combinations outside cfg1."""
+    from src.prediction.trainer import PredictionTrainer
+    for tag, flags in SWEEP.items():
+        kw = dict(g_dim=32, z_dim=8, batch_size=2, n_past=1, n_future=2, lr=1e-4)
+        kw.update(flags)
+        cfg = orc.Cfg(**kw)
+        B, T, H, W = cfg.batch_size, cfg.n_past + cfg.n_future, cfg.image_height, cfg.image_width
+        sd = orc.make_weights(cfg, seed=6, randomize_bn_stats=False)
+        ns = ns_for(cfg, wandb=False, jobname="g", wandb_project="x", wandb_entity="x", wandb_group=None,
+                    wandb_job_type=None, img_augmentation=False, seed=0, scheduled_sampling_k=4000,
+                    learned_robot_model=False)
+        tr = PredictionTrainer(ns)
+        tr.model.load_state_dict({k: v.clone() for k, v in sd.items()})
+        tr.model.train()
+        tr._step = 0
+        for e in syn.synth_eps(seed=32, steps=T - 1, B=B, z=cfg.z_dim, h=H // 8, w=W // 8):
+            _EPS.extend(e)
+        losses = tr._train_step(syn.synth_video(seed=31, T=T, B=B, H=H, W=W))
+        assert not _EPS
+        out = {f"train_{k}": v for k, v in losses.items()}
+        grads = dict(tr.model.named_parameters())
+        pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+        out["train_grad_norms"] = np.array([grads[k].grad.double().norm().item() for k in pk])
+        st = tr.model.state_dict()
+        out["rm_enc"] = st["encoder.c1.1.main.1.running_mean"].clone()
+        save(f"sweep_{tag}", **out)
+
+
 CEM_GAIN = 200.0
 CEM_SEED = {"vanilla": 5, "ra": 4}
 
@@ -421,7 +461,7 @@ def gen_cem():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval"]
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep"]
     if "forward" in which:
         gen_forward()
     if "shape" in which:
@@ -436,3 +476,5 @@ if __name__ == "__main__":
         gen_groupnorm()
     if "eval" in which:
         gen_eval()
+    if "sweep" in which:
+        gen_sweep()

@@ -237,6 +237,70 @@ def test_train_step_128x128_vs_oracle(dev):
     assert dot / np.sqrt(na * nb) > GRAD_COS
 
 
+SWEEP = [
+    dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
+         reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
+    dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=False, black_robot_input=True,
+         reconstruction_loss="mse"),
+    dict(last_frame_skip=False, n_past=2, n_future=2, reconstruction_loss="l1"),                    # step-by-step path
+    dict(model_use_mask=True, model_use_robot_state=True, reconstruction_loss="dontcare_l1", batch_size=3),   # ragged rows
+    dict(image_height=48, image_width=64, reconstruction_loss="l1", batch_size=2),                  # 6x8 latent maps
+]
+
+
+@pytest.mark.parametrize("flags", SWEEP, ids=[str(i) for i in range(len(SWEEP))])
+def test_train_step_flag_sweep_vs_oracle(dev, flags):
+    """One train step against the oracle over flag / shape combinations the golden traces do not cover: future robot
+    state, black_robot_input, the other reconstruction losses, last_frame_skip off with two context frames (falls
+    back to the step-by-step path), a batch whose rows are not whole tiles, a non-square frame."""
+    kw = dict(g_dim=32, z_dim=8, batch_size=2, n_past=1, n_future=2, lr=1e-4)
+    kw.update(flags)
+    cfg = orc.Cfg(**kw)
+    B, T = cfg.batch_size, cfg.n_past + cfg.n_future
+    H, W = cfg.image_height, cfg.image_width
+    sd = orc.make_weights(cfg, seed=6, randomize_bn_stats=False)
+    data = syn.synth_video(seed=31, T=T, B=B, H=H, W=W)
+    eps = syn.synth_eps(seed=32, steps=T - 1, B=B, z=cfg.z_dim, h=H // 8, w=W // 8)
+    ts = orc.TrainState.create(cfg, sd)
+    ref = orc.train_step(ts, data, eps, None, do_update=False)
+    tr = make_trainer(cfg, sd, dev)
+    queue = [e for pair in eps for e in pair]
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    tr.optimizer.step = lambda: None
+    got = tr._train_step(data)
+    assert not queue
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, atol=1e-9)
+    grads = dict(tr.model.named_parameters())
+    dot = na = nb = 0.0
+    for k in ts.param_keys:
+        a, b = grads[k].grad.double().cpu(), ts.sd[k].grad.double()
+        dot, na, nb = dot + float((a * b).sum()), na + float((a * a).sum()), nb + float((b * b).sum())
+    assert dot / np.sqrt(na * nb) > GRAD_COS
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_train_step_flag_sweep_vs_reference_golden(dev, golden_dir, tag):
+    """The two reference-generated flag-sweep traces (oracle/gen_golden.py:gen_sweep): losses, gradient norms and a
+    BatchNorm running mean of one train step of the REAL reference."""
+    from tests.test_oracle_golden import sweep_case
+    g = load(golden_dir, f"sweep_{tag}")
+    cfg, sd, data, eps = sweep_case(tag)
+    tr = make_trainer(cfg, sd, dev)
+    queue = [e for pair in eps for e in pair]
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    tr.optimizer.step = lambda: None
+    got = tr._train_step(data)
+    assert not queue
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        np.testing.assert_allclose(got[k], float(g[f"train_{k}"]), rtol=1e-4, atol=1e-9)
+    grads = dict(tr.model.named_parameters())
+    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    gn = np.array([grads[k].grad.double().norm().item() for k in pk])
+    np.testing.assert_allclose(gn, g["train_grad_norms"], rtol=GRAD_TOL, atol=1e-9)
+    assert rel(tr.model.state_dict()["encoder.c1.1.main.1.running_mean"], g["rm_enc"]) < 1e-4
+
+
 def cem_setup(tag, dev):
     ra = tag == "ra"
     cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=5, sample_mean=True,

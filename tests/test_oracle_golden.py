@@ -197,6 +197,40 @@ def test_groupnorm_lstm(golden_dir):
     close(gn, g["train_grad_norms"], rtol=1e-4, atol=1e-10)
 
 
+SWEEP = {  # the flag sets of oracle/gen_golden.py:gen_sweep
+    "a": dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True,
+              model_use_future_robot_state=True, black_robot_input=True, reconstruction_loss="dontcare_mse",
+              robot_pixel_weight=0.3, last_frame_skip=False, n_past=2, n_future=2),
+    "b": dict(reconstruction_loss="mse", image_height=48, image_width=64, batch_size=3),
+}
+
+
+def sweep_case(tag):
+    kw = dict(g_dim=32, z_dim=8, batch_size=2, n_past=1, n_future=2, lr=1e-4)
+    kw.update(SWEEP[tag])
+    cfg = orc.Cfg(**kw)
+    B, T, H, W = cfg.batch_size, cfg.n_past + cfg.n_future, cfg.image_height, cfg.image_width
+    sd = orc.make_weights(cfg, seed=6, randomize_bn_stats=False)
+    data = syn.synth_video(seed=31, T=T, B=B, H=H, W=W)
+    eps = syn.synth_eps(seed=32, steps=T - 1, B=B, z=cfg.z_dim, h=H // 8, w=W // 8)
+    return cfg, sd, data, eps
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_train_step_flag_sweep(golden_dir, tag):
+    """Flag / shape combinations outside cfg1 (future robot state, black_robot_input, dontcare_mse with a robot pixel
+    weight, last_frame_skip off with two context frames; mse on a 48x64 frame) against the reference's train step."""
+    g = load(golden_dir, f"sweep_{tag}")
+    cfg, sd, data, eps = sweep_case(tag)
+    ts = orc.TrainState.create(cfg, sd)
+    losses = orc.train_step(ts, data, eps, None, do_update=False)
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        close(losses[k], g[f"train_{k}"], rtol=2e-5)
+    gn = np.array([ts.sd[k].grad.double().norm().item() for k in ts.param_keys])
+    close(gn, g["train_grad_norms"], rtol=1e-4, atol=1e-10)
+    close(ts.sd["encoder.c1.1.main.1.running_mean"], g["rm_enc"], rtol=1e-5, atol=1e-8)
+
+
 def test_eval_step_and_metrics(golden_dir):
     """_eval_step (trainer.py:566-734) and psnr / ssim (src/utils/metrics.py) against the reference."""
     g = load(golden_dir, "eval_ra")
