@@ -238,7 +238,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="both", choices=["both", "train", "cem"])
     ap.add_argument("--cem-candidates", type=int, default=1000, help="candidates per GPU")
-    ap.add_argument("--cem-batch", type=int, default=500, help="candidates per GPU pass")
+    ap.add_argument("--cem-batch", type=int, default=1000, help="candidates per GPU pass (1000: 667 vs 661 rollouts/s at 500)")
     ap.add_argument("--cem-iters", type=int, default=2)
     ap.add_argument("--cem-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")

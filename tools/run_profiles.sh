@@ -19,6 +19,6 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_cem" -o run --output-format csv -- python3 bench.py $C > /dev/null 2> "$out/pmc_${ctr}_cem.err"
   echo "[profiles] pmc $ctr gate GEMMs" >&2
   RAC_BENCH_SPLIT=1 rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_gemm_train" -o run --output-format csv -- python3 tools/bench_gemm.py fwd 16 512 5 3 > /dev/null 2> "$out/pmc_${ctr}_gemm_train.err"
-  RAC_BENCH_SPLIT=1 rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_gemm_cem" -o run --output-format csv -- python3 tools/bench_gemm.py fwd 500 512 5 3 > /dev/null 2> "$out/pmc_${ctr}_gemm_cem.err"
+  RAC_BENCH_SPLIT=1 rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_gemm_cem" -o run --output-format csv -- python3 tools/bench_gemm.py fwd 1000 512 5 3 > /dev/null 2> "$out/pmc_${ctr}_gemm_cem.err"
 done
 echo "[profiles] done" >&2
