@@ -441,7 +441,9 @@ WGRAD_DIRECT = os.environ.get("RAC_WGRAD_DIRECT", "1") == "1"
 
 
 @contextlib.contextmanager
-def deferred_wgrad():
+def deferred_wgrad(on_ready=None):
+    """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
+    in stream order): the trainer starts that slice's data-parallel all-reduce there."""
     global _DEFERRED
     if not DEFER_WGRAD or _DEFERRED is not None:
         yield
@@ -450,8 +452,11 @@ def deferred_wgrad():
     try:
         yield
         pending, _DEFERRED = _DEFERRED, None
-        for weight, items in pending.values():
+        # largest first: their all-reduces are the longest and overlap the remaining launches
+        for weight, items in sorted(pending.values(), key=lambda wi: -wi[0].numel()):
             _wgrad_split_batch(items, weight)
+            if on_ready is not None:
+                on_ready(weight)
     finally:
         _DEFERRED = None
 

@@ -37,14 +37,49 @@ def allreduce_flat_grad(flat_grad: torch.Tensor, bucket_mb: int = 64):
     contiguous slice, so there is no pack/unpack copy), then one scale."""
     if not _dist_on():
         return
-    world = dist.get_world_size()
-    n = flat_grad.numel()
-    step = max(1, bucket_mb * (1 << 20) // 4)
-    works = [dist.all_reduce(flat_grad[s:min(n, s + step)], op=dist.ReduceOp.SUM, async_op=True)
-             for s in range(0, n, step)]
-    for w in works:
-        w.wait()
-    flat_grad.mul_(1.0 / world)
+    red = GradReducer(flat_grad, bucket_mb)
+    red.finish()
+
+
+class GradReducer:
+    """Data-parallel mean of the flat gradient buffer, overlapped with the tail of backward.
+
+    The ConvLSTM gate weights are 90 % of the parameters (214 M of 238.6 M at g512) and their gradients are the LAST
+    thing backward produces (one time-batched wgrad launch per weight when `ops.deferred_wgrad()` exits).  `ready(p)`
+    is called right after a weight's launch is enqueued: the all-reduce of that weight's slice starts on RCCL's
+    stream while the next weight's wgrad computes.  `finish()` reduces whatever has not been reduced yet (vgg
+    stack, input convs, heads, biases: 10 %), waits for everything and applies the 1/world scale once."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_mb: int = 64):
+        self.flat = flat_grad
+        self.step = max(1, bucket_mb * (1 << 20) // 4)
+        self.works = []
+        self.done = []  # reduced [start, end) element ranges
+
+    def _reduce(self, start: int, end: int):
+        for s in range(start, end, self.step):
+            e = min(end, s + self.step)
+            self.works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+
+    def ready(self, param: torch.Tensor):
+        g = param.grad
+        if g is None or g.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+            return  # not a view of the flat buffer: left to finish()
+        start = g.storage_offset() - self.flat.storage_offset()
+        self._reduce(start, start + g.numel())
+        self.done.append((start, start + g.numel()))
+
+    def finish(self):
+        pos = 0
+        for start, end in sorted(self.done):
+            if start > pos:
+                self._reduce(pos, start)
+            pos = max(pos, end)
+        if pos < self.flat.numel():
+            self._reduce(pos, self.flat.numel())
+        for w in self.works:
+            w.wait()
+        self.flat.mul_(1.0 / dist.get_world_size())
 
 
 class PredictionTrainer(object):
@@ -236,9 +271,12 @@ class PredictionTrainer(object):
                     skip = curr_skip
                 add_losses(x_pred, i, mu, logvar, mu_p, logvar_p)
         # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
-        with ops.deferred_wgrad():  # ConvLSTM weight gradients: one time-batched launch per weight
+        reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64)) if _dist_on() else None
+        # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce
+        with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
             torch.autograd.backward(roots, seeds)
-        allreduce_flat_grad(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
+        if reducer is not None:
+            reducer.finish()
         self.optimizer.step()
 
         vals = torch.stack([t[k] for _, t, k in log]).cpu().tolist()  # the one host sync of the step

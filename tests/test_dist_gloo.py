@@ -28,6 +28,18 @@ def _worker(rank, world, port, N, q):
     g2 = full[rank].clone()
     allreduce_flat_grad(g2, bucket_mb=64)        # one bucket
     ok_grad = torch.allclose(g, full.mean(0), atol=1e-6) and torch.allclose(g2, full.mean(0), atol=1e-6)
+    # overlapped reducer: two parameters' slices go first (out of order, as the deferred wgrads finish), the rest last
+    from robot_aware_control_amd.trainer import GradReducer
+    g3 = full[rank].clone()
+    pa, pb = torch.nn.Parameter(torch.zeros(300)), torch.nn.Parameter(torch.zeros(17, 20))
+    pa.grad, pb.grad = g3[1200:1500], g3[100:440].view(17, 20)
+    red = GradReducer(g3, bucket_mb=0)
+    red.step = 128
+    red.ready(pa)
+    red.ready(pb)
+    red.ready(torch.nn.Parameter(torch.zeros(3)))  # no grad / foreign storage: ignored
+    red.finish()
+    ok_grad = ok_grad and torch.allclose(g3, full.mean(0), atol=1e-6)
     costs = torch.arange(N, dtype=torch.float64) * -1.5
     lo, hi = shard_bounds(N, world, rank)
     got = gather_costs(costs[lo:hi].clone(), N, world, rank)

@@ -76,14 +76,14 @@ def _worker(rank, world, port, q):
         tr.model.eps_source = lambda shape: torch.zeros(shape)
         tr.optimizer.step = lambda: None
         data = syn.synth_video(seed=30 + rank, T=3, B=2)
-        real = trainer_mod.allreduce_flat_grad
-        trainer_mod.allreduce_flat_grad = lambda *a, **k: None
+        real = trainer_mod._dist_on
+        trainer_mod._dist_on = lambda: False  # local gradients only
         tr._train_step(data)
         local = tr.model.flat_parameters()[1].clone()
         parts = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(parts, local)
         mean = sum(parts) / world
-        trainer_mod.allreduce_flat_grad = real
+        trainer_mod._dist_on = real  # GradReducer: LSTM slices as their wgrads finish, the rest at the end
         tr.model.load_state_dict({k: v.clone() for k, v in orc.make_weights(cfg, seed=1, randomize_bn_stats=False).items()})
         tr._train_step(data)
         got = tr.model.flat_parameters()[1]
