@@ -295,6 +295,7 @@ ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 # frozen model: pad the input convs' concatenated input to 32-channel chunks (split-precision pipe)
 PAD32_INPUT_CONVS = os.environ.get("RAC_PAD32_INPUT_CONVS", "1") == "1"
+PAD32_TRAIN = os.environ.get("RAC_PAD32_TRAIN", "1") == "1"  # ... in the training step too
 CONVBIAS_SPLIT = os.environ.get("RAC_CONVBIAS_SPLIT", "1") == "1"
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
 
@@ -477,6 +478,9 @@ def _wgrad_split_batch(items, weight):
     Co, Cin, k, _ = weight.shape
     C0 = x0.shape[3]
     C1 = x1.shape[3] if x1 is not None else 0
+    ci_real = Cin
+    if x1 is None and C0 > Cin:  # x0 carries zero pad channels (32-channel chunks): gradient of the padded weight
+        Cin = C0
     P = B * H * W
     ld = T * P
     dev = dy.device
@@ -492,11 +496,16 @@ def _wgrad_split_batch(items, weight):
         call("rac_transpose_split", ptr(x0_t), ptr(x0t), P, C0, W, k, ld, xl, t * P, sp)
         if C1:
             call("rac_transpose_split", ptr(x1_t), ptr(x1t), P, C1, W, k, ld, xl, t * P, sp)
-    g = weight_mem(grad_buffer(weight))
+    if Cin != ci_real:
+        g = torch.zeros((Cout, k, k, Cin), device=dev, dtype=torch.float32)
+    else:
+        g = weight_mem(grad_buffer(weight))
     args = ConvArgs(mode=WGRAD, B=B * T, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
                     a_split=C0, o_split=0, slab_stride=0, a0=ptr(x0t), a1=ptr(x1t), w=ptr(dyt), out0=ptr(g), out1=None,
                     bias=None, scale=None, shift=None, stats=None)
     call("rac_conv2d_wgrad_split", C.byref(args), xl, sp)
+    if Cin != ci_real:
+        call("rac_unpad_add", ptr(g), Cin, ptr(weight_mem(grad_buffer(weight))), ci_real, Cout * k * k, sp)
 
 
 def wgrad_split_ok(x0, x1, W: int) -> bool:
@@ -545,9 +554,14 @@ class ConvBias(torch.autograd.Function):
     def forward(ctx, x0, x1, weight, bias, act, frozen=False):
         ci = weight.shape[1]
         # `frozen` = not torch.is_grad_enabled() at the call site (grad mode is always off inside forward())
-        if frozen and x1 is None and x0.shape[3] == ci + (-ci) % 32 and x0.shape[3] != ci + pad4(ci) and act == ACT_NONE:
-            # frozen model: TileCat padded the input to whole 32-channel chunks so that the conv runs split-precision
-            return conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias)
+        ctx.pad32 = (x1 is None and x0.shape[3] == ci + (-ci) % 32 and x0.shape[3] != ci + pad4(ci) and act == ACT_NONE)
+        if ctx.pad32:
+            # TileCat padded the input to whole 32-channel chunks so that the conv runs split-precision
+            y = conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias)
+            if not frozen:
+                ctx.save_for_backward(x0, None, weight, bias, None)
+                ctx.act, ctx.padded, ctx.split = act, False, False
+            return y
         padded = ci % 4 != 0 and x1 is None and x0.shape[3] == ci + pad4(ci)
         w = padded_weight(weight) if padded else weight
         B, H, W, _ = x0.shape
@@ -574,6 +588,14 @@ class ConvBias(torch.autograd.Function):
         C0 = x0.shape[3]
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
+        if ctx.pad32:  # both gradients on the split pipe, against the 32-channel-padded weight
+            if ctx.needs_input_grad[0]:
+                dx0, _ = conv_dgrad_split(dy, padded_weight(weight, C0), C0, 0)
+            if weight.requires_grad:
+                conv_wgrad_split_acc(dy, x0, None, weight, defer=True)  # unpads into weight.grad
+            if bias is not None and bias.requires_grad:
+                bias_grad_acc(dy, bias)
+            return dx0, None, None, None, None, None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
             if ctx.split:
                 dx0, dx1 = conv_dgrad_split(dy, weight, C0, C1)
@@ -757,8 +779,8 @@ class TileCat(torch.autograd.Function):
         c1 = m1.shape[3] if m1 is not None else 0
         ct = sum(ns) + c0 + c1
         pad = pad4(ct)
-        if frozen and SPLIT_GEMM and PAD32_INPUT_CONVS and ct >= 128 and H * W <= 128:
-            pad = (-ct) % 32  # frozen model: whole 32-channel chunks, the consumer conv runs split-precision
+        if (SPLIT_GEMM if frozen else (SPLIT_GEMM_TRAIN and PAD32_TRAIN)) and PAD32_INPUT_CONVS and ct >= 128 and 128 % (H * W) == 0:
+            pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
              ptr(out), B, H * W, stream_ptr())
