@@ -100,6 +100,7 @@ class PredictionTrainer(object):
         self._plot_rng = np.random.RandomState(self._config.seed)
         self._video_sample_rng = np.random.RandomState(self._config.seed)
         self._grad_seeds = {}
+        self._loss_host = None  # pinned staging buffer of the per-step loss readback
         self._wandb = None
         if getattr(config, "wandb", False):
             import wandb  # only when asked for (reference trainer.py:70-84)
@@ -270,6 +271,17 @@ class PredictionTrainer(object):
                 if i <= cf.n_past:
                     skip = curr_skip
                 add_losses(x_pred, i, mu, logvar, mu_p, logvar_p)
+        # the step's loss scalars are final once the forward pass is enqueued: start their device->host copy now (into
+        # pinned memory) and collect it after the optimiser step is enqueued, so that the host never waits for the
+        # backward pass or Adam (the reference likewise reads its losses before loss.backward(), trainer.py:433-458)
+        with torch.no_grad():
+            vals_dev = torch.stack([t.detach()[k] for _, t, k in log])
+        if self._loss_host is None or self._loss_host.numel() < vals_dev.numel():
+            self._loss_host = torch.empty(max(64, vals_dev.numel()), dtype=vals_dev.dtype).pin_memory()
+        vals_host = self._loss_host[:vals_dev.numel()]
+        vals_host.copy_(vals_dev, non_blocking=True)
+        copied = torch.cuda.Event()
+        copied.record()
         # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
         reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64)) if _dist_on() else None
         # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce
@@ -279,7 +291,8 @@ class PredictionTrainer(object):
             reducer.finish()
         self.optimizer.step()
 
-        vals = torch.stack([t[k] for _, t, k in log]).cpu().tolist()  # the one host sync of the step
+        copied.synchronize()  # the one host wait of the step (normally already satisfied)
+        vals = vals_host.tolist()
         losses = defaultdict(float)
         for (name, _, _), v in zip(log, vals):
             losses[name] += v
