@@ -237,6 +237,50 @@ def test_train_step_128x128_vs_oracle(dev):
     assert dot / np.sqrt(na * nb) > GRAD_COS
 
 
+def test_train_step_full_width_vs_oracle(dev):
+    """The benchmarked model width (g 512 / z 64: gate GEMMs N = 2048, K = 25 600 with split-K, XCD-grouped launch,
+    time-batched wgrad, fragment-order weights of 52 M elements) at batch 4, two predicted frames, against the oracle."""
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=4, n_past=1, n_future=2, lr=1e-4, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=8, randomize_bn_stats=False)
+    data = syn.synth_video(seed=14, T=3, B=4)
+    eps = syn.synth_eps(seed=15, steps=2, B=4, z=64, h=8, w=8)
+    ts = orc.TrainState.create(cfg, sd)
+    ref = orc.train_step(ts, data, eps, None, do_update=False)
+    tr = make_trainer(cfg, sd, dev)
+    queue = [e for pair in eps for e in pair]
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    tr.optimizer.step = lambda: None  # compare raw gradients
+    got = tr._train_step(data)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4)
+    grads = dict(tr.model.named_parameters())
+    dot = na = nb = 0.0
+    for k in ts.param_keys:
+        a, b = grads[k].grad.double().cpu(), ts.sd[k].grad.double()
+        if "lstm" in k and k.endswith("gates.weight"):
+            assert float((a - b).norm() / (b.norm() + 1e-20)) < GRAD_TOL, k
+        dot, na, nb = dot + float((a * b).sum()), na + float((a * a).sum()), nb + float((b * b).sum())
+    assert dot / np.sqrt(na * nb) > GRAD_COS
+
+
+def test_cem_rollouts_full_width_vs_oracle(dev):
+    """Frozen model at the benchmarked width (g 512 / z 64), 6 candidates x 3 steps: sum_cost <= 1e-5 vs the oracle."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=2, candidates_batch_size=4, sample_mean=True, reward_type="dense",
+                  topk=3, **FLAGSETS["vanilla"])
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=5, N=6, T=3, with_robot=False, goal_blend=0.15)
+    ref = orc.cem_rollouts(sd, cfg, prob["actions"], prob["start_img"], prob["goal_imgs"], prob["goal_masks"])
+    model = build_model(cfg, sd, dev)
+    sampler = TrajectorySampler(ns_for(cfg, dev), model)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    ro = sampler.generate_model_rollouts(prob["actions"].clone(), start, goal)
+    err = float(np.abs(ro["sum_cost"] - ref["sum_cost"]).max() / np.abs(ref["sum_cost"]).max())
+    assert err < 1e-5, err
+
+
 SWEEP = [
     dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
          reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
