@@ -281,6 +281,37 @@ def test_cem_rollouts_full_width_vs_oracle(dev):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("sparse", [False, True])
+def test_cem_rollout_options_vs_oracle(dev, sparse):
+    """generate_model_rollouts options (trajectory_sampler.py:35-199): ragged last batch (7 candidates, batches of 3),
+    sparse_cost (only the last step is costed), ret_obs (predicted frames of the elites), ret_step_cost, opt_traj."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=3, sample_mean=True, reward_type="dense",
+                  topk=3, sparse_cost=sparse, **FLAGSETS["vanilla"])
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    N, T = 7, 3
+    prob = syn.synth_cem_problem(seed=5, N=N + 1, T=T, with_robot=False, goal_blend=0.15)
+    acts, opt = prob["actions"][:N], prob["actions"][N, :, :2]
+    ref = orc.cem_rollouts(sd, cfg, acts, prob["start_img"], prob["goal_imgs"], prob["goal_masks"], opt_traj=opt.clone(),
+                           ret_obs=True)
+    sampler = TrajectorySampler(ns_for(cfg, dev), build_model(cfg, sd, dev))
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    ro = sampler.generate_model_rollouts(acts.clone(), start, goal, opt_traj=opt.clone(), ret_obs=True, ret_step_cost=True)
+    scale = np.abs(ref["sum_cost"]).max()
+    assert np.abs(ro["sum_cost"] - ref["sum_cost"]).max() / scale < 1e-5
+    assert abs(ro["optimal_sum_cost"] - ref["optimal_sum_cost"]) / scale < 1e-5
+    assert ro["sum_cost"].shape == (N,) and ro["step_cost"].shape == (N, T)
+    np.testing.assert_allclose(ro["step_cost"].sum(1), ro["sum_cost"], rtol=1e-9, atol=1e-9 * scale)
+    if sparse:
+        assert np.all(ro["step_cost"][:, :-1] == 0)
+    top = np.argsort(ref["sum_cost"])[-3:]
+    assert list(ro["topk_idx"]) == list(top)
+    assert np.abs(ro["obs"] - ref["obs_all"][top]).max() < 1e-4
+    assert np.abs(ro["optimal_obs"] - ref["obs_all"][N]).max() < 1e-4
+
+
 SWEEP = [
     dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
          reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
