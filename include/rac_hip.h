@@ -92,11 +92,11 @@ int rac_conv2d(const rac_conv_args* a, void* stream);
  * ------------------------------------------------------------------------ */
 /* parts[k*part_stride + i] = k-th bf16 part of x[i], k = 0..2 (round-to-nearest-even at every level) */
 int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream);
-/* Conv weight (fp32, [Cout][k][k][Cin] memory) -> bf16 parts in MFMA fragment order (w_layout 2 below), in one pass.
+/* Conv weight (fp32, [Cout][k][k][Cin] memory) -> bf16 parts in MFMA fragment order (w_layout 2 or 3 below), in one pass.
  * transposed = 0: rows = Cout, K = Cin (forward).  transposed = 1: rows = Cin, K = Cout, taps flipped: the weight of
  * the forward conv that IS the data gradient (dgrad(dy, W) == fwd(dy, Wt)).  Channel counts % 32 == 0. */
 int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Cout, int32_t Cin, int32_t ksize, int32_t transposed,
-                          int64_t part_stride, void* stream);
+                          int64_t part_stride, int32_t w_layout, void* stream);
 /* FWD conv (as rac_conv2d mode RAC_CONV_FWD) on split operands: a0 / a1 / w point to bf16 part arrays
  * ([3][pixels][C] and [3][Cout][k][k][Cin]; *_part_stride in elements).  Needs Cin % 8 == 0, a_split % 32 == 0.
  * Epilogue fields (bias, scale/shift, act, stats, split_k slabs) behave as in rac_conv2d. */
@@ -111,7 +111,10 @@ int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t
  *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps).  With this layout a0 / a1
  *       are plain fp32 [pixels][C] maps (a0_part_stride = a1_part_stride = 0): the kernel splits them on the way
  *       into LDS, no rac_split_bf16x3 pass.  Also serves maps larger than a tile (H*W > 128) when W divides 128
- *       and H is a multiple of 128 / W (image rows + halo per tile), and N <= 64 (64-column workgroups). */
+ *       and H is a multiple of 128 / W (image rows + halo per tile), and N <= 64 (64-column workgroups).
+ *   3 = as 2 for the v_mfma_f32_16x16x32_bf16 form of the same kernel (H*W dividing 128 only):
+ *       [Cout/32][Cin/32][k*k][nb 2][lane 64][8] with lane = 16 q + (co mod 16), co = 32 tile + 16 nb + lane mod 16,
+ *       ci = 32 chunk + 8 q + j.  The chip holds a higher clock on that instruction under this load. */
 /* Transposed bf16 parts for the split-precision weight gradient:
  *   out[dxi][k][c][p] = k-th part of (0 <= x(p)+dx < W ? x[p+dx][c] : 0),  dx = dxi - ndx/2,
  * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy).

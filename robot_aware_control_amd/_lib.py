@@ -34,7 +34,7 @@ class ConvArgs(C.Structure):
 _SIGS = {
     "rac_conv2d": [C.POINTER(ConvArgs), vp],
     "rac_split_bf16x3": [vp, vp, i64, i64, vp],
-    "rac_weight_frag_split": [vp, vp, i32, i32, i32, i32, i64, vp],
+    "rac_weight_frag_split": [vp, vp, i32, i32, i32, i32, i64, i32, vp],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), i64, i64, i64, i32, vp],
     "rac_transpose_split": [vp, vp, i32, i32, i32, i32, i64, i32, i64, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(ConvArgs), i32, vp],

@@ -732,6 +732,242 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
 
 
 // ---------------------------------------------------------------------------------------------------------
+// igemm_split_bdirect_kernel on v_mfma_f32_16x16x32_bf16 (weight layout 3).  Same algorithm, same sums; the matrix
+// instruction is the 16x16x32 form because the chip holds a higher clock on it under this MFMA-bound load
+// (MI355X_MICROARCH.md DVFS item 7: ~1.12-1.15x the FLOP/s of the 32x32x16 form at equal cycles per FLOP).
+//   A operand: lane l holds row l & 15, k = 8 (l >> 4) .. +7  -> the LDS image is CHUNK-major,
+//     [part][16-byte chunk 0..3][row 0..143][16 B] (rows 128.. are zeros), so that the 16 lanes of a ds_read_b128
+//     group always touch 16 distinct rows mod 16 = 16 distinct bank slots, and a tap shift is still one uniform offset.
+//   B operand: lane l holds column l & 15, k = 8 (l >> 4) .. +7 -> weights in the matching fragment order
+//     [part][Cout/32][Cin/32][tap][nb 0..1][lane][8]  (nb = 16-column half of the wave's 32 columns).
+//   C: 8 x 2 accumulators of 16x16 per wave (128 rows x 32 columns), col = l & 15, row = 4 (l >> 4) + reg.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int B16_CP = 144 * 16, B16_PP = 4 * B16_CP, B16_ABUF = 3 * B16_PP;  // chunk plane, part plane, buffer (bytes)
+
+__global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {  // see igemm_split_tapinner_kernel
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int m0 = bx * SBM, n0 = by * SBN;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  // zero rows 128..143 of every chunk plane of both buffers: 2 * 3 * 4 * 16 = 384 vectors
+  for (int v = tid; v < 384; v += 256) {
+    const int pl = v >> 4, r = v & 15;  // plane index (buffer, part, chunk), row
+    *reinterpret_cast<u32x4*>(lds_raw + (pl / 12) * B16_ABUF + ((pl / 4) % 3) * B16_PP + (pl & 3) * B16_CP +
+                              (128 + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  // staging: thread -> row tid & 127, chunks (tid >> 7) and (tid >> 7) + 2 (8 consecutive lanes = 8 rows of one
+  // chunk plane: distinct bank slots on the ds_write side too)
+  const int srow = tid & 127, sch = tid >> 7;
+  const bool a_ok = m0 + srow < p.M;
+  // fragment rows of this lane (eight 16-row blocks): one bit per tap and block for the shifted pixel's validity
+  unsigned amask[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = t * 16 + lr;
+    const int im = r / p.HW;
+    const int q = r - im * p.HW;
+    const int y = q / p.W, x = q - y * p.W;
+    unsigned mk = 0;
+    for (int tp = 0; tp < p.taps; ++tp) {
+      const int yy = y + tp / p.ks - p.pad, xx = x + tp % p.ks - p.pad;
+      mk |= (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) ? (1u << tp) : 0u;
+    }
+    amask[t] = mk;
+  }
+  const int abase = lq * B16_CP + lr * 16;       // block t adds t * 256
+  const int zrow = lq * B16_CP + 128 * 16;
+  const int ntile = (n0 >> 5) + wid;
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part)
+    b_off[part] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u +
+                  part * w_pstride;
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        rb[part * 2 + nb] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + nb * 1024u), so, 0));
+  };
+  u32x4 ra[4];  // fp32 activations: [chunk i][half]
+  auto issue_a = [&](int cc) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = first ? c0 : c0 - p.a_split;
+    const rsrc_t a_rsrc = mk_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned oa = (unsigned)((m0 + srow) * Cs + cl + (sch + 2 * i) * 8) * 4u;
+      ra[2 * i] = ld16(a_rsrc, a_ok ? oa : OOBS);
+      ra[2 * i + 1] = ld16(a_rsrc, a_ok ? oa + 16u : OOBS);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 q[3];
+      split8(ra[2 * i], ra[2 * i + 1], q);
+#pragma unroll
+      for (int part = 0; part < 3; ++part)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * B16_ABUF + part * B16_PP + (sch + 2 * i) * B16_CP + srow * 16) = q[part];
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    int cur = 0;
+    bool fresh = true;
+    u32x4 b0[6], b1[6], b2[6];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    load_b(b1, kc_begin + 1);
+    store_a(0);
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
+      fresh = false;
+      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * 16 + cur * B16_ABUF + abase;
+      const int zr = zrow + cur * B16_ABUF;
+      const unsigned bit = 1u << tap;
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[nb][part] = __builtin_bit_cast(bf16x8, rb[part * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 fa[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int mb = 4 * h + t;
+          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            fa[t][part] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * B16_PP));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x4 c = acc[4 * h + t][nb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][2], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][0], c, 0, 0, 0);
+            acc[4 * h + t][nb] = c;
+          }
+      }
+      if (last_tap && more) {
+        store_a(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 3) {
+      load_b(b2, kc + 2);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 3);
+        step(b1, kc + 1);
+      }
+      if (kc + 2 < kc_end) {
+        load_b(b1, kc + 4);
+        step(b2, kc + 2);
+      }
+    }
+  }
+
+  // ---- epilogue (same semantics as rac_conv2d FWD): col = l & 15 (+16 nb), rows 4 (l >> 4) + reg of each block ----
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wid * 32 + nb * 16 + lr;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mb * 16 + 4 * lq + r;
+        if (m >= p.M || !nok) continue;
+        float v = acc[mb][nb][r];
+        if (slab) {
+          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        s1 += v;
+        s2 += v * v;
+        v = v * sc + sh;
+        if (p.act == RAC_ACT_LEAKY02)
+          v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == RAC_ACT_SIGMOID)
+          v = sigmoid_acc(v);
+        p.out0[(long)m * p.N + n] = v;
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lq == 0 && nok) {
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The same kernel for maps LARGER than a tile (W = 16, 32 or 64 and 128 / W rows of one image per tile: the 16x16
 // and 32x32 vgg maps, the 16x16 ConvLSTM maps of a 128x128 model).  The tile's pixels plus `pad` image rows above
 // and below (the halo; zeros outside the image) are staged per channel chunk as (R + 2 pad) * W rows of the padded
@@ -1370,7 +1606,7 @@ __global__ void split_bf16x3_vec4_kernel(const float4* x, u16x4* parts, long n4,
 // transposed: rows r = ci, k = co, value w[k][taps-1-tap][r]   (the conv that IS the data gradient)
 // One workgroup = two (row tile, k chunk, tap) cells: every wave writes 1 KB contiguous per part.
 __global__ void weight_frag_split_kernel(const float* w, unsigned short* out, int Cout, int Cin, int taps, int transposed,
-                                         long ps) {
+                                         long ps, int mfma16) {
   const int R = transposed ? Cin : Cout, Kc = transposed ? Cout : Cin;
   const int cch = Kc >> 5;
   const long cell = (long)blockIdx.x * 2 + (threadIdx.x >> 7);  // ((nt * cch + cc) * taps + tap)
@@ -1379,8 +1615,10 @@ __global__ void weight_frag_split_kernel(const float* w, unsigned short* out, in
   const int cc = (int)((cell / taps) % cch);
   const int nt = (int)(cell / ((long)taps * cch));
   const int s = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
-  const int li = lane & 31, lh = lane >> 5;
-  const int r = nt * 32 + li, k0 = cc * 32 + 16 * s + 8 * lh;
+  // 32x32x16 operand: lane = 32 h + r mod 32, k = 16 s + 8 h + j;  16x16x32 operand (layout 3): s = 16-column half,
+  // lane = 16 q + r mod 16, k = 8 q + j
+  const int r = mfma16 ? nt * 32 + s * 16 + (lane & 15) : nt * 32 + (lane & 31);
+  const int k0 = mfma16 ? cc * 32 + 8 * (lane >> 4) : cc * 32 + 16 * s + 8 * (lane >> 5);
   float v[8];
   if (!transposed) {
     const float4* src = reinterpret_cast<const float4*>(w + ((long)r * taps + tap) * Cin + k0);
@@ -1427,7 +1665,8 @@ extern "C" int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int6
 }
 
 extern "C" int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Cout, int32_t Cin, int32_t ksize,
-                                     int32_t transposed, int64_t part_stride, void* stream) {
+                                     int32_t transposed, int64_t part_stride, int32_t w_layout, void* stream) {
+  RAC_REQUIRE(w_layout == 2 || w_layout == 3, "rac_weight_frag_split: w_layout must be 2 or 3");
   RAC_REQUIRE(w && parts && Cout > 0 && Cin > 0 && ksize >= 1 && (ksize & 1), "rac_weight_frag_split: bad args");
   RAC_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "rac_weight_frag_split: channel counts must be multiples of 32");
   const long n = (long)Cout * Cin * ksize * ksize;
@@ -1436,7 +1675,7 @@ extern "C" int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Co
   const long cells = n / 1024;  // (row tile, k chunk, tap) cells of 32 x 32 weights
   hipLaunchKernelGGL(weight_frag_split_kernel, dim3((unsigned)((cells + 1) / 2)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), w, parts, Cout, Cin, ksize * ksize, transposed,
-                     (long)part_stride);
+                     (long)part_stride, w_layout == 3 ? 1 : 0);
   return check_launch("rac_weight_frag_split");
 }
 
@@ -1469,8 +1708,8 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   RAC_REQUIRE(a->Cin % 8 == 0 && p.a_split % 8 == 0, "rac_conv2d_fwd_split: channel counts must be multiples of 8");
   RAC_REQUIRE(p.a_split == a->Cin || p.a_split % SBK == 0, "rac_conv2d_fwd_split: a_split must be a multiple of 32");
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
-  if (w_layout == 2) {  // fragment-order weights: the activations are fp32 [pixel][channel], split inside the kernel
-    RAC_REQUIRE(a0_ps == 0 && a1_ps == 0, "rac_conv2d_fwd_split: w_layout 2 takes fp32 activations (part strides 0)");
+  if (w_layout >= 2) {  // fragment-order weights: the activations are fp32 [pixel][channel], split inside the kernel
+    RAC_REQUIRE(a0_ps == 0 && a1_ps == 0, "rac_conv2d_fwd_split: w_layout 2 / 3 take fp32 activations (part strides 0)");
     RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
                 "rac_conv2d_fwd_split: operand larger than 4 GiB");
   } else {
@@ -1499,9 +1738,9 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   dim3 grid(cdiv(p.M, SBM), cdiv(p.N, SBN), p.split_k);
   static const bool no_tapinner = getenv("RAC_SPLIT_TAPOUTER") != nullptr;  // A/B switch for benchmarks
   p.w_chunk_major = 0;
-  RAC_REQUIRE(w_layout >= 0 && w_layout <= 2, "rac_conv2d_fwd_split: w_layout must be 0, 1 or 2");
+  RAC_REQUIRE(w_layout >= 0 && w_layout <= 3, "rac_conv2d_fwd_split: w_layout must be 0 .. 3");
   const bool w_chunk_major = w_layout == 1;
-  RAC_REQUIRE(w_layout == 0 || (w_layout == 2 && p.HW > SBM) ||
+  RAC_REQUIRE(w_layout == 0 || (w_layout >= 2 && p.HW > SBM) ||
                   (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1),
               "rac_conv2d_fwd_split: chunk-major / fragment-order weights need Cin % 32 == 0, k > 1 and whole images "
               "per 128-pixel tile");
@@ -1542,6 +1781,25 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
     p.xcd_group = p.xcd_group && (grid.y * grid.z) % 8 == 0;
     hipLaunchKernelGGL(fns[narrow][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(weights direct, image rows)");
+  }
+  if (w_layout == 3) {
+    RAC_REQUIRE(p.HW <= SBM, "rac_conv2d_fwd_split: w_layout 3 serves maps of at most 128 pixels");
+    RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,
+                "rac_conv2d_fwd_split: fragment-order weights need Cout % 32 == 0 and k <= 5");
+    RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+    constexpr size_t lds_b16 = 2 * B16_ABUF;  // 55,296 B
+    static bool b16_attr = false;
+    if (!b16_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_split_bdirect16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b16);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      b16_attr = true;
+    }
+    hipLaunchKernelGGL(igemm_split_bdirect16_kernel, grid, dim3(256), lds_b16, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_fwd_split(weights direct, 16x16x32)");
   }
   if (w_layout == 2) {
     RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,

@@ -291,6 +291,8 @@ TAPINNER_MIN_TILES = int(os.environ.get("RAC_TAPINNER_MIN_TILES", "0"))
 W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
 # ... also on maps larger than a tile (16x16 / 32x32): the image-rows + halo variant of that kernel
 ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
+# v_mfma_f32_16x16x32_bf16 instead of 32x32x16 in the weights-direct kernel for the latent maps (weight layout 3)
+MFMA16 = os.environ.get("RAC_MFMA16", "1") == "1"
 # narrowest layer (output channels) of the frozen model that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 # frozen model: pad the input convs' concatenated input to 32-channel chunks (split-precision pipe)
@@ -313,13 +315,24 @@ def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int
         return 2 if (direct and ROWS_KERNEL and rows_ok) else 0
     if not tapinner_ok(H, W, Cin, k, M, N):
         return 0
-    return 2 if direct else 1
+    if direct:
+        return 3 if MFMA16 else 2  # the 16x16x32 form of the same kernel: higher sustained clock
+    return 1
 
 
-_W_LAYOUT_FN = {1: chunk_major, 2: frag_order}
+def frag_order16(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][k][k][Cin] memory -> contiguous [Cout/32][Cin/32][k*k][nb][q][co mod 16][8] (weight layout 3: the
+    operand registers of v_mfma_f32_16x16x32_bf16, lane = 16 q + co mod 16, co = 32 tile + 16 nb + .., ci = 32 chunk
+    + 8 q + j)."""
+    co, ci, k, _ = w.shape
+    mem = w.permute(0, 2, 3, 1).reshape(co // 32, 2, 16, k * k, ci // 32, 4, 8)  # nt, nb, lr, tap, cc, q, j
+    return mem.permute(0, 4, 3, 1, 5, 2, 6).contiguous()
 
 
-def weight_frag_parts(weight: torch.Tensor, transposed: bool = False) -> torch.Tensor:
+_W_LAYOUT_FN = {1: chunk_major, 2: frag_order, 3: frag_order16}
+
+
+def weight_frag_parts(weight: torch.Tensor, transposed: bool = False, layout: int = 2) -> torch.Tensor:
     """bf16 parts of a channels_last conv weight in MFMA fragment order (w_layout 2), one pass over the weight;
     `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient.
     Equals split_parts(frag_order(w)) resp. split_parts(frag_order(transposed_weight(w)))."""
@@ -327,7 +340,7 @@ def weight_frag_parts(weight: torch.Tensor, transposed: bool = False) -> torch.T
     w = weight_mem(weight.detach())
     n = w.numel()
     parts = torch.empty((3, n), device=w.device, dtype=torch.bfloat16)
-    call("rac_weight_frag_split", ptr(w), ptr(parts), co, ci, k, 1 if transposed else 0, n, stream_ptr())
+    call("rac_weight_frag_split", ptr(w), ptr(parts), co, ci, k, 1 if transposed else 0, n, layout, stream_ptr())
     return parts
 
 
@@ -342,8 +355,8 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    a0_ps = 0 if w_layout == 2 else p0.shape[1]  # layout 2: p0 / p1 are the fp32 maps themselves
-    a1_ps = 0 if (w_layout == 2 or p1 is None) else p1.shape[1]
+    a0_ps = 0 if w_layout >= 2 else p0.shape[1]  # layouts 2 / 3: p0 / p1 are the fp32 maps themselves
+    a1_ps = 0 if (w_layout >= 2 or p1 is None) else p1.shape[1]
     call("rac_conv2d_fwd_split", C.byref(args), a0_ps, a1_ps, pw.shape[1], w_layout, stream_ptr())
     if timed:
         e1.record()
@@ -362,13 +375,13 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     assert Cin == C0 + C1
     M = B * H * W
     cm = split_weight_layout(H, W, Cin, k, M, Cout)
-    if cm == 2:  # the weights-direct kernels read fp32 activations and split them on the way into LDS
+    if cm >= 2:  # the weights-direct kernels read fp32 activations and split them on the way into LDS
         p0, p1 = x0.contiguous(), (x1.contiguous() if x1 is not None else None)
     else:
         p0 = split_parts(x0)
         p1 = split_parts(x1) if x1 is not None else None
-    if cm == 2:
-        pw = _derived(weight, "_rac_split_l2", lambda: weight_frag_parts(weight))
+    if cm >= 2:
+        pw = _derived(weight, f"_rac_split_l{cm}", lambda: weight_frag_parts(weight, layout=cm))
     elif cm:
         pw = _derived(weight, f"_rac_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](weight.detach())))
     else:
@@ -411,14 +424,15 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     assert Co == Cout and Cin == C0 + C1
     M = B * H * W
     cm = split_weight_layout(H, W, Cout, k, M, Cin)
-    if cm == 2:
-        pw = _derived(weight, "_rac_transposed_split_l2", lambda: weight_frag_parts(weight, transposed=True))
+    if cm >= 2:
+        pw = _derived(weight, f"_rac_transposed_split_l{cm}",
+                      lambda: weight_frag_parts(weight, transposed=True, layout=cm))
     elif cm:
         pw = _derived(weight, f"_rac_transposed_split_l{cm}",
                       lambda: split_parts(_W_LAYOUT_FN[cm](transposed_weight(weight))))  # (Cin, Cout, k, k)
     else:
         pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(transposed_weight(weight))))
-    pd = dy.contiguous() if cm == 2 else split_parts(dy)  # layout 2: fp32 activations, split inside the kernel
+    pd = dy.contiguous() if cm >= 2 else split_parts(dy)  # layout 2: fp32 activations, split inside the kernel
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
     _split_launch(pd, None, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout, split_k=split,
@@ -568,7 +582,7 @@ class ConvBias(torch.autograd.Function):
         # the weights-direct split-precision kernels where the shape allows (the NormConvLSTM gate convs, the heads)
         ctx.split = (CONVBIAS_SPLIT and act == ACT_NONE and not padded and (SPLIT_GEMM if frozen else SPLIT_GEMM_TRAIN)
                      and x0.shape[3] % 32 == 0 and weight.shape[0] >= 128
-                     and split_weight_layout(H, W, ci, weight.shape[2], B * H * W, weight.shape[0]) == 2)
+                     and split_weight_layout(H, W, ci, weight.shape[2], B * H * W, weight.shape[0]) >= 2)
         if ctx.split:
             y = conv_forward_split(x0, x1, w, bias)
         else:

@@ -321,16 +321,17 @@ def test_cem_step_tail(dev, golden_dir):
         np.testing.assert_allclose(cost.cpu().numpy(), g[key].astype(np.float64), rtol=2e-6)
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 1, 2, 3])
 @pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 64, 160, 3), (4, 8, 8, 64, 64, 1024, 3)])
 def test_conv_split_precision_bf16x6(dev, case, layout, monkeypatch):
     """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe.  All three
-    kernels: tap-outer (layout 0, any shape), tap-inner with chunk-major weights through LDS (1) and tap-inner
-    with fragment-order weights loaded straight into the MFMA registers (2)."""
+    kernels: tap-outer (layout 0, any shape), tap-inner with chunk-major weights through LDS (1), tap-inner with
+    fragment-order weights loaded straight into the MFMA registers (2) and its 16x16x32 form (3)."""
     from robot_aware_control_amd import ops
     monkeypatch.setattr(ops, "TAPINNER_MIN_TILES", 0 if layout else 1 << 30)
-    monkeypatch.setattr(ops, "W_DIRECT", layout == 2)
+    monkeypatch.setattr(ops, "W_DIRECT", layout >= 2)
+    monkeypatch.setattr(ops, "MFMA16", layout == 3)
     B, H, W, C0, C1, Cout, k = case
     assert ops.split_weight_layout(H, W, C0 + C1, k, B * H * W, Cout) == layout
     Cin = C0 + C1
@@ -372,6 +373,9 @@ def test_weight_frag_split(dev, shape):
     w = cl_weight(rnd(5, co, ci, k, k)).to(dev)
     assert torch.equal(ops.weight_frag_parts(w), ops.split_parts(ops.frag_order(w)))
     assert torch.equal(ops.weight_frag_parts(w, transposed=True), ops.split_parts(ops.frag_order(ops.transposed_weight(w))))
+    assert torch.equal(ops.weight_frag_parts(w, layout=3), ops.split_parts(ops.frag_order16(w)))
+    assert torch.equal(ops.weight_frag_parts(w, transposed=True, layout=3),
+                       ops.split_parts(ops.frag_order16(ops.transposed_weight(w))))
     x = rnd(6, 4099, scale=3.0).to(dev)  # odd length: scalar kernel; first 4096: vector kernel
     pa, pb = ops.split_parts(x), ops.split_parts(x[:4096].clone())
     assert torch.equal(pa[:, :4096], pb)

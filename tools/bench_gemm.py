@@ -54,10 +54,10 @@ if mode == "fwd" and os.environ.get("RAC_BENCH_SPLIT"):
     ms = e0.elapsed_time(e1) / iters
     print(f"fwd-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective  "
           f"({flop / ms / 1e9 / 157.3 * 100:.1f}% of the fp32 MFMA peak, {6 * flop / ms / 1e9 / 2500 * 100:.1f}% of bf16 peak x6)", flush=True)
-    wl = int(os.environ.get('RAC_W_LAYOUT', '2'))
-    pw = ops.split_parts({1: ops.chunk_major, 2: ops.frag_order}[wl](w))
-    px, ph = (x, h) if wl == 2 else (ops.split_parts(x), ops.split_parts(h))  # layout 2 reads fp32 activations
-    aps = 0 if wl == 2 else px.shape[1]
+    wl = int(os.environ.get('RAC_W_LAYOUT', '3'))
+    pw = ops.split_parts({1: ops.chunk_major, 2: ops.frag_order, 3: ops.frag_order16}[wl](w))
+    px, ph = (x, h) if wl >= 2 else (ops.split_parts(x), ops.split_parts(h))  # layouts 2 / 3 read fp32 activations
+    aps = 0 if wl >= 2 else px.shape[1]
     import ctypes as C
     from robot_aware_control_amd._lib import ConvArgs, call, ptr, stream_ptr
     out = torch.empty((B, H, W, 4 * g), device=dev)
