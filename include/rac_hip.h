@@ -122,14 +122,17 @@ int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t
  * calls lay T time steps side by side along the pixel axis, and ONE rac_conv2d_wgrad_split over B*T images sums
  * their weight gradients.
  * layout 0: out[dxi][k][c][ld] rows.  layout 1 (C % 32 == 0): MFMA fragment order
- *   out[dxi][k][c / 32][p / 8][c mod 32][8 pixels]  (the B operand of rac_conv2d_wgrad_split with x_layout = 1). */
+ *   out[dxi][k][c / 32][p / 8][c mod 32][8 pixels]  (the B operand of rac_conv2d_wgrad_split with x_layout = 1 or 2).
+ * layout 2 (ndx = 1, C % 128 == 0, 32-pixel aligned): tile order out[k][c / 128][p / 32][(p mod 32) / 8][c mod 128][8],
+ *   the dy operand of rac_conv2d_wgrad_split with x_layout = 2 (each 8 KB block is that kernel's LDS image). */
 int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx, int64_t ld,
                         int32_t layout, int64_t p_off, void* stream);
 /* Weight gradient dw[co][tap][ci] += sum_p dy[p][co] x[p+tap][ci] on the split-precision pipe.
  * a->a0 / a->a1 = rac_transpose_split(x0 / x1, ndx = ksize) parts in layout `x_layout`, a->w =
  * rac_transpose_split(dy, ndx = 1, layout 0) parts, a->out0 = dw (fp32, accumulated in place), a->a_split = channels
  * of x0 (multiple of 128 when a1 is given), a->split_k = 0 picks it.  Needs W % 8 == 0.  x_layout = 1: the input
- * operand goes straight from L2 into the MFMA registers (needs both channel counts % 32 == 0). */
+ * operand goes straight from L2 into the MFMA registers (needs both channel counts % 32 == 0).  x_layout = 2: the
+ * same on v_mfma_f32_16x16x32_bf16 with a->w = rac_transpose_split(dy, layout 2) (needs Cout % 128 == 0 too). */
 int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, void* stream);
 
 /* ------------------------------------------------------------------------ *

@@ -1491,6 +1491,166 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_bdirect_kernel(WgradSplitP
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad_split_bdirect_kernel on v_mfma_f32_16x16x32_bf16 (x_layout 2).  dy^T comes in TILE ORDER
+// (rac_transpose_split layout 2): [part][Cout/128][P/32][8-pixel group 0..3][co mod 128][8 pixels], i.e. every
+// (Cout tile, K chunk, part) is one contiguous 8 KB block that IS the chunk-major LDS image of the A operand
+// (conflict-free for the 16-lane read groups of this instruction): staging is a linear, fully coalesced copy.
+// x^T stays in the fragment order of the 32x32x16 kernel; a lane loads column ci mod 16 (+16 nb) of pixel vector
+// 4 kc + (l >> 4).  8 x 2 accumulators of 16x16 per wave.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad_split_bdirect16_kernel(WgradSplitP p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];  // 2 x [part 3][group 4][128 rows][16 B]
+  constexpr int PPL = 4 * 128 * 16, ABUF = 3 * PPL;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  const int m0 = blockIdx.x * SBM;
+  const int tap = blockIdx.y / p.ntile_per_tap;
+  const int n0 = (blockIdx.y - tap * p.ntile_per_tap) * SBN;
+  const int ky = tap / p.ks, kx = tap - ky * p.ks;
+  const int dy = ky - p.pad;
+  const int kc_begin = blockIdx.z * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+
+  // block-uniform source of this channel range (virtual concat [x0 | x1])
+  const bool first = n0 < p.a_split;
+  const int Cs = first ? p.a_split : p.Cin - p.a_split;
+  const int nl0 = first ? n0 : n0 - p.a_split;
+  const long xps = (long)Cs * p.P;
+  const unsigned short* xbase = (first ? p.x0t : p.x1t) + (long)kx * 3 * xps;
+  const rsrc_t x_rsrc = mk_rsrc(xbase, (unsigned)(3 * xps * 2));
+  const long dps = (long)p.Cout * p.P;
+  const rsrc_t d_rsrc = mk_rsrc(p.dyt, (unsigned)(3 * dps * 2));
+
+  const int ct = (nl0 >> 5) + wid;
+  const bool n_live = (n0 + wid * 32 < p.Cin) & (ct * 32 < Cs);
+  const int R = p.P >> 3;
+  const int rshift = dy * p.wr;
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part) b_off[part] = (unsigned)(((long)ct * R * 32 + lr) * 16 + part * xps * 2);
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+    const int r = kc * 4 + lq;  // this lane's 8-pixel vector of the chunk
+    const int irow = r >> p.wr_shift;
+    const int img = (int)(((unsigned long long)(unsigned)irow * p.magic_hw) >> 40);
+    const int y = irow - img * p.H;
+    const bool ok = n_live & (kc < kc_end) & (r < R) & ((unsigned)(y + dy) < (unsigned)p.H);
+    const unsigned o = (unsigned)(r + rshift) * 512u;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) rb[part * 2 + nb] = ld16(x_rsrc, ok ? b_off[part] + o + nb * 256u : OOBS);
+  };
+
+  // dy^T: the (Cout tile, chunk, part) block of 512 vectors, two per thread
+  const unsigned a_tile = (unsigned)(((long)(m0 >> 7) * p.nchunks) * 8192);
+  u32x4 ra[6];
+  auto issue_a = [&](int kc) {
+    const bool ok = kc < kc_end;
+    const unsigned o = a_tile + (unsigned)kc * 8192u + (unsigned)tid * 16u;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        ra[part * 2 + i] = ld16(d_rsrc, ok ? o + i * 4096u + (unsigned)(part * dps * 2) : OOBS);
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * ABUF + part * PPL + i * 4096 + tid * 16) = ra[part * 2 + i];
+  };
+  const int abase = lq * 2048 + lr * 16;
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kc_begin < kc_end) {
+    u32x4 b0[6], b1[6], b2[6];
+    issue_a(kc_begin);
+    load_b(b0, kc_begin);
+    load_b(b1, kc_begin + 1);
+    store_a(0);
+    issue_a(kc_begin + 1);
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const int cur = (kc - kc_begin) & 1;
+      store_a(cur ^ 1);  // chunk kc + 1
+      issue_a(kc + 2);
+      const int aoff = cur * ABUF + abase;
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[nb][part] = __builtin_bit_cast(bf16x8, rb[part * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 fa[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            fa[t][part] = __builtin_bit_cast(
+                bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + aoff + (4 * h + t) * 256 + part * PPL));
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x4 c = acc[4 * h + t][nb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][2], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][0], c, 0, 0, 0);
+            acc[4 * h + t][nb] = c;
+          }
+      }
+      __syncthreads();
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 3) {
+      load_b(b2, kc + 2);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 3);
+        step(b1, kc + 1);
+      }
+      if (kc + 2 < kc_end) {
+        load_b(b1, kc + 4);
+        step(b2, kc + 2);
+      }
+    }
+  }
+
+  // dw[co][tap][ci] += acc: col = l & 15 (+16 nb) -> ci, rows 4 (l >> 4) + reg of each 16-row block -> co
+  const long wrow = (long)p.taps * p.Cin;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wid * 32 + nb * 16 + lr;
+    if (n >= p.Cin || (first && n >= p.a_split)) continue;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mb * 16 + 4 * lq + r;
+        if (m >= p.Cout) continue;
+        float* dst = p.dw + m * wrow + (long)tap * p.Cin + n;
+        if (p.split_k > 1)
+          atomicAdd(dst, acc[mb][nb][r]);
+        else
+          *dst += acc[mb][nb][r];
+      }
+  }
+}
+
 // out[dxi][part][c][p] = part-th bf16 part of (x in-row ? in[p + dx][c] : 0), dx = dxi - pad, dxi < ndx
 // (ndx = 1: plain transpose + split).  32x32 tiles through LDS: coalesced on both sides.
 __global__ void transpose_split_kernel(const float* in, unsigned short* out, int P, int C, int W, int ndx, int pad,
@@ -1570,6 +1730,35 @@ __global__ void transpose_split_frag_kernel(const float* in, unsigned short* out
     o[0] = __builtin_bit_cast(unsigned short, q1);
     o[ps] = __builtin_bit_cast(unsigned short, q2);
     o[2 * ps] = __builtin_bit_cast(unsigned short, q3);
+  }
+}
+
+// Tile-order variant for dy^T (layout 2, ndx = 1): out[part][c / 128][(p_off + p) / 32][(p mod 32) / 8][c mod 128][8],
+// the chunk-major A image of wgrad_split_bdirect16_kernel.  One 32 x 32 tile = four 512-byte runs.
+__global__ void transpose_split_tile_kernel(const float* in, unsigned short* out, int P, int C, long ld, long p_off) {
+  __shared__ float tile[32][33];
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pr = p0 + ty + 8 * i;
+    const int c = c0 + tx;
+    tile[ty + 8 * i][tx] = (pr < P && c < C) ? in[(long)pr * C + c] : 0.f;
+  }
+  __syncthreads();
+  const long ps = (long)C * ld;
+  const int j = threadIdx.x & 7, cl = threadIdx.x >> 3;
+  if (c0 + cl >= C) return;
+  const long blk = ((long)(c0 >> 7) * (ld >> 5) + ((p_off + p0) >> 5)) * 4096;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float a = tile[8 * g + j][cl];
+    unsigned short q1, q2, q3;
+    split3(a, q1, q2, q3);
+    unsigned short* o = out + blk + g * 1024 + ((c0 & 127) + cl) * 8 + j;
+    o[0] = q1;
+    o[ps] = q2;
+    o[2 * ps] = q3;
   }
 }
 
@@ -1852,7 +2041,14 @@ extern "C" int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int
                        reinterpret_cast<hipStream_t>(stream), x, out, P, C, W, ndx, ndx / 2, ldl, (long)p_off);
     return check_launch("rac_transpose_split(fragment order)");
   }
-  RAC_REQUIRE(layout == 0, "rac_transpose_split: layout must be 0 or 1");
+  if (layout == 2) {
+    RAC_REQUIRE(ndx == 1 && C % 128 == 0 && P % 32 == 0 && ldl % 32 == 0 && p_off % 32 == 0 && p_off + P <= ldl,
+                "rac_transpose_split: tile order is for dy (ndx 1), C % 128 == 0 and 32-pixel aligned ranges");
+    hipLaunchKernelGGL(transpose_split_tile_kernel, dim3(cdiv(P, 32), cdiv(C, 32)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, out, P, C, ldl, (long)p_off);
+    return check_launch("rac_transpose_split(tile order)");
+  }
+  RAC_REQUIRE(layout == 0, "rac_transpose_split: layout must be 0, 1 or 2");
   hipLaunchKernelGGL(transpose_split_kernel, dim3(cdiv(P, 32), cdiv(C, 32), ndx), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), x, out + p_off, P, C, W, ndx, ndx / 2, ldl);
   return check_launch("rac_transpose_split");
@@ -1919,6 +2115,28 @@ extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, 
     attr_done = true;
   }
   dim3 grid(cdiv(a->Cout, SBM), p.ntile_per_tap * p.taps, split);
+  if (x_layout == 2) {
+    const int c1 = a->Cin - p.a_split;
+    RAC_REQUIRE(p.a_split % 32 == 0 && c1 % 32 == 0 && p.P % 32 == 0 && a->Cout % 128 == 0,
+                "rac_conv2d_wgrad_split: x_layout 2 needs channel counts % 32 == 0, Cout % 128 == 0, pixels % 32 == 0");
+    p.wr = a->W / 8;
+    RAC_REQUIRE((p.wr & (p.wr - 1)) == 0, "rac_conv2d_wgrad_split: fragment-order inputs need W / 8 a power of two");
+    p.wr_shift = __builtin_ctz((unsigned)p.wr);
+    p.magic_hw = ((1ULL << 40) + a->H - 1) / a->H;
+    constexpr size_t lds_b16 = 2 * 3 * 4 * 128 * 16;  // 49,152 B
+    static bool b16_attr = false;
+    if (!b16_attr) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_split_bdirect16_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b16);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      b16_attr = true;
+    }
+    hipLaunchKernelGGL(wgrad_split_bdirect16_kernel, grid, dim3(256), lds_b16, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_wgrad_split(inputs direct, 16x16x32)");
+  }
   if (x_layout == 1) {
     const int c1 = a->Cin - p.a_split;
     RAC_REQUIRE(p.a_split % 32 == 0 && c1 % 32 == 0 && p.P % 8 == 0,
@@ -1941,7 +2159,7 @@ extern "C" int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, 
     hipLaunchKernelGGL(wgrad_split_bdirect_kernel, grid, dim3(256), lds_bd, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_wgrad_split(inputs direct)");
   }
-  RAC_REQUIRE(x_layout == 0, "rac_conv2d_wgrad_split: x_layout must be 0 or 1");
+  RAC_REQUIRE(x_layout == 0, "rac_conv2d_wgrad_split: x_layout must be 0, 1 or 2");
   hipLaunchKernelGGL(wgrad_split_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_wgrad_split");
 }

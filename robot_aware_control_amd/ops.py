@@ -504,12 +504,14 @@ def _wgrad_split_batch(items, weight):
     sp = stream_ptr()
     # inputs in MFMA fragment order (loaded straight into registers by the kernel) where the channel counts allow
     xl = 1 if (WGRAD_DIRECT and C0 % 32 == 0 and C1 % 32 == 0 and W % 8 == 0 and (W // 8) & (W // 8 - 1) == 0) else 0
+    if xl and MFMA16 and Cout % 128 == 0 and P % 32 == 0:
+        xl = 2  # 16x16x32 form: dy^T in tile order (the kernel's LDS image), same x^T fragment order
     for t, (dy_t, x0_t, x1_t) in enumerate(items):
         assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
-        call("rac_transpose_split", ptr(dy_t), ptr(dyt), P, Cout, W, 1, ld, 0, t * P, sp)
-        call("rac_transpose_split", ptr(x0_t), ptr(x0t), P, C0, W, k, ld, xl, t * P, sp)
+        call("rac_transpose_split", ptr(dy_t), ptr(dyt), P, Cout, W, 1, ld, 2 if xl == 2 else 0, t * P, sp)
+        call("rac_transpose_split", ptr(x0_t), ptr(x0t), P, C0, W, k, ld, min(xl, 1), t * P, sp)
         if C1:
-            call("rac_transpose_split", ptr(x1_t), ptr(x1t), P, C1, W, k, ld, xl, t * P, sp)
+            call("rac_transpose_split", ptr(x1_t), ptr(x1t), P, C1, W, k, ld, min(xl, 1), t * P, sp)
     if Cin != ci_real:
         g = torch.zeros((Cout, k, k, Cin), device=dev, dtype=torch.float32)
     else:

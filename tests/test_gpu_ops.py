@@ -415,13 +415,14 @@ def test_conv_split_rows_kernel(dev, case):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
-                                  (5, 4, 8, 32, 0, 64, 3)])
-@pytest.mark.parametrize("direct", [False, True])
+                                  (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3)])
+@pytest.mark.parametrize("direct", [0, 1, 2])
 def test_wgrad_split_precision(dev, case, direct, monkeypatch):
     """Weight gradient from transposed bf16 parts (dx-shifted input copies, dy as whole-vector offsets); both
     kernels: inputs through LDS, and inputs in fragment order loaded straight into the MFMA registers."""
     from robot_aware_control_amd import ops
-    monkeypatch.setattr(ops, "WGRAD_DIRECT", direct)
+    monkeypatch.setattr(ops, "WGRAD_DIRECT", direct > 0)   # 0: inputs through LDS, 1: direct (32x32x16),
+    monkeypatch.setattr(ops, "MFMA16", direct == 2)        # 2: direct on 16x16x32 where Cout % 128 == 0
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
     x = rnd(1, B, Cin, H, W)
