@@ -1196,6 +1196,237 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows_kernel(SplitP
 
 
 // ---------------------------------------------------------------------------------------------------------
+// igemm_split_bdirect_rows_kernel on v_mfma_f32_16x16x32_bf16 (weight layout 3, maps larger than a tile).
+// LDS image chunk-major: [part][8-channel group 0..3][staged pixel row 0..nrows+15][16 B], the 16 rows after the
+// staged range are zeros (x shifts that leave the image row).  TN = 4: waves 1 x 4 (128 rows x 32 columns each,
+// 8 x 2 accumulators of 16x16); TN = 2: waves 2 x 2 (64 rows x 32 columns, 4 x 2 accumulators).
+// ---------------------------------------------------------------------------------------------------------
+template <int NV, int TN>
+__global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(SplitP p) {
+  constexpr int MB = 2 * TN;       // 16-row blocks per wave
+  constexpr int BNW = TN * 32;     // columns per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {  // see igemm_split_tapinner_kernel
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int wn = wid % TN, wm = wid / TN;
+  const int m0 = bx * SBM, n0 = by * BNW;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  const int halo = p.pad * p.W;
+  const int nrows = SBM + 2 * halo;          // staged pixel rows (a multiple of 16)
+  const int cplane = (nrows + 16) * 16;      // one 8-channel group: staged rows + 16 zero rows
+  const int pplane = 4 * cplane;
+  if (tid < 3 * 4 * 16)
+    *reinterpret_cast<u32x4*>(lds_raw + (tid >> 6) * pplane + ((tid >> 4) & 3) * cplane + (nrows + (tid & 15)) * 16) =
+        u32x4{0u, 0u, 0u, 0u};
+
+  // staging: vector v = tid + 256 i -> 8-channel group v / nrows, staged row v % nrows (consecutive lanes =
+  // consecutive rows of one group: distinct bank slots)
+  const int y_tile = (m0 % p.HW) / p.W;
+  int s_off[NV], s_row[NV], s_grp[NV];
+  bool s_ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i;
+    const int g = v / nrows, row = v - g * nrows;
+    s_grp[i] = g;
+    s_row[i] = row;
+    s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
+    const int y = y_tile - p.pad + row / p.W;
+    s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
+  }
+  unsigned amask[MB];
+#pragma unroll
+  for (int t = 0; t < MB; ++t) {
+    const int r = (wm * MB + t) * 16 + lr;
+    const int x = r % p.W;
+    unsigned mk = 0;
+    for (int kx = 0; kx < p.ks; ++kx) mk |= ((unsigned)(x + kx - p.pad) < (unsigned)p.W) ? (1u << kx) : 0u;
+    amask[t] = mk;
+  }
+  const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;   // block t adds t * 256
+  const int zrow = lq * cplane + nrows * 16;
+  const int ntile = (n0 >> 5) + wn;
+  const rsrc_t w_rsrc = mk_rsrc(p.w, (unsigned)(3 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  unsigned b_off[3];
+#pragma unroll
+  for (int part = 0; part < 3; ++part)
+    b_off[part] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u +
+                  part * w_pstride;
+  auto load_b = [&](u32x4(&rb)[6], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int part = 0; part < 3; ++part)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        rb[part * 2 + nb] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[part] + nb * 1024u), so, 0));
+  };
+  u32x4 ra[2 * NV];
+  auto issue_a = [&](int cc) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = first ? c0 : c0 - p.a_split;
+    const rsrc_t a_rsrc = mk_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned oa = (unsigned)((m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      ra[2 * i] = ld16(a_rsrc, s_ok[i] ? oa : OOBS);
+      ra[2 * i + 1] = ld16(a_rsrc, s_ok[i] ? oa + 16u : OOBS);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (s_off[i] < 0) continue;
+      u32x4 q[3];
+      split8(ra[2 * i], ra[2 * i + 1], q);
+#pragma unroll
+      for (int part = 0; part < 3; ++part) *reinterpret_cast<u32x4*>(lds_raw + part * pplane + s_off[i]) = q[part];
+    }
+  };
+
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    bool fresh = true;
+    u32x4 b0[6], b1[6];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    store_a();
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[6], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
+      fresh = false;
+      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * 16 + abase;
+      const unsigned bit = 1u << kx;
+      bf16x8 fb[2][3];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) fb[nb][part] = __builtin_bit_cast(bf16x8, rb[part * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < MB / 4; ++h) {
+        bf16x8 fa[4][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int mb = 4 * h + t;
+          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zrow;
+#pragma unroll
+          for (int part = 0; part < 3; ++part)
+            fa[t][part] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x4 c = acc[4 * h + t][nb];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][2], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][0], fb[nb][0], c, 0, 0, 0);
+            acc[4 * h + t][nb] = c;
+          }
+      }
+      if (last_tap && more) {
+        __syncthreads();
+        store_a();
+        __syncthreads();
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 2) {
+      load_b(b1, kc + 1);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 2);
+        step(b1, kc + 1);
+      }
+    }
+  }
+
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wn * 32 + nb * 16 + lr;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * MB + mb) * 16 + 4 * lq + r;
+        if (m >= p.M || !nok) continue;
+        float v = acc[mb][nb][r];
+        if (slab) {
+          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        v += bias;
+        s1 += v;
+        s2 += v * v;
+        v = v * sc + sh;
+        if (p.act == RAC_ACT_LEAKY02)
+          v = v > 0.f ? v : 0.2f * v;
+        else if (p.act == RAC_ACT_SIGMOID)
+          v = sigmoid_acc(v);
+        p.out0[(long)m * p.N + n] = v;
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lq == 0 && nok) {
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient on the split-precision pipe.
 //   dw[co][tap][ci] += sum_p dy[p][co] * x[p + tap][ci]
 // The bf16 MFMA wants 8 consecutive k (= pixels) per lane for both operands, so both are consumed TRANSPOSED:
@@ -1936,7 +2167,7 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   // few M-tiles (training batch): the launch is bound by weight re-reads across XCDs unless they are grouped
   static const char* xg = getenv("RAC_XCD_GROUP");
   p.xcd_group = (xg ? atoi(xg) != 0 : (int)grid.x <= 32) && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
-  if (w_layout == 2 && p.HW > SBM) {
+  if (w_layout >= 2 && p.HW > SBM) {
     // maps larger than a tile: whole image rows per tile plus a halo (igemm_split_bdirect_rows_kernel)
     RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5 && a->Cin % SBK == 0 && p.taps > 1 && SBM % a->W == 0 &&
                     a->H % (SBM / a->W) == 0,
@@ -1946,15 +2177,20 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
     const int nrows = SBM + 2 * p.pad * a->W;
     const int nv = cdiv(nrows * 4, 256);
     RAC_REQUIRE(nv >= 2 && nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
-    const size_t lds_rows = (size_t)3 * (nrows + 1) * BD_ROW;
+    const bool m16 = w_layout == 3;
+    const size_t lds_rows = m16 ? (size_t)3 * 4 * (nrows + 16) * 16 : (size_t)3 * (nrows + 1) * BD_ROW;
     static bool rows_attr = false;
     typedef void (*rows_fn)(SplitP);
-    static const rows_fn fns[2][3] = {
+    static const rows_fn fns[4][3] = {
         {igemm_split_bdirect_rows_kernel<2, 4>, igemm_split_bdirect_rows_kernel<3, 4>, igemm_split_bdirect_rows_kernel<4, 4>},
-        {igemm_split_bdirect_rows_kernel<2, 2>, igemm_split_bdirect_rows_kernel<3, 2>, igemm_split_bdirect_rows_kernel<4, 2>}};
+        {igemm_split_bdirect_rows_kernel<2, 2>, igemm_split_bdirect_rows_kernel<3, 2>, igemm_split_bdirect_rows_kernel<4, 2>},
+        {igemm_split_bdirect_rows16_kernel<2, 4>, igemm_split_bdirect_rows16_kernel<3, 4>,
+         igemm_split_bdirect_rows16_kernel<4, 4>},
+        {igemm_split_bdirect_rows16_kernel<2, 2>, igemm_split_bdirect_rows16_kernel<3, 2>,
+         igemm_split_bdirect_rows16_kernel<4, 2>}};
     if (!rows_attr) {
       const int max_lds = 3 * (256 + 1) * BD_ROW;
-      for (int i = 0; i < 6; ++i) {
+      for (int i = 0; i < 12; ++i) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i / 3][i % 3]),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (e != hipSuccess) {
@@ -1968,11 +2204,11 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
     const int narrow = p.N <= 64 ? 1 : 0;
     if (narrow) grid.y = cdiv(p.N, 64);
     p.xcd_group = p.xcd_group && (grid.y * grid.z) % 8 == 0;
-    hipLaunchKernelGGL(fns[narrow][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(fns[narrow + (m16 ? 2 : 0)][nv - 2], grid, dim3(256), lds_rows,
+                       reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(weights direct, image rows)");
   }
   if (w_layout == 3) {
-    RAC_REQUIRE(p.HW <= SBM, "rac_conv2d_fwd_split: w_layout 3 serves maps of at most 128 pixels");
     RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,
                 "rac_conv2d_fwd_split: fragment-order weights need Cout % 32 == 0 and k <= 5");
     RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");

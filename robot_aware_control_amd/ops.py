@@ -312,7 +312,7 @@ def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int
     direct = W_DIRECT and N % 32 == 0 and Cin % 32 == 0 and 1 < k <= 5
     if H * W > 128:  # maps larger than a tile: whole image rows per tile + halo, fragment-order weights only
         rows_ok = 128 % W == 0 and H % (128 // W) == 0 and (128 + 2 * (k // 2) * W) * 4 <= 1024
-        return 2 if (direct and ROWS_KERNEL and rows_ok) else 0
+        return (3 if MFMA16 else 2) if (direct and ROWS_KERNEL and rows_ok) else 0
     if not tapinner_ok(H, W, Cin, k, M, N):
         return 0
     if direct:

@@ -384,13 +384,15 @@ def test_weight_frag_split(dev, shape):
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 96, 3), (1, 32, 32, 64, 0, 128, 3), (3, 16, 16, 32, 0, 64, 5),
                                   (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3), (1, 64, 64, 64, 64, 64, 3)])
-def test_conv_split_rows_kernel(dev, case):
+@pytest.mark.parametrize("m16", [False, True])
+def test_conv_split_rows_kernel(dev, case, m16, monkeypatch):
     """Weights-direct kernel on maps larger than a tile (whole image rows per tile + halo) against fp64, forward and
     data gradient, and bit-identical sums with the tap-outer kernel's exactness test (small integers)."""
     from robot_aware_control_amd import ops
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
-    assert ops.split_weight_layout(H, W, Cin, k, B * H * W, Cout) == 2 and H * W > 128
+    monkeypatch.setattr(ops, "MFMA16", m16)  # 32x32x16 (weight layout 2) or 16x16x32 (layout 3) form of the kernel
+    assert ops.split_weight_layout(H, W, Cin, k, B * H * W, Cout) == (3 if m16 else 2) and H * W > 128
     g = np.random.Generator(np.random.Philox(key=[11, 9]))
     xi = torch.from_numpy(g.integers(-3, 4, (B, Cin, H, W)).astype(np.float32))
     wi = torch.from_numpy(g.integers(-3, 4, (Cout, Cin, k, k)).astype(np.float32))
