@@ -286,7 +286,7 @@ def main():
         if k is None:  # no launch of the profiled shape (e.g. --group-norm: separate ih / hh gate convs)
             k = {"split": False, "tflops": train["step_tflops_per_gpu"], "avg_ms": None, "launches": 0}
         gr = gate_roofline(k)
-        kname = "igemm_split_bdirect_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128"
+        kname = "igemm_split_bdirect16_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128"
         # PMC pass over exactly this launch (tools/bench_gemm.py at the same shape; tools/run_profiles.sh)
         traffic, traffic_src = pmc_traffic("gemm_train", kname, 512)
         out["roofline"] = {"bound": "mfma", "kernel": "FWD 5x5 ConvLSTM gate GEMM (M=1024,N=2048,K=25600), " + gr["dtype"],
@@ -304,7 +304,7 @@ def main():
         gate = {"avg_launch_ms": k["avg_ms"], "tflops": k["tflops"], "launches": k["launches"]}
         gate.update(gate_roofline(k))
         gate["traffic"], gate["traffic_source"] = pmc_traffic(
-            "gemm_cem", "igemm_split_bdirect_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128",
+            "gemm_cem", "igemm_split_bdirect16_kernel" if k["split"] else "igemm_fast_kernel<0, 128, 128",
             _cdiv(cem["candidates_batch_size"] * 64, 128) * 16)
         cem_obj = {"value": cem["rollouts_per_s"], "unit": "candidate-rollouts/s", "s_per_iteration": cem["s_per_iter"],
                    "config": {"workload": "CEM rollouts, BASELINE configs[2]: 1000 candidates/GPU x horizon 15 "
