@@ -129,11 +129,15 @@ def profile_summary(prof, flops_per_pixel_row):
 
 def bench_train(args, dev, rank, world, distributed):
     cf = namespace(dev, lstm_group_norm=args.group_norm)
+    if args.cfg5:  # BASELINE configs[4] per GPU: 128x128 frames, 8 samples, 10 predicted frames (16x16 latent maps)
+        cf.image_width = cf.image_height = 128
+        cf.batch_size, cf.n_future = 8, 10
     log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
     tr.model.train()
     B, T = cf.batch_size, cf.n_past + cf.n_future
-    batches = [syn.synth_video(seed=100 + rank * 1000 + i, T=T, B=B) for i in range(2)]
+    batches = [syn.synth_video(seed=100 + rank * 1000 + i, T=T, B=B, H=cf.image_height, W=cf.image_width)
+               for i in range(2)]
     batches = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     for i in range(3):  # prime the caching allocator (new tensor sizes cost a hipMalloc + sync each); not a warmup step
         tr._train_step(batches[i % 2])
@@ -156,7 +160,8 @@ def bench_train(args, dev, rank, world, distributed):
     log(f"train: {args.steps} steps in {dt:.3f} s")
     ops.PROFILE = None
     frames = world * B * T * args.steps
-    step_flop = 3 * B * (T - 1) * TRAIN_FWD_GFLOP_PER_SAMPLE_STEP * 1e9
+    fwd_gflop = 145.03 if args.cfg5 else TRAIN_FWD_GFLOP_PER_SAMPLE_STEP  # 128x128 / 64x64 train forward
+    step_flop = 3 * B * (T - 1) * fwd_gflop * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
     return {"frames_per_s": frames / dt, "ms_per_step": dt / args.steps * 1e3,
             "step_tflops_per_gpu": step_flop / (dt / args.steps) / 1e12, "kernel": kern,
@@ -242,6 +247,8 @@ def main():
     ap.add_argument("--cem-iters", type=int, default=2)
     ap.add_argument("--cem-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="train workload at BASELINE configs[4] per-GPU size (128x128, bs 8, n_future 10); not the headline")
     ap.add_argument("--group-norm", action="store_true",
                     help="train workload with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
     args = ap.parse_args()
