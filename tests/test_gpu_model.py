@@ -312,6 +312,37 @@ def test_cem_rollout_options_vs_oracle(dev, sparse):
     assert np.abs(ro["optimal_obs"] - ref["obs_all"][N]).max() < 1e-4
 
 
+def test_cli_train_loop_synthetic(dev, tmp_path, monkeypatch):
+    """`python -m src.prediction.multirobot_trainer` with the README's flag style on `--data_root synthetic`: two epochs
+    of two videos (each split into windows by _train_video, random snippets, scheduled sampling on), checkpoint written
+    and discovered again on resume (trainer.py:736-897)."""
+    import sys
+    from src.prediction import multirobot_trainer as cli
+    argv = ("prog --jobname t --wandb False --data_root synthetic --batch_size 2 --n_future 2 --n_past 1 --n_eval 3 "
+            "--g_dim 32 --z_dim 8 --model svg --niter 2 --epoch_size 2 --checkpoint_interval 1 --eval_interval 10 "
+            "--reconstruction_loss dontcare_l1 --last_frame_skip True --scheduled_sampling True --action_dim 5 "
+            "--robot_dim 5 --data_threads 0 --lr 0.0001 --experiment train_robonet --model_use_robot_state True "
+            "--model_use_mask True --model_use_future_mask True --random_snippet True --video_length 7 "
+            f"--log_dir {tmp_path}").split()
+    monkeypatch.setattr(sys, "argv", argv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    cli.main()
+    ckpts = sorted(os.listdir(os.path.join(tmp_path, "t")))
+    assert any(f.startswith("ckpt_") and f.endswith(".pt") for f in ckpts), ckpts
+    last = max(int(f[5:-3]) for f in ckpts if f.startswith("ckpt_"))
+    ck = torch.load(os.path.join(tmp_path, "t", f"ckpt_{last}.pt"), map_location="cpu")
+    assert set(ck) == {"model", "optimizer", "step"} and ck["step"] == last > 0
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.is_floating_point())
+    # resume: the newest checkpoint of log_dir is discovered and its step restored
+    monkeypatch.setattr(sys, "argv", argv)
+    from robot_aware_control_amd.config import argparser
+    from robot_aware_control_amd.trainer import PredictionTrainer
+    cfg, _ = argparser(argv[1:])
+    cli.make_log_folder(cfg)
+    tr = PredictionTrainer(cfg)
+    assert tr._load_checkpoint(None) == last
+
+
 SWEEP = [
     dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
          reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
