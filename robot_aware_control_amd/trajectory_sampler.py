@@ -12,6 +12,7 @@ elite selection.
 """
 from __future__ import annotations
 
+import os
 import time as timer
 from collections import defaultdict
 
@@ -58,6 +59,10 @@ class TrajectorySampler(object):
         self.high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
         self.robot_model = robot_model
         self._robot_ctor = (cam_ext, franka_ik, wx250s_bot, push_height, default_pitch, default_roll)
+        if os.environ.get("RAC_GC_FREEZE", "1") == "1":  # see PredictionTrainer.__init__: no full-GC walks of the model
+            import gc
+            gc.collect()
+            gc.freeze()
 
     def _needs_robot(self):
         cfg = self.cfg
