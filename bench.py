@@ -258,11 +258,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     distributed = world > 1
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    backend = os.environ.get("RAC_DIST_BACKEND", "nccl")  # "gloo" + RAC_BENCH_ONE_GPU=1: rehearse N ranks on one GPU
+    if os.environ.get("RAC_BENCH_ONE_GPU") == "1":
+        local = 0
+        os.environ["LOCAL_RANK"] = "0"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     torch.manual_seed(1234)
 
     out = {"metric": "SVG train frames/sec + CEM candidate-rollouts/sec, 64x64", "n_gpus": world,
