@@ -199,11 +199,21 @@ def bench_cem(args, dev, rank, world, distributed, model=None):
     log(f"cem: {args.cem_iters} iterations in {dt:.3f} s")
     ops.PROFILE = None
     assert len(ro["sum_cost"]) == N and np.all(np.isfinite(ro["sum_cost"]))
+    # secondary metric: the whole planner call -- sampling, rollouts, cost gather, top-k, refit --
+    # at a reduced iteration count (the per-iteration cost does not depend on it)
+    pol.optimization_iter = 2
+    barrier_sync(distributed)
+    t1 = time.perf_counter()
+    pol.get_action(start, goal, 0, 0)
+    barrier_sync(distributed)
+    dt_ga = max_over_ranks(time.perf_counter() - t1, dev, distributed)
     it_flop_per_gpu = n_per_gpu * (horizon - 1) * CEM_FWD_GFLOP_PER_CAND_STEP * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
     return {"rollouts_per_s": N * args.cem_iters / dt, "s_per_iter": dt / args.cem_iters,
             "tflops_per_gpu": it_flop_per_gpu / (dt / args.cem_iters) / 1e12, "kernel": kern, "candidates": N,
-            "candidates_batch_size": args.cem_batch}
+            "candidates_batch_size": args.cem_batch,
+            "get_action": {"value": N * 2 / dt_ga, "unit": "candidate-rollouts/s", "opt_iter": 2,
+                           "note": "CEMPolicy.get_action end to end (sampling, rollouts, cost gather, top-k, refit)"}}
 
 
 def cpu_baseline(train_state_dict, args):
@@ -327,7 +337,7 @@ def main():
                               "parallelism": f"candidate-shard{world}"},
                    "achieved_tflops_per_gpu": cem["tflops_per_gpu"],
                    "frac_of_f32_mfma_peak": cem["tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS,
-                   "gate_gemm": gate}
+                   "gate_gemm": gate, "get_action": cem["get_action"]}
         if train is None:
             out.update(value=cem["rollouts_per_s"], unit="candidate-rollouts/s", ms_per_step=cem["s_per_iter"] * 1e3,
                        config=cem_obj["config"],
