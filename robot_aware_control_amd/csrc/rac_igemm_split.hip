@@ -857,8 +857,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
-      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * 16 + cur * B16_ABUF + abase;
-      const int zr = zrow + cur * B16_ABUF;
+      const int drow = (ky - p.pad) * p.W + (kx - p.pad);
+      const int shift = drow * 16 + cur * B16_ABUF + abase;
+      // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
+      // would have used, so that the read group stays conflict-free
+      const int zr = zrow + cur * B16_ABUF + ((lr + drow) & 15) * 16;
       const unsigned bit = 1u << tap;
       bf16x8 fb[2][3];
 #pragma unroll
@@ -1322,7 +1325,9 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
-      const int shift = ((ky - p.pad) * p.W + (kx - p.pad)) * 16 + abase;
+      const int drow = (ky - p.pad) * p.W + (kx - p.pad);
+      const int shift = drow * 16 + abase;
+      const int zr = zrow + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
       const unsigned bit = 1u << kx;
       bf16x8 fb[2][3];
 #pragma unroll
@@ -1335,7 +1340,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
-          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zrow;
+          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
           for (int part = 0; part < 3; ++part)
             fa[t][part] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
