@@ -171,7 +171,8 @@ def bench_train(args, dev, rank, world, distributed):
 def bench_cem(args, dev, rank, world, distributed, model=None):
     n_per_gpu, horizon = args.cem_candidates, 15
     cf = namespace(dev, model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
-                   reconstruction_loss="l1", candidates_batch_size=args.cem_batch, batch_size=args.cem_batch)
+                   reconstruction_loss="l1", candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
+                   lstm_group_norm=args.group_norm)
     model = SVGConvModel(cf)
     if distributed:
         dist.broadcast(model.flat_parameters()[0], src=0)
@@ -260,7 +261,7 @@ def main():
     ap.add_argument("--cfg5", action="store_true",
                     help="train workload at BASELINE configs[4] per-GPU size (128x128, bs 8, n_future 10); not the headline")
     ap.add_argument("--group-norm", action="store_true",
-                    help="train workload with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
+                    help="both workloads with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -325,6 +326,8 @@ def main():
             out["roofline"]["bf16_mfma_issue_frac"] = gr["bf16_mfma_issue_frac"]
     if cem is not None:
         k = cem["kernel"]
+        if k is None:  # no launch of the profiled shape (--group-norm: separate ih / hh gate convs)
+            k = {"split": False, "tflops": cem["tflops_per_gpu"], "avg_ms": None, "launches": 0}
         gate = {"avg_launch_ms": k["avg_ms"], "tflops": k["tflops"], "launches": k["launches"]}
         gate.update(gate_roofline(k))
         gate["traffic"], gate["traffic_source"] = pmc_traffic(
