@@ -129,6 +129,8 @@ def profile_summary(prof, flops_per_pixel_row):
 
 def bench_train(args, dev, rank, world, distributed):
     cf = namespace(dev, lstm_group_norm=args.group_norm)
+    if args.h48:  # the reference's default frame size (config/__init__.py:166-171): 48 x 64 -> 6 x 8 latent maps
+        cf.image_height = 48
     if args.cfg5:  # BASELINE configs[4] per GPU: 128x128 frames, 8 samples, 10 predicted frames (16x16 latent maps)
         cf.image_width = cf.image_height = 128
         cf.batch_size, cf.n_future = 8, 10
@@ -161,6 +163,8 @@ def bench_train(args, dev, rank, world, distributed):
     ops.PROFILE = None
     frames = world * B * T * args.steps
     fwd_gflop = 145.03 if args.cfg5 else TRAIN_FWD_GFLOP_PER_SAMPLE_STEP  # 128x128 / 64x64 train forward
+    if args.h48:
+        fwd_gflop *= 48.0 / 64.0  # every conv's FLOPs scale with the pixel count
     step_flop = 3 * B * (T - 1) * fwd_gflop * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
     return {"frames_per_s": frames / dt, "ms_per_step": dt / args.steps * 1e3,
@@ -258,6 +262,8 @@ def main():
     ap.add_argument("--cem-iters", type=int, default=2)
     ap.add_argument("--cem-warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--h48", action="store_true",
+                    help="train workload on 48x64 frames, the reference's default --image_height (not the headline)")
     ap.add_argument("--cfg5", action="store_true",
                     help="train workload at BASELINE configs[4] per-GPU size (128x128, bs 8, n_future 10); not the headline")
     ap.add_argument("--group-norm", action="store_true",

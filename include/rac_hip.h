@@ -112,7 +112,8 @@ int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t
  *       are plain fp32 [pixels][C] maps (a0_part_stride = a1_part_stride = 0): the kernel splits them on the way
  *       into LDS, no rac_split_bf16x3 pass.  Also serves maps larger than a tile (H*W > 128) when W divides 128
  *       and H is a multiple of 128 / W (image rows + halo per tile), and N <= 64 (64-column workgroups).
- *   3 = as 2 for the v_mfma_f32_16x16x32_bf16 form of the same kernel (H*W dividing 128 only):
+ *   3 = as 2 for the v_mfma_f32_16x16x32_bf16 form of the same kernels; for H*W <= 128 the workgroup tile is
+ *       (128 / (H*W)) * H*W rows, which must be a multiple of 16 (so 6x8 maps work: 96 rows):
  *       [Cout/32][Cin/32][k*k][nb 2][lane 64][8] with lane = 16 q + (co mod 16), co = 32 tile + 16 nb + lane mod 16,
  *       ci = 32 chunk + 8 q + j.  The chip holds a higher clock on that instruction under this load. */
 /* Transposed bf16 parts for the split-precision weight gradient:

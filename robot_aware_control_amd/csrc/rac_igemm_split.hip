@@ -27,6 +27,7 @@ struct SplitP {
   int M, N, HW, P, taps, cchunks, nchunks, cps;
   int w_chunk_major;  // weights stored [Cout][Cin/32][taps][32] (tap-inner streaming order) instead of [Cout][taps][Cin]
   int xcd_group;      // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
+  int tile_m;         // igemm_split_bdirect16_kernel: output rows per workgroup (whole images, multiple of 16, <= 128)
 };
 
 constexpr unsigned OOBS = 0xFFFFFFF0u;
@@ -741,6 +742,8 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_kernel(SplitP p) {
 //   B operand: lane l holds column l & 15, k = 8 (l >> 4) .. +7 -> weights in the matching fragment order
 //     [part][Cout/32][Cin/32][tap][nb 0..1][lane][8]  (nb = 16-column half of the wave's 32 columns).
 //   C: 8 x 2 accumulators of 16x16 per wave (128 rows x 32 columns), col = l & 15, row = 4 (l >> 4) + reg.
+//   Rows per workgroup = the largest whole number of images within 128 pixels that is a multiple of 16 (128 for 8x8
+//   maps, 96 = two 6x8 maps of 48x64 frames): blocks past it are skipped.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int B16_CP = 144 * 16, B16_PP = 4 * B16_CP, B16_ABUF = 3 * B16_PP;  // chunk plane, part plane, buffer (bytes)
 
@@ -760,7 +763,11 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
     by = grp % nt;
     bz = grp / nt;
   }
-  const int m0 = bx * SBM, n0 = by * SBN;
+  // rows per workgroup: the largest whole number of images that fits 128 pixels (128 for the 8x8 maps, 96 = two
+  // images for the reference's default 48x64 frames, whose latent maps are 6x8), a multiple of 16
+  const int TM = p.tile_m;
+  const int nmb = TM >> 4;  // live 16-row blocks of the wave's 8
+  const int m0 = bx * TM, n0 = by * SBN;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   // zero rows 128..143 of every chunk plane of both buffers: 2 * 3 * 4 * 16 = 384 vectors
@@ -773,12 +780,12 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
   // staging: thread -> row tid & 127, chunks (tid >> 7) and (tid >> 7) + 2 (8 consecutive lanes = 8 rows of one
   // chunk plane: distinct bank slots on the ds_write side too)
   const int srow = tid & 127, sch = tid >> 7;
-  const bool a_ok = m0 + srow < p.M;
+  const bool a_ok = (srow < TM) & (m0 + srow < p.M);
   // fragment rows of this lane (eight 16-row blocks): one bit per tap and block for the shifted pixel's validity
   unsigned amask[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
-    const int r = t * 16 + lr;
+    const int r = t * 16 + lr;  // blocks t >= nmb are never used
     const int im = r / p.HW;
     const int q = r - im * p.HW;
     const int y = q / p.W, x = q - y * p.W;
@@ -874,6 +881,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
+          if (mb >= nmb) continue;  // wave-uniform
           const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
           for (int part = 0; part < 3; ++part)
@@ -883,6 +891,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
+            if (4 * h + t >= nmb) continue;
             f32x4 c = acc[4 * h + t][nb];
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][2], fb[nb][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][1], c, 0, 0, 0);
@@ -939,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect16_kernel(SplitP p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + mb * 16 + 4 * lq + r;
-        if (m >= p.M || !nok) continue;
+        if (mb >= nmb || m >= p.M || !nok) continue;
         float v = acc[mb][nb][r];
         if (slab) {
           p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
@@ -2122,7 +2131,7 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   p.out0 = a->out0;
   p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
   p.stats_rows = a->stats ? a->stats_rows : 0;
-  RAC_REQUIRE(p.stats_rows >= 0 && p.stats_rows % 128 == 0 &&
+  RAC_REQUIRE(p.stats_rows >= 0 && (p.stats_rows % 128 == 0 || w_layout == 3) &&
                   (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
               "rac_conv2d_fwd_split: stats_rows must be a multiple of 128 that divides B*H*W");
   p.HW = a->H * a->W;
@@ -2166,7 +2175,7 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   RAC_REQUIRE(w_layout >= 0 && w_layout <= 3, "rac_conv2d_fwd_split: w_layout must be 0 .. 3");
   const bool w_chunk_major = w_layout == 1;
   RAC_REQUIRE(w_layout == 0 || (w_layout >= 2 && p.HW > SBM) ||
-                  (a->Cin % SBK == 0 && p.HW <= SBM && SBM % p.HW == 0 && p.taps > 1),
+                  (a->Cin % SBK == 0 && p.HW <= SBM && (SBM % p.HW == 0 || w_layout == 3) && p.taps > 1),
               "rac_conv2d_fwd_split: chunk-major / fragment-order weights need Cin % 32 == 0, k > 1 and whole images "
               "per 128-pixel tile");
   // XCD x runs the (N-tile, K-slab) columns x, x+8, ...: with few M-tiles (training batch) the launch is otherwise
@@ -2218,6 +2227,11 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   if (w_layout == 3) {
     RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5,
                 "rac_conv2d_fwd_split: fragment-order weights need Cout % 32 == 0 and k <= 5");
+    p.tile_m = (SBM / p.HW) * p.HW;  // whole images per workgroup
+    RAC_REQUIRE(p.tile_m % 16 == 0, "rac_conv2d_fwd_split: w_layout 3 needs (128 / (H*W)) * H*W to be a multiple of 16");
+    RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
+    grid.x = cdiv(p.M, p.tile_m);
+    p.xcd_group = p.xcd_group && grid.x > 1;
     RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
     constexpr size_t lds_b16 = 2 * B16_ABUF;  // 55,296 B
     static bool b16_attr = false;

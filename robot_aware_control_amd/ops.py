@@ -313,11 +313,13 @@ def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int
     if H * W > 128:  # maps larger than a tile: whole image rows per tile + halo, fragment-order weights only
         rows_ok = 128 % W == 0 and H % (128 // W) == 0 and (128 + 2 * (k // 2) * W) * 4 <= 1024
         return (3 if MFMA16 else 2) if (direct and ROWS_KERNEL and rows_ok) else 0
+    if direct and MFMA16 and ((128 // (H * W)) * H * W) % 16 == 0 and _cdiv(M, 128) * _cdiv(N, 128) >= TAPINNER_MIN_TILES:
+        # the 16x16x32 form (higher sustained clock); its tile is any whole number of images that is a multiple of 16
+        # rows, e.g. 96 = two 6x8 maps of the reference's default 48x64 frames
+        return 3
     if not tapinner_ok(H, W, Cin, k, M, N):
         return 0
-    if direct:
-        return 3 if MFMA16 else 2  # the 16x16x32 form of the same kernel: higher sustained clock
-    return 1
+    return 2 if direct else 1
 
 
 def frag_order16(w: torch.Tensor) -> torch.Tensor:
@@ -795,7 +797,9 @@ class TileCat(torch.autograd.Function):
         c1 = m1.shape[3] if m1 is not None else 0
         ct = sum(ns) + c0 + c1
         pad = pad4(ct)
-        if (SPLIT_GEMM if frozen else (SPLIT_GEMM_TRAIN and PAD32_TRAIN)) and PAD32_INPUT_CONVS and ct >= 128 and 128 % (H * W) == 0:
+        hw = H * W
+        whole = hw <= 128 and (128 % hw == 0 or (MFMA16 and ((128 // hw) * hw) % 16 == 0))  # whole-image tiles exist
+        if (SPLIT_GEMM if frozen else (SPLIT_GEMM_TRAIN and PAD32_TRAIN)) and PAD32_INPUT_CONVS and ct >= 128 and whole:
             pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
