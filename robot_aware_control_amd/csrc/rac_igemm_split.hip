@@ -1233,11 +1233,15 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
     bz = grp / nt;
   }
   const int wn = wid % TN, wm = wid / TN;
-  const int m0 = bx * SBM, n0 = by * BNW;
+  // rows per workgroup: R whole image rows with R | H, R * W <= 128 and a multiple of 16 (128 for 16x16 / 32x32 /
+  // 64x64 maps; 96 = six rows of the 12x16 maps of 48x64 frames)
+  const int TM = p.tile_m;
+  const int nmb = TM >> 4;  // live 16-row blocks of the workgroup
+  const int m0 = bx * TM, n0 = by * BNW;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   const int halo = p.pad * p.W;
-  const int nrows = SBM + 2 * halo;          // staged pixel rows (a multiple of 16)
+  const int nrows = TM + 2 * halo;           // staged pixel rows (a multiple of 16)
   const int cplane = (nrows + 16) * 16;      // one 8-channel group: staged rows + 16 zero rows
   const int pplane = 4 * cplane;
   if (tid < 3 * 4 * 16)
@@ -1349,6 +1353,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
+          if (wm * MB + mb >= nmb) continue;  // wave-uniform: past the tile's rows
           const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
           for (int part = 0; part < 3; ++part)
@@ -1358,6 +1363,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int nb = 0; nb < 2; ++nb) {
+            if (wm * MB + 4 * h + t >= nmb) continue;
             f32x4 c = acc[4 * h + t][nb];
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][2], fb[nb][0], c, 0, 0, 0);
             c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[t][1], fb[nb][1], c, 0, 0, 0);
@@ -1409,7 +1415,7 @@ __global__ __launch_bounds__(256, 2) void igemm_split_bdirect_rows16_kernel(Spli
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (wm * MB + mb) * 16 + 4 * lq + r;
-        if (m >= p.M || !nok) continue;
+        if (wm * MB + mb >= nmb || m >= p.M || !nok) continue;
         float v = acc[mb][nb][r];
         if (slab) {
           p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
@@ -2184,15 +2190,25 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_ps, int64
   static const char* xg = getenv("RAC_XCD_GROUP");
   p.xcd_group = (xg ? atoi(xg) != 0 : 1) && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
   if (w_layout >= 2 && p.HW > SBM) {
-    // maps larger than a tile: whole image rows per tile plus a halo (igemm_split_bdirect_rows_kernel)
-    RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5 && a->Cin % SBK == 0 && p.taps > 1 && SBM % a->W == 0 &&
-                    a->H % (SBM / a->W) == 0,
-                "rac_conv2d_fwd_split: fragment-order weights on large maps need W dividing 128, H a multiple of "
-                "128 / W, channel counts % 32 == 0 and 1 < k <= 5");
+    // maps larger than a tile: whole image rows per tile plus a halo (igemm_split_bdirect_rows*_kernel)
+    RAC_REQUIRE(a->Cout % 32 == 0 && a->ksize <= 5 && a->Cin % SBK == 0 && p.taps > 1,
+                "rac_conv2d_fwd_split: fragment-order weights on large maps need channel counts % 32 == 0, 1 < k <= 5");
+    int rows = 0;  // image rows per tile: R | H, R * W <= 128; the 32x32x16 form needs exactly 128 pixels
+    for (int r = SBM / a->W; r >= 1; --r)
+      if (a->H % r == 0 && (r * a->W) % 16 == 0) {
+        rows = r;
+        break;
+      }
+    p.tile_m = rows * a->W;
+    RAC_REQUIRE(rows > 0 && a->W <= SBM && (w_layout == 3 || p.tile_m == SBM),
+                "rac_conv2d_fwd_split: no whole-row tile for this map (W must be <= 128; layout 2 needs W | 128 and "
+                "H a multiple of 128 / W)");
+    RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
     RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
-    const int nrows = SBM + 2 * p.pad * a->W;
-    const int nv = cdiv(nrows * 4, 256);
-    RAC_REQUIRE(nv >= 2 && nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
+    grid.x = cdiv(p.M, p.tile_m);
+    const int nrows = p.tile_m + 2 * p.pad * a->W;
+    const int nv = cdiv(nrows * 4, 256) < 2 ? 2 : cdiv(nrows * 4, 256);
+    RAC_REQUIRE(nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
     const bool m16 = w_layout == 3;
     const size_t lds_rows = m16 ? (size_t)3 * 4 * (nrows + 16) * 16 : (size_t)3 * (nrows + 1) * BD_ROW;
     static bool rows_attr = false;

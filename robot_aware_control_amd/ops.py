@@ -311,8 +311,13 @@ def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int
     """Weight layout (w_layout of rac_conv2d_fwd_split) for a conv of this shape."""
     direct = W_DIRECT and N % 32 == 0 and Cin % 32 == 0 and 1 < k <= 5
     if H * W > 128:  # maps larger than a tile: whole image rows per tile + halo, fragment-order weights only
+        if not (direct and ROWS_KERNEL and W <= 128):
+            return 0
+        if MFMA16:  # R image rows per tile: R | H, R * W <= 128 and a multiple of 16 (96 = 6 rows of a 12x16 map)
+            tm = max([r * W for r in range(1, 128 // W + 1) if H % r == 0 and (r * W) % 16 == 0], default=0)
+            return 3 if (tm and (tm + 2 * (k // 2) * W) * 4 <= 1024) else 0
         rows_ok = 128 % W == 0 and H % (128 // W) == 0 and (128 + 2 * (k // 2) * W) * 4 <= 1024
-        return (3 if MFMA16 else 2) if (direct and ROWS_KERNEL and rows_ok) else 0
+        return 2 if rows_ok else 0
     if direct and MFMA16 and ((128 // (H * W)) * H * W) % 16 == 0 and _cdiv(M, 128) * _cdiv(N, 128) >= TAPINNER_MIN_TILES:
         # the 16x16x32 form (higher sustained clock); its tile is any whole number of images that is a multiple of 16
         # rows, e.g. 96 = two 6x8 maps of the reference's default 48x64 frames
