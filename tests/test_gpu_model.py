@@ -343,6 +343,29 @@ def test_cli_train_loop_synthetic(dev, tmp_path, monkeypatch):
     assert tr._load_checkpoint(None) == last
 
 
+@pytest.mark.parametrize("ra", [False, True])
+def test_cem_rollouts_48x64_vs_oracle(dev, ra):
+    """The reference's default frame size (48x64 -> 6x8 latent maps: 96-row tiles of the 16x16x32 kernel, 12x16 maps on
+    six-row tiles) through the frozen model at g 128, with and without the robot-aware inputs: sum_cost <= 1e-5."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    flags = FLAGSETS["ra"] if ra else FLAGSETS["vanilla"]
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=2, candidates_batch_size=4, sample_mean=True, image_height=48,
+                  image_width=64, reward_type="dontcare" if ra else "dense", topk=3, **flags)
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=5, N=6, T=3, H=48, W=64, with_robot=ra, goal_blend=0.15)
+    ref = orc.cem_rollouts(sd, cfg, prob["actions"], prob["start_img"], prob["goal_imgs"], prob["goal_masks"],
+                           prob.get("states"), prob.get("masks"))
+    model = build_model(cfg, sd, dev)
+    sampler = TrajectorySampler(ns_for(cfg, dev), model,
+                                robot_model=FakeRobotModel(prob["states"], prob["masks"]) if ra else None)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    ro = sampler.generate_model_rollouts(prob["actions"].clone(), start, goal)
+    err = float(np.abs(ro["sum_cost"] - ref["sum_cost"]).max() / np.abs(ref["sum_cost"]).max())
+    assert err < 1e-5, err
+
+
 SWEEP = [
     dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
          reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
