@@ -27,6 +27,93 @@ BN_MOMENTUM = 0.1
 TRACE = None  # debugging aid: set to a list to collect (name, tensor-with-retained-grad) of every vgg block output
 
 
+class Forcing:
+    """Test aid for the LeakyReLU / max-pool *selection* pattern of a training pass.
+
+    `record=True`: collect, per vgg block prefix and call, the sign of the block output (LeakyReLU keeps the sign of
+    its pre-activation) and the pre-activation itself; per pooling call the arg-max index map.
+    `masks` / `pools` given: the pass takes the GIVEN selections instead of its own -- LeakyReLU slope 1 where the
+    mask is set, 0.2 elsewhere; pooling reads the given positions.  Two fp32 implementations of the same network
+    agree to ~1e-6, so a handful of pre-activations per million land on the other side of zero; with the selections
+    of one implementation forced onto the other, every remaining operation is smooth and the gradients must agree
+    to fp32 rounding.  `reps[prefix-root]`: calls that share one selection (the reference encodes the current frame
+    twice per training step, dynamics.py:584,619)."""
+
+    def __init__(self, masks=None, pools=None, rows_per_call=0, reps=None, record=False, l1_signs=None):
+        self.masks, self.pools, self.rows, self.record = masks, pools, rows_per_call, record
+        self.l1_signs, self.seen_l1 = l1_signs, []
+        self.reps = reps or {"encoder": 2}
+        self.calls = {}
+        self.seen_sign, self.seen_pool = {}, {}
+        self.flips = {}  # prefix -> [selections that differ, elements, max |pre-activation| / rms at a differing one]
+
+    def _slice(self, table, key):
+        c = self.calls.get(key, 0)
+        self.calls[key] = c + 1
+        step = c // self.reps.get(key.split(".")[0], 1)
+        return table[key][step * self.rows:(step + 1) * self.rows]
+
+    def leaky(self, prefix, y):
+        if self.masks is None:
+            if self.record:
+                self.seen_sign.setdefault(prefix, []).append((y.detach() > 0))
+            return F.leaky_relu(y, 0.2)
+        m = self._slice(self.masks, prefix)
+        if self.record:  # where does the forced selection differ from this pass's own, and how close to zero is it there
+            yd = y.detach()
+            diff = (yd > 0) != m
+            n = int(diff.sum())
+            worst = float(yd[diff].abs().max() / yd.pow(2).mean().sqrt()) if n else 0.0
+            st = self.flips.setdefault(prefix, [0, 0, 0.0])
+            st[0] += n
+            st[1] += yd.numel()
+            st[2] = max(st[2], worst)
+        return torch.where(m, y, 0.2 * y)
+
+    def abs(self, d):
+        """|d| of the L1 reconstruction losses: d * sign with the sign pattern given per call (`l1_signs`, a list in
+        call order of bool tensors `d > 0`), so that d |d| / dd agrees with the recorded pass also where d is zero to
+        rounding."""
+        if self.l1_signs is None:
+            if self.record:
+                self.seen_l1.append(d.detach() > 0)
+            return d.abs()
+        c = self.calls.get("l1", 0)
+        self.calls["l1"] = c + 1
+        pos = self.l1_signs[c]
+        if self.record:
+            dd = d.detach()
+            diff = ((dd > 0) != pos) & (dd != 0)
+            n = int(diff.sum())
+            st = self.flips.setdefault("l1_sign", [0, 0, 0.0])
+            st[0] += n
+            st[1] += dd.numel()
+            st[2] = max(st[2], float(dd[diff].abs().max()) if n else 0.0)
+        return torch.where(pos, d, -d)
+
+    def pool(self, tag, x):
+        if self.pools is None:
+            out, idx = F.max_pool2d(x, 2, 2, return_indices=True)
+            if self.record:
+                self.seen_pool.setdefault(tag, []).append(idx)
+            return out
+        idx = self._slice(self.pools, tag)
+        b, c, h, w = x.shape
+        out = x.flatten(2).gather(2, idx.flatten(2)).view(b, c, h // 2, w // 2)
+        if self.record:  # a forced position that is not this pass's maximum: how far below the maximum is it
+            own = F.max_pool2d(x.detach(), 2, 2)
+            gap = (own - out.detach())
+            n = int((gap > 0).sum())
+            st = self.flips.setdefault(tag, [0, 0, 0.0])
+            st[0] += n
+            st[1] += gap.numel()
+            st[2] = max(st[2], float(gap.max() / x.detach().pow(2).mean().sqrt()) if n else 0.0)
+        return out
+
+
+FORCING: Optional["Forcing"] = None
+
+
 # --------------------------------------------------------------------------- #
 # configuration
 # --------------------------------------------------------------------------- #
@@ -232,7 +319,7 @@ def vgg_block(sd: Dict[str, Tensor], prefix: str, x: Tensor, training: bool) -> 
         sd[f"{base}.1.num_batches_tracked"] += 1
     y = F.batch_norm(y, sd[f"{base}.1.running_mean"], sd[f"{base}.1.running_var"],
                      sd[f"{base}.1.weight"], sd[f"{base}.1.bias"], training, BN_MOMENTUM, BN_EPS)
-    y = F.leaky_relu(y, 0.2)
+    y = F.leaky_relu(y, 0.2) if FORCING is None else FORCING.leaky(prefix, y)
     if TRACE is not None and y.requires_grad:
         y.retain_grad()
         TRACE.append((prefix, y))
@@ -247,10 +334,11 @@ def _stack(sd, prefix, n, x, training):
 
 def encoder(sd: Dict[str, Tensor], x: Tensor, training: bool):
     """ConvEncoder.forward (vgg_64.py:122-129): returns (h4, [h1,h2,h3,h4])."""
+    pool = (lambda tag, t: F.max_pool2d(t, 2, 2)) if FORCING is None else FORCING.pool
     h1 = _stack(sd, "encoder.c1", 2, x, training)
-    h2 = _stack(sd, "encoder.c2", 2, F.max_pool2d(h1, 2, 2), training)
-    h3 = _stack(sd, "encoder.c3", 3, F.max_pool2d(h2, 2, 2), training)
-    h4 = _stack(sd, "encoder.c4", 3, F.max_pool2d(h3, 2, 2), training)
+    h2 = _stack(sd, "encoder.c2", 2, pool("encoder.pool1", h1), training)
+    h3 = _stack(sd, "encoder.c3", 3, pool("encoder.pool2", h2), training)
+    h4 = _stack(sd, "encoder.c4", 3, pool("encoder.pool3", h3), training)
     return h4, [h1, h2, h3, h4]
 
 
@@ -384,9 +472,13 @@ def composite(x_pred4: Tensor, x_prev: Tensor) -> Tensor:
     return (1 - m) * x_prev + m * x_pred4[:, :3]
 
 
+def _abs(d: Tensor) -> Tensor:
+    return d.abs() if FORCING is None else FORCING.abs(d)
+
+
 def l1_loss(pred, target, batch_weight=None):
     """losses.py:13-19."""
-    d = (target - pred).abs()
+    d = _abs(target - pred)
     return d.mean() if batch_weight is None else torch.mean(batch_weight * d.mean((1, 2, 3)))
 
 
@@ -406,7 +498,7 @@ def _masked_diff(pred, target, mask, robot_weight):
 def dontcare_l1_loss(pred, target, mask, robot_weight, batch_weight=None):
     """losses.py:35-50."""
     d, n_world = _masked_diff(pred, target, mask, robot_weight)
-    per = d.abs().sum((1, 2, 3))
+    per = _abs(d).sum((1, 2, 3))
     if batch_weight is not None:
         per = batch_weight * per
     return torch.mean(per / n_world)
