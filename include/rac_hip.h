@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 1
+#define RAC_ABI_VERSION 2
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -84,57 +84,39 @@ int rac_conv2d(const rac_conv_args* a, void* stream);
 
 
 /* ------------------------------------------------------------------------ *
- * Split-precision path for the frozen-model (CEM) gate GEMMs: every fp32 operand is the exact sum of three
- * bf16 parts, x = p1 + p2 + p3 (8+8+8 mantissa bits); the product keeps the six terms of order <= 2^-16
- * (p1q1, p1q2, p2q1, p1q3, p2q2, p3q1) on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the fp32
- * MFMA rate) with fp32 accumulation: fp32-level accuracy (dropped terms <= 2^-24 relative) at up to 2.67x
- * the fp32-MFMA roofline.
+ * Split-precision convolutions on the fp16 matrix pipe (v_mfma_f32_16x16x32_f16, fp32 accumulation): the same
+ * aten::conv2d call sites as rac_conv2d, for the layers that carry the FLOPs (ConvLSTM gate convs lstm.py:129-149,
+ * the >= 64-channel vgg layers vgg_64.py:8-18, the input convs dynamics.py:496-513).
+ *
+ * Every fp32 operand tensor X is scaled by a power of two s_X (max |x| s_X in [2^14, 2^15)) and written as two fp16
+ * parts, x s_X = h1 + h2 (22 significant bits); a product keeps h1 g1 + h1 g2 + h2 g1 (the dropped term is <= 2^-22
+ * relative) with fp32 accumulation, and the exact scales are removed in the epilogue.  Against an fp64 reference the
+ * results are as close as rac_conv2d's exact-fp32 MFMA path (the fp32 accumulation dominates both; tests hold every
+ * kernel to <= 4x that path's error) at 3 fp16 MFMA products per fp32 product: 2500 / 3 = 833 TFLOP/s algorithmic peak.
+ * Scales come from device-side maxima (`amax` slots: the IEEE bit pattern of max |x|, which orders like an unsigned
+ * integer), so nothing synchronises with the host.
  * ------------------------------------------------------------------------ */
-/* parts[k*part_stride + i] = k-th bf16 part of x[i], k = 0..2 (round-to-nearest-even at every level) */
-int rac_split_bf16x3(const float* x, uint16_t* parts, int64_t n, int64_t part_stride, void* stream);
-/* Conv weight (fp32, [Cout][k][k][Cin] memory) -> bf16 parts in MFMA fragment order (w_layout 2 or 3 below), in one pass.
+/* *amax = max(*amax, bits(max |x|)) over x0[0..n0) and x1[0..n1) (x1 may be NULL, n1 = 0).  The slot must hold 0 or
+ * an earlier maximum on entry; several calls may accumulate into one slot.  n % 4 == 0, 16-byte aligned. */
+int rac_absmax(const float* x0, int64_t n0, const float* x1, int64_t n1, uint32_t* amax, void* stream);
+/* Conv weight (fp32, [Cout][k][k][Cin] memory) -> the two fp16 parts of w * s_W in MFMA fragment order
+ *   parts[part][R/32][K/32][k*k][nb 2][lane 64][8],  lane = 16 q + (r mod 16), row r = 32 tile + 16 nb + lane mod 16,
+ *   k = 32 chunk + 8 q + j   (the B operand of v_mfma_f32_16x16x32_f16: one coalesced 1 KB load per MFMA operand).
  * transposed = 0: rows = Cout, K = Cin (forward).  transposed = 1: rows = Cin, K = Cout, taps flipped: the weight of
- * the forward conv that IS the data gradient (dgrad(dy, W) == fwd(dy, Wt)).  Channel counts % 32 == 0. */
-int rac_weight_frag_split(const float* w, uint16_t* parts, int32_t Cout, int32_t Cin, int32_t ksize, int32_t transposed,
-                          int64_t part_stride, int32_t w_layout, void* stream);
-/* FWD conv (as rac_conv2d mode RAC_CONV_FWD) on split operands: a0 / a1 / w point to bf16 part arrays
- * ([3][pixels][C] and [3][Cout][k][k][Cin]; *_part_stride in elements).  Needs Cin % 8 == 0, a_split % 32 == 0.
- * Epilogue fields (bias, scale/shift, act, stats, split_k slabs) behave as in rac_conv2d. */
-int rac_conv2d_fwd_split(const rac_conv_args* a, int64_t a0_part_stride, int64_t a1_part_stride,
-                         int64_t w_part_stride, int32_t w_layout, void* stream);
-/* w_layout: 0 = [Cout][k][k][Cin].  1 and 2 need Cin % 32 == 0, k > 1 and H*W dividing 128: a 128-pixel tile then
- * holds whole images, the kernel stages each 32-channel activation chunk once and runs the k*k taps against it
- * ("tap-inner").
- *   1 = chunk-major [Cout][Cin/32][k*k][32]: per-tap weight reads sequential in memory, staged through LDS;
- *   2 = fragment order [Cout/32][Cin/32][k*k][s 2][lane 64][8] with lane = 32 h + (co mod 32) and
- *       ci = 32 chunk + 16 s + 8 h + j (needs Cout % 32 == 0): the weight operand of every MFMA is one coalesced
- *       1 KB load straight into registers (no LDS staging, one barrier per k*k taps).  With this layout a0 / a1
- *       are plain fp32 [pixels][C] maps (a0_part_stride = a1_part_stride = 0): the kernel splits them on the way
- *       into LDS, no rac_split_bf16x3 pass.  Also serves maps larger than a tile (H*W > 128) when W divides 128
- *       and H is a multiple of 128 / W (image rows + halo per tile), and N <= 64 (64-column workgroups).
- *   3 = as 2 for the v_mfma_f32_16x16x32_bf16 form of the same kernels; for H*W <= 128 the workgroup tile is
- *       (128 / (H*W)) * H*W rows, which must be a multiple of 16 (so 6x8 maps work: 96 rows):
- *       [Cout/32][Cin/32][k*k][nb 2][lane 64][8] with lane = 16 q + (co mod 16), co = 32 tile + 16 nb + lane mod 16,
- *       ci = 32 chunk + 8 q + j.  The chip holds a higher clock on that instruction under this load. */
-/* Transposed bf16 parts for the split-precision weight gradient:
- *   out[dxi][k][c][p] = k-th part of (0 <= x(p)+dx < W ? x[p+dx][c] : 0),  dx = dxi - ndx/2,
- * x = fp32 [P][C] map of images `W` pixels wide; ndx = 1 gives the plain transpose (used for dy).
- * ld = pixels per row of the whole operand (0 = P), p_off = first pixel written: with ld = T*P and p_off = t*P, T
- * calls lay T time steps side by side along the pixel axis, and ONE rac_conv2d_wgrad_split over B*T images sums
- * their weight gradients.
- * layout 0: out[dxi][k][c][ld] rows.  layout 1 (C % 32 == 0): MFMA fragment order
- *   out[dxi][k][c / 32][p / 8][c mod 32][8 pixels]  (the B operand of rac_conv2d_wgrad_split with x_layout = 1 or 2).
- * layout 2 (ndx = 1, C % 128 == 0, 32-pixel aligned): tile order out[k][c / 128][p / 32][(p mod 32) / 8][c mod 128][8],
- *   the dy operand of rac_conv2d_wgrad_split with x_layout = 2 (each 8 KB block is that kernel's LDS image). */
-int rac_transpose_split(const float* x, uint16_t* out, int32_t P, int32_t C, int32_t W, int32_t ndx, int64_t ld,
-                        int32_t layout, int64_t p_off, void* stream);
-/* Weight gradient dw[co][tap][ci] += sum_p dy[p][co] x[p+tap][ci] on the split-precision pipe.
- * a->a0 / a->a1 = rac_transpose_split(x0 / x1, ndx = ksize) parts in layout `x_layout`, a->w =
- * rac_transpose_split(dy, ndx = 1, layout 0) parts, a->out0 = dw (fp32, accumulated in place), a->a_split = channels
- * of x0 (multiple of 128 when a1 is given), a->split_k = 0 picks it.  Needs W % 8 == 0.  x_layout = 1: the input
- * operand goes straight from L2 into the MFMA registers (needs both channel counts % 32 == 0).  x_layout = 2: the
- * same on v_mfma_f32_16x16x32_bf16 with a->w = rac_transpose_split(dy, layout 2) (needs Cout % 128 == 0 too). */
-int rac_conv2d_wgrad_split(const rac_conv_args* a, int32_t x_layout, void* stream);
+ * the forward conv that IS the data gradient (dgrad(dy, W) == fwd(dy, Wt)).  w_amax = rac_absmax of w.
+ * Channel counts % 32 == 0; part_stride in elements. */
+int rac_weight_frag_split(const float* w, const uint32_t* w_amax, uint16_t* parts, int32_t Cout, int32_t Cin,
+                          int32_t ksize, int32_t transposed, int64_t part_stride, void* stream);
+/* 1 if rac_conv2d_fwd_split takes this shape: k 3 or 5, Cin % 32 == Cout % 32 == 0 (a_split % 32 == 0), and either
+ * H*W <= 128 with a whole number of images per tile that is a multiple of 16 rows (8x8, 6x8 latent maps), or
+ * W <= 128 with R | H image rows per tile, R*W <= 128 a multiple of 16, halo included <= 256 staged rows. */
+int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin, int32_t Cout, int32_t a_split);
+/* FWD conv (as rac_conv2d mode RAC_CONV_FWD; epilogue fields bias, scale/shift, act, stats, split_k slabs behave the
+ * same) with a->a0 / a->a1 the fp32 NHWC activations (split into parts on the way into LDS), a->w the fragment-order
+ * parts of rac_weight_frag_split, a_amax0 / a_amax1 the maxima of a0 / a1 (a_amax1 may be NULL), w_amax as given to
+ * rac_weight_frag_split.  The data gradient of a conv is this call on dy with the transposed parts. */
+int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
+                         int64_t w_part_stride, const uint32_t* w_amax, void* stream);
 
 /* ------------------------------------------------------------------------ *
  * BatchNorm2d (training statistics) + LeakyReLU(0.2)

@@ -33,11 +33,10 @@ class ConvArgs(C.Structure):
 # name -> argtypes (return type is always int unless listed in _RET)
 _SIGS = {
     "rac_conv2d": [C.POINTER(ConvArgs), vp],
-    "rac_split_bf16x3": [vp, vp, i64, i64, vp],
-    "rac_weight_frag_split": [vp, vp, i32, i32, i32, i32, i64, i32, vp],
-    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), i64, i64, i64, i32, vp],
-    "rac_transpose_split": [vp, vp, i32, i32, i32, i32, i64, i32, i64, vp],
-    "rac_conv2d_wgrad_split": [C.POINTER(ConvArgs), i32, vp],
+    "rac_absmax": [vp, i64, vp, i64, vp, vp],
+    "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
+    "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
+    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, vp, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
     "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp],
     "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],

@@ -1,0 +1,720 @@
+// Split-precision convolutions on the fp16 matrix pipe of gfx950 (v_mfma_f32_16x16x32_f16, fp32 accumulation).
+//
+// Every fp32 operand tensor X is brought to fp16 range by a power-of-two scale s_X = 2^k (k from the tensor's
+// max |x|, so that max |x| s_X lies in [2^14, 2^15)) and written as the sum of two fp16 parts,
+//     x s_X = h1 + h2 (+ r),   h1 = fp16(x s_X),  h2 = fp16(x s_X - h1),   |r| <= 2^-22 |x s_X|,
+// and a product keeps the three part-products h1 g1 + h1 g2 + h2 g1 (the dropped h2 g2 is <= 2^-22 relative):
+// 22 bits of every operand enter the MFMA, products are exact in the fp32 accumulator's input, sums are fp32.
+// Against an fp64 reference the result is as close as the exact-fp32 MFMA kernels of rac_igemm.hip (the rounding of
+// the fp32 accumulation dominates both: tests/test_gpu_ops.py holds every kernel here to <= 4x the fp32 kernel's
+// error), at 3 fp16 MFMA products per fp32 product: algorithmic peak 2500 / 3 = 833 TFLOP/s.
+// The scale is exact (power of two) and removed in the epilogue; tensors' max |x| are produced on the device
+// (rac_absmax, an atomic max over the value's bit pattern) so nothing synchronises with the host.
+//
+// Kernels:
+//   conv16_tile_kernel      forward conv (= data gradient with the transposed weight) for maps that fit a tile
+//                           (H*W <= 128: the 8x8 / 6x8 latent maps): activations staged once per 32-channel chunk and
+//                           reused by all k*k taps through a wave-uniform row shift, weights in MFMA fragment order
+//                           straight from L2 into registers.
+//   conv16_rows_kernel      the same for larger maps: a tile = R whole image rows plus a halo.
+//   wgrad16_kernel          weight gradient: both operands in their natural NHWC layout, transposed on the way out of
+//                           LDS by ds_read_b64_tr_b16; K walks pixel COLUMNS so that one staged input column serves
+//                           every horizontal tap and the border taps are skipped instead of masked.
+#include <stdlib.h>
+
+#include "rac_common.h"
+
+namespace rac {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+constexpr unsigned OOB = 0xFFFFFFF0u;  // buffer offset past every range: the load returns zeros
+constexpr int SBN = 128, SBK = 32;
+
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {
+  unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const void*>(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(uniform_ptr(p)), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 load16(rsrc_t r, unsigned voff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, 0, 0));
+}
+
+// power-of-two scale of a tensor from the bit pattern of its max |x|: max |x| * scale in [2^14, 2^15)
+// (k clamped to +-80; an all-zero tensor gets scale 1)
+__host__ __device__ __forceinline__ int scale_exp(unsigned amax_bits) {
+  const int e = (int)((amax_bits >> 23) & 0xFF);
+  if (e == 0) return 0;
+  int k = 14 - (e - 127);
+  return k > 80 ? 80 : (k < -80 ? -80 : k);
+}
+__device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
+
+// eight fp32 values (two 16-byte vectors) * scale -> two fp16 parts, packed as 16-byte MFMA operand vectors
+__device__ __forceinline__ void split8h(u32x4 lo, u32x4 hi, float s, u32x4 (&q)[2]) {
+  const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  f16x8 h1, h2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = __builtin_bit_cast(float, w[j]) * s;
+    const _Float16 a = (_Float16)v;
+    h1[j] = a;
+    h2[j] = (_Float16)(v - (float)a);
+  }
+  q[0] = __builtin_bit_cast(u32x4, h1);
+  q[1] = __builtin_bit_cast(u32x4, h2);
+}
+
+// acc += a * b with a = a1 + a2, b = b1 + b2 (fp16 parts): smallest terms first
+__device__ __forceinline__ f32x4 mma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
+struct Conv16P {
+  int B, H, W, ks, pad, Cin, Cout, act, split_k, a_split;
+  long slab_stride;
+  const float *a0, *a1;       // fp32 NHWC activations (virtual concat at a_split)
+  const unsigned short* w;    // fp16 parts, fragment order [part][Cout/32][Cin/32][tap][nb 2][lane 64][8]
+  long w_ps;                  // part stride in elements
+  const unsigned *a_amax0, *a_amax1, *w_amax;  // bit patterns of max |x| of the operands (a_amax1 may be null)
+  float* out0;
+  const float *bias, *scale, *shift;
+  double* stats;
+  long stats_rows;
+  int M, N, HW, P, taps, cchunks, nchunks, cps;
+  int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
+  int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
+};
+
+// LDS image of the tile kernel: CHUNK-major [part 2][8-channel group 4][row 144][16 B]; rows 128..143 are zeros.
+// The 16 lanes of a ds_read_b128 group touch 16 distinct rows mod 16 = 16 distinct bank slots; a tap shift is one
+// wave-uniform byte offset.
+constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
+
+__device__ __forceinline__ void conv16_epilogue_store(const Conv16P& p, float v, float bias, float sc, float sh,
+                                                      float& s1, float& s2, long idx) {
+  v += bias;
+  s1 += v;
+  s2 += v * v;
+  v = v * sc + sh;
+  if (p.act == RAC_ACT_LEAKY02)
+    v = v > 0.f ? v : 0.2f * v;
+  else if (p.act == RAC_ACT_SIGMOID)
+    v = sigmoid_acc(v);
+  p.out0[idx] = v;
+}
+
+__global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int TM = p.tile_m;
+  const int nmb = TM >> 4;  // live 16-row blocks of the wave's 8
+  const int m0 = bx * TM, n0 = by * SBN;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  unsigned am = *p.a_amax0;
+  if (p.a_amax1) am = max(am, *p.a_amax1);
+  const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
+  const float sa = pow2f(ka);
+  // zero rows 128..143 of every chunk plane of both buffers: 2 * 2 * 4 * 16 = 256 vectors
+  {
+    const int pl = tid >> 4, r = tid & 15;  // plane index (buffer, part, chunk), row
+    *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * T16_ABUF + ((pl >> 2) & 1) * T16_PP + (pl & 3) * T16_CP +
+                              (128 + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+
+  const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
+  const bool a_ok = (srow < TM) & (m0 + srow < p.M);
+  unsigned amask[8];  // per 16-row block: one bit per tap for the shifted pixel's validity
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = t * 16 + lr;
+    const int im = r / p.HW;
+    const int q = r - im * p.HW;
+    const int y = q / p.W, x = q - y * p.W;
+    unsigned mk = 0;
+    for (int tp = 0; tp < p.taps; ++tp) {
+      const int yy = y + tp / p.ks - p.pad, xx = x + tp % p.ks - p.pad;
+      mk |= (((unsigned)yy < (unsigned)p.H) & ((unsigned)xx < (unsigned)p.W)) ? (1u << tp) : 0u;
+    }
+    amask[t] = mk;
+  }
+  const int abase = lq * T16_CP + lr * 16;  // block t adds t * 256
+  const int zrow = lq * T16_CP + 128 * 16;
+  const int ntile = (n0 >> 5) + wid;
+  const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  const unsigned b_off0 = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+  auto load_b = [&](u32x4(&rb)[4], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        rb[part * 2 + nb] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off0 + part * w_pstride + nb * 1024u), so, 0));
+  };
+  u32x4 ra[4];  // fp32 activations: [chunk i][half]
+  auto issue_a = [&](int cc) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = first ? c0 : c0 - p.a_split;
+    const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned oa = (unsigned)((m0 + srow) * Cs + cl + (sch + 2 * i) * 8) * 4u;
+      ra[2 * i] = load16(a_rsrc, a_ok ? oa : OOB);
+      ra[2 * i + 1] = load16(a_rsrc, a_ok ? oa + 16u : OOB);
+    }
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 q[2];
+      split8h(ra[2 * i], ra[2 * i + 1], sa, q);
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * T16_ABUF + part * T16_PP + (sch + 2 * i) * T16_CP + srow * 16) = q[part];
+    }
+  };
+
+  f32x4 acc[8][2];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    int cur = 0;
+    bool fresh = true;
+    u32x4 b0[4], b1[4], b2[4];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    load_b(b1, kc_begin + 1);
+    store_a(0);
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[4], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
+      fresh = false;
+      const int drow = (ky - p.pad) * p.W + (kx - p.pad);
+      const int shift = drow * 16 + cur * T16_ABUF + abase;
+      // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
+      // would have used, so that the read group stays conflict-free
+      const int zr = zrow + cur * T16_ABUF + ((lr + drow) & 15) * 16;
+      const unsigned bit = 1u << tap;
+      f16x8 fb[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) fb[nb][part] = __builtin_bit_cast(f16x8, rb[part * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        f16x8 fa[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int mb = 4 * h + t;
+          if (mb >= nmb) continue;  // wave-uniform
+          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * T16_PP));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            if (4 * h + t >= nmb) continue;
+            acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
+          }
+      }
+      if (last_tap && more) {
+        store_a(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 3) {
+      load_b(b2, kc + 2);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 3);
+        step(b1, kc + 1);
+      }
+      if (kc + 2 < kc_end) {
+        load_b(b1, kc + 4);
+        step(b2, kc + 2);
+      }
+    }
+  }
+
+  // ---- epilogue: undo the two scales, then as rac_conv2d FWD; col = l & 15 (+16 nb), rows 4 (l >> 4) + reg ----
+  const float ia = pow2f(-ka), iw = pow2f(-kw);
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wid * 32 + nb * 16 + lr;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + mb * 16 + 4 * lq + r;
+        if (mb >= nmb || m >= p.M || !nok) continue;
+        const float v = acc[mb][nb][r] * ia * iw;
+        if (slab) {
+          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n);
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lq == 0 && nok) {
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The same for maps LARGER than a tile (the 16x16 / 32x32 / 64x64 vgg maps, the 16x16 ConvLSTM maps of a 128x128
+// model, the 12x16 maps of 48x64 frames): a tile = R whole image rows (R | H, R * W <= 128 and a multiple of 16);
+// its pixels plus `pad` image rows above and below (the halo; zeros outside the image) are staged per channel chunk
+// as one CONTIGUOUS pixel range of the input.  The y shift of a tap lands in the halo, only the x shift can leave
+// the row (one bit per kernel column and lane selects a zero row).  LDS image [part 2][8-channel group 4]
+// [staged row + 16 zero rows][16 B]; one buffer, two barriers per channel chunk; weights one chunk ahead.
+// NV = 16-byte staging vectors per thread and part; TN = 32-column groups per workgroup: 4 (waves 1 x 4, each 128
+// rows x 32 columns) or 2 (64-column workgroups for the 64-channel layers: waves 2 x 2, 64 rows x 32 columns).
+// ---------------------------------------------------------------------------------------------------------
+template <int NV, int TN>
+__global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
+  constexpr int MB = 2 * TN;    // 16-row blocks per wave
+  constexpr int BNW = TN * 32;  // columns per workgroup
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, lq = lane >> 4;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.xcd_group) {
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * (by + nt * bz);
+    const int xcd = lin & 7, s = lin >> 3;
+    const int grp = (s / mt) * 8 + xcd;
+    bx = s % mt;
+    by = grp % nt;
+    bz = grp / nt;
+  }
+  const int wn = wid % TN, wm = wid / TN;
+  const int TM = p.tile_m;
+  const int nmb = TM >> 4;
+  const int m0 = bx * TM, n0 = by * BNW;
+  const int kc_begin = bz * p.cps;
+  const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  unsigned am = *p.a_amax0;
+  if (p.a_amax1) am = max(am, *p.a_amax1);
+  const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
+  const float sa = pow2f(ka);
+  const int halo = p.pad * p.W;
+  const int nrows = TM + 2 * halo;       // staged pixel rows (a multiple of 16)
+  const int cplane = (nrows + 16) * 16;  // one 8-channel group: staged rows + 16 zero rows
+  const int pplane = 4 * cplane;
+  if (tid < 2 * 4 * 16)
+    *reinterpret_cast<u32x4*>(lds_raw + (tid >> 6) * pplane + ((tid >> 4) & 3) * cplane + (nrows + (tid & 15)) * 16) =
+        u32x4{0u, 0u, 0u, 0u};
+
+  const int y_tile = (m0 % p.HW) / p.W;
+  int s_off[NV], s_row[NV], s_grp[NV];
+  bool s_ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i;
+    const int g = v / nrows, row = v - g * nrows;
+    s_grp[i] = g;
+    s_row[i] = row;
+    s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
+    const int y = y_tile - p.pad + row / p.W;
+    s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
+  }
+  unsigned amask[MB];
+#pragma unroll
+  for (int t = 0; t < MB; ++t) {
+    const int r = (wm * MB + t) * 16 + lr;
+    const int x = r % p.W;
+    unsigned mk = 0;
+    for (int kx = 0; kx < p.ks; ++kx) mk |= ((unsigned)(x + kx - p.pad) < (unsigned)p.W) ? (1u << kx) : 0u;
+    amask[t] = mk;
+  }
+  const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;  // block t adds t * 256
+  const int zrow = lq * cplane + nrows * 16;
+  const int ntile = (n0 >> 5) + wn;
+  const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  const unsigned b_off0 = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+  auto load_b = [&](u32x4(&rb)[4], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+        rb[part * 2 + nb] = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off0 + part * w_pstride + nb * 1024u), so, 0));
+  };
+  u32x4 ra[2 * NV];
+  auto issue_a = [&](int cc) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = first ? c0 : c0 - p.a_split;
+    const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned oa = (unsigned)((m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      ra[2 * i] = load16(a_rsrc, s_ok[i] ? oa : OOB);
+      ra[2 * i + 1] = load16(a_rsrc, s_ok[i] ? oa + 16u : OOB);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (s_off[i] < 0) continue;
+      u32x4 q[2];
+      split8h(ra[2 * i], ra[2 * i + 1], sa, q);
+#pragma unroll
+      for (int part = 0; part < 2; ++part) *reinterpret_cast<u32x4*>(lds_raw + part * pplane + s_off[i]) = q[part];
+    }
+  };
+
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kc_begin < kc_end) {
+    int cc = kc_begin / p.taps;
+    int tap = kc_begin - cc * p.taps;
+    int ky = tap / p.ks, kx = tap - ky * p.ks;
+    bool fresh = true;
+    u32x4 b0[4], b1[4];
+    issue_a(cc);
+    load_b(b0, kc_begin);
+    store_a();
+    __syncthreads();
+
+    auto step = [&](const u32x4(&rb)[4], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
+      fresh = false;
+      const int drow = (ky - p.pad) * p.W + (kx - p.pad);
+      const int shift = drow * 16 + abase;
+      const int zr = zrow + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
+      const unsigned bit = 1u << kx;
+      f16x8 fb[2][2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) fb[nb][part] = __builtin_bit_cast(f16x8, rb[part * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < MB / 4; ++h) {
+        f16x8 fa[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int mb = 4 * h + t;
+          if (wm * MB + mb >= nmb) continue;  // wave-uniform: past the tile's rows
+          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            if (wm * MB + 4 * h + t >= nmb) continue;
+            acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
+          }
+      }
+      if (last_tap && more) {
+        __syncthreads();
+        store_a();
+        __syncthreads();
+        fresh = true;
+      }
+      cc = last_tap ? cc + 1 : cc;
+      tap = last_tap ? 0 : tap + 1;
+      kx = (kx + 1 == p.ks) ? 0 : kx + 1;
+      ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
+    };
+
+    for (int kc = kc_begin; kc < kc_end; kc += 2) {
+      load_b(b1, kc + 1);
+      step(b0, kc);
+      if (kc + 1 < kc_end) {
+        load_b(b0, kc + 2);
+        step(b1, kc + 1);
+      }
+    }
+  }
+
+  const float ia = pow2f(-ka), iw = pow2f(-kw);
+  const bool slab = p.split_k > 1;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const int n = n0 + wn * 32 + nb * 16 + lr;
+    const bool nok = n < p.N;
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (!slab && nok) {
+      if (p.bias) bias = p.bias[n];
+      if (p.scale) {
+        sc = p.scale[n];
+        sh = p.shift[n];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (wm * MB + mb) * 16 + 4 * lq + r;
+        if (wm * MB + mb >= nmb || m >= p.M || !nok) continue;
+        const float v = acc[mb][nb][r] * ia * iw;
+        if (slab) {
+          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          continue;
+        }
+        conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n);
+      }
+    }
+    if (p.stats && !slab) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lq == 0 && nok) {
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + p.N + n, (double)s2);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// max |x| of one or two fp32 arrays as a bit pattern (non-negative floats order like unsigned integers):
+// *amax = max(*amax, bits(max |x|)).  The slot must hold 0 (or an earlier maximum) on entry.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void absmax_kernel(const float4* x0, long n0v, const float4* x1, long n1v, unsigned* amax) {
+  unsigned m = 0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0v + n1v; i += stride) {
+    const float4 v = i < n0v ? x0[i] : x1[i - n0v];
+    const unsigned a = __builtin_bit_cast(unsigned, v.x) & 0x7FFFFFFFu, b = __builtin_bit_cast(unsigned, v.y) & 0x7FFFFFFFu,
+                   c = __builtin_bit_cast(unsigned, v.z) & 0x7FFFFFFFu, d = __builtin_bit_cast(unsigned, v.w) & 0x7FFFFFFFu;
+    m = max(m, max(max(a, b), max(c, d)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(amax, m);
+}
+
+// Conv weight [Cout][taps][Cin] fp32 -> fp16 parts of (w * scale) in MFMA fragment order:
+//   out[part][R/32][Kc/32][tap][nb 2][lane 64][8],  lane = 16 q + r mod 16, row r = 32 tile + 16 nb + lane mod 16,
+//   k = 32 chunk + 8 q + j
+// forward:    rows r = co, k = ci, value w[r][tap][k]
+// transposed: rows r = ci, k = co, value w[k][taps-1-tap][r]   (the conv that IS the data gradient)
+__global__ void weight_frag16_kernel(const float* w, const unsigned* w_amax, unsigned short* out, int Cout, int Cin,
+                                     int taps, int transposed, long ps) {
+  const int R = transposed ? Cin : Cout, Kc = transposed ? Cout : Cin;
+  const int cch = Kc >> 5;
+  const long cell = (long)blockIdx.x * 2 + (threadIdx.x >> 7);  // ((nt * cch + cc) * taps + tap)
+  if (cell >= (long)(R >> 5) * cch * taps) return;
+  const float s = pow2f(scale_exp(*w_amax));
+  const int tap = (int)(cell % taps);
+  const int cc = (int)((cell / taps) % cch);
+  const int nt = (int)(cell / ((long)taps * cch));
+  const int nb = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+  const int r = nt * 32 + nb * 16 + (lane & 15);
+  const int k0 = cc * 32 + 8 * (lane >> 4);
+  u32x4 lo, hi;
+  if (!transposed) {
+    const u32x4* src = reinterpret_cast<const u32x4*>(w + ((long)r * taps + tap) * Cin + k0);
+    lo = src[0], hi = src[1];
+  } else {
+    unsigned v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = __builtin_bit_cast(unsigned, w[((long)(k0 + j) * taps + (taps - 1 - tap)) * Cin + r]);
+    lo = u32x4{v[0], v[1], v[2], v[3]}, hi = u32x4{v[4], v[5], v[6], v[7]};
+  }
+  u32x4 q[2];
+  split8h(lo, hi, s, q);
+  const long o = (cell * 2 + nb) * 512 + lane * 8;
+  *reinterpret_cast<u32x4*>(out + o) = q[0];
+  *reinterpret_cast<u32x4*>(out + ps + o) = q[1];
+}
+
+}  // namespace rac
+
+using namespace rac;
+
+extern "C" int rac_absmax(const float* x0, int64_t n0, const float* x1, int64_t n1, uint32_t* amax, void* stream) {
+  RAC_REQUIRE(x0 && n0 > 0 && n1 >= 0 && (n1 == 0 || x1) && amax, "rac_absmax: bad args");
+  RAC_REQUIRE(n0 % 4 == 0 && n1 % 4 == 0 && aligned16(x0) && (!x1 || aligned16(x1)),
+              "rac_absmax: element counts must be multiples of 4, pointers 16-byte aligned");
+  long nb = ((n0 + n1) / 4 + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(absmax_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(x0), (long)(n0 / 4), reinterpret_cast<const float4*>(x1),
+                     (long)(n1 / 4), amax);
+  return check_launch("rac_absmax");
+}
+
+extern "C" int rac_weight_frag_split(const float* w, const uint32_t* w_amax, uint16_t* parts, int32_t Cout, int32_t Cin,
+                                     int32_t ksize, int32_t transposed, int64_t part_stride, void* stream) {
+  RAC_REQUIRE(w && w_amax && parts && Cout > 0 && Cin > 0 && ksize >= 1 && (ksize & 1), "rac_weight_frag_split: bad args");
+  RAC_REQUIRE(Cout % 32 == 0 && Cin % 32 == 0, "rac_weight_frag_split: channel counts must be multiples of 32");
+  const long n = (long)Cout * Cin * ksize * ksize;
+  RAC_REQUIRE(part_stride >= n && part_stride % 8 == 0 && aligned16(w) && aligned16(parts),
+              "rac_weight_frag_split: part stride / alignment");
+  const long cells = n / 1024;  // (row tile, k chunk, tap) cells of 32 x 32 weights
+  hipLaunchKernelGGL(weight_frag16_kernel, dim3((unsigned)((cells + 1) / 2)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), w, w_amax, parts, Cout, Cin, ksize * ksize, transposed,
+                     (long)part_stride);
+  return check_launch("rac_weight_frag_split");
+}
+
+// image rows per tile of conv16_rows_kernel: R | H, R * W <= 128 and a multiple of 16 (0: none)
+static int rows_tile_m(int H, int W) {
+  for (int r = 128 / W; r >= 1; --r)
+    if (H % r == 0 && (r * W) % 16 == 0) return r * W;
+  return 0;
+}
+
+extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin, int32_t Cout, int32_t a_split) {
+  if (H <= 0 || W <= 0 || ksize < 3 || ksize > 5 || !(ksize & 1) || Cin % 32 || Cout % 32) return 0;
+  if (a_split > 0 && a_split < Cin && a_split % 32) return 0;
+  const int HW = H * W;
+  if (HW <= 128) return ((128 / HW) * HW) % 16 == 0;
+  const int tm = W <= 128 ? rows_tile_m(H, W) : 0;
+  return tm && (tm + 2 * (ksize / 2) * W) * 4 <= 1024;
+}
+
+extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
+                                    int64_t w_part_stride, const uint32_t* w_amax, void* stream) {
+  RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
+  RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0 && a_amax0 && w_amax,
+              "rac_conv2d_fwd_split: bad args");
+  const int a_split = (a->a1 && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
+  RAC_REQUIRE(rac_conv2d_split_supported(a->H, a->W, a->ksize, a->Cin, a->Cout, a_split),
+              "rac_conv2d_fwd_split: shape not supported (k 3 or 5, channel counts %% 32 == 0, whole images or whole "
+              "image rows per 128-pixel tile): use rac_conv2d");
+  Conv16P p{};
+  p.B = a->B, p.H = a->H, p.W = a->W, p.ks = a->ksize, p.pad = a->ksize / 2;
+  p.Cin = a->Cin, p.Cout = a->Cout, p.act = a->act;
+  p.split_k = a->split_k > 1 ? a->split_k : 1;
+  p.slab_stride = a->slab_stride;
+  p.a0 = a->a0, p.a1 = a->a1;
+  p.w = reinterpret_cast<const unsigned short*>(a->w);
+  p.w_ps = w_part_stride;
+  p.a_amax0 = a_amax0, p.a_amax1 = a_amax1, p.w_amax = w_amax;
+  p.out0 = a->out0;
+  p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
+  p.stats_rows = a->stats ? a->stats_rows : 0;
+  p.HW = a->H * a->W;
+  p.P = a->B * p.HW;
+  p.M = p.P, p.N = a->Cout;
+  p.taps = a->ksize * a->ksize;
+  p.a_split = a_split;
+  RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
+  RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
+              "rac_conv2d_fwd_split: operand larger than 4 GiB");
+  RAC_REQUIRE(w_part_stride >= (long)p.Cout * p.taps * p.Cin && 2 * w_part_stride * 2 < 0xFFFFFF00L,
+              "rac_conv2d_fwd_split: weight part stride");
+  RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.N, "rac_conv2d_fwd_split: slab_stride too small");
+  RAC_REQUIRE(p.stats_rows >= 0 && (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
+              "rac_conv2d_fwd_split: stats_rows must divide B*H*W");
+  p.cchunks = a->Cin / SBK;
+  p.nchunks = p.taps * p.cchunks;
+  p.cps = cdiv(p.nchunks, p.split_k);
+  RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+  static const char* xg = getenv("RAC_XCD_GROUP");
+  const bool want_xcd = xg ? atoi(xg) != 0 : true;
+  if (p.HW > 128) {
+    p.tile_m = rows_tile_m(a->H, a->W);
+    RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
+    const int nrows = p.tile_m + 2 * p.pad * a->W;
+    const int nv = cdiv(nrows * 4, 256) < 2 ? 2 : cdiv(nrows * 4, 256);
+    RAC_REQUIRE(nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
+    typedef void (*rows_fn)(Conv16P);
+    static const rows_fn fns[2][3] = {
+        {conv16_rows_kernel<2, 4>, conv16_rows_kernel<3, 4>, conv16_rows_kernel<4, 4>},
+        {conv16_rows_kernel<2, 2>, conv16_rows_kernel<3, 2>, conv16_rows_kernel<4, 2>}};
+    const size_t lds_rows = (size_t)2 * 4 * (nrows + 16) * 16;
+    const int narrow = p.N <= 64 ? 1 : 0;
+    dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, narrow ? 64 : 128), p.split_k);
+    p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+    hipLaunchKernelGGL(fns[narrow][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_fwd_split(image rows)");
+  }
+  p.tile_m = (128 / p.HW) * p.HW;  // whole images per workgroup
+  RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
+  dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
+  p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+  constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
+  hipLaunchKernelGGL(conv16_tile_kernel, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("rac_conv2d_fwd_split(whole images)");
+}

@@ -239,122 +239,97 @@ def bias_grad_acc(dy, bias):
 
 
 # --------------------------------------------------------------------------- #
-# split-precision (3 x bf16 per operand, 6 part-products) forward GEMMs for the frozen model
+# split-precision convolutions on the fp16 matrix pipe (csrc/rac_split16.hip)
 # --------------------------------------------------------------------------- #
-# default on: the frozen-model (no-grad) gate GEMMs and wide vgg layers run split-precision; RAC_SPLIT_GEMM=0 keeps
-# everything on the exact-fp32 MFMA path
+# Every fp32 operand is scaled by a power of two taken from its max |x| (computed on the device: `amax` slots hold
+# the bit pattern of the maximum) and split into two fp16 parts; three part-products per fp32 product, fp32
+# accumulation.  RAC_SPLIT_GEMM=0 keeps every conv on the exact-fp32 MFMA path (rac_conv2d).
 SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
-# the training step's ConvLSTM gate GEMMs: forward and data gradient on the split-precision pipe (the weight
-# gradient stays on exact-fp32 MFMA)
-SPLIT_GEMM_TRAIN = os.environ.get("RAC_SPLIT_GEMM_TRAIN", "1") == "1"
-# the wide (>= 128 output channels) vgg layers of the training step on the same pipe: "1" all of them (default:
-# 56.7 vs 59.7 ms/step at cfg2 with the time-batched encoder / decoder, 60.7 vs 61.1 step by step), "latent" only
-# the layers whose maps fit the tap-inner kernels, "0" none (exact-fp32 MFMA)
-SPLIT_VGG_TRAIN = os.environ.get("RAC_SPLIT_VGG_TRAIN", "1")
-
-
-def split_parts(x: torch.Tensor) -> torch.Tensor:
-    """fp32 tensor -> (3, numel) bf16 parts with x == p1 + p2 + p3 exactly (memory order of x is kept)."""
-    n = x.numel()
-    parts = torch.empty((3, n), device=x.device, dtype=torch.bfloat16)
-    call("rac_split_bf16x3", ptr(x), ptr(parts), n, n, stream_ptr())
-    return parts
-
-
-def split_weight(weight: torch.Tensor) -> torch.Tensor:
-    """bf16 parts of a channels_last conv weight, cached until the parameter changes."""
-    return _derived(weight, "_rac_split", lambda: split_parts(weight_mem(weight)))
-
-
-def chunk_major(w: torch.Tensor) -> torch.Tensor:
-    """[Cout][k][k][Cin] memory -> contiguous [Cout][Cin/32][k*k][32] (weight layout 1 of rac_conv2d_fwd_split)."""
-    co, ci, k, _ = w.shape
-    mem = w.permute(0, 2, 3, 1).reshape(co, k * k, ci // 32, 32)
-    return mem.permute(0, 2, 1, 3).contiguous()
-
-
-def frag_order(w: torch.Tensor) -> torch.Tensor:
-    """[Cout][k][k][Cin] memory -> contiguous [Cout/32][Cin/32][k*k][s][h][co mod 32][8] (weight layout 2: the
-    operand registers of v_mfma_f32_32x32x16_bf16, lane = 32 h + co mod 32, ci = 32 chunk + 16 s + 8 h + j)."""
-    co, ci, k, _ = w.shape
-    mem = w.permute(0, 2, 3, 1).reshape(co // 32, 32, k * k, ci // 32, 2, 2, 8)  # nt, li, tap, cc, s, h, j
-    return mem.permute(0, 3, 2, 4, 5, 1, 6).contiguous()
-
-
-# the tap-inner kernel (chunk-major weights) wins at every size measured on one box, back to back: 223 vs 184
-# TFLOP/s at M=32000, 168 vs 145 at M=6400, 162 vs 148 at M=1024 (cfg2 train step 72.3 vs 77.4 ms), so it is
-# used whenever the shape allows; the knob keeps the tap-outer kernel reachable for A/B runs and tests
-TAPINNER_MIN_TILES = int(os.environ.get("RAC_TAPINNER_MIN_TILES", "0"))
-
-
-# weight layout 2 (fragment order, weights loaded straight into MFMA registers) instead of 1 where Cout allows
-W_DIRECT = os.environ.get("RAC_SPLIT_W_DIRECT", "1") == "1"
-# ... also on maps larger than a tile (16x16 / 32x32): the image-rows + halo variant of that kernel
-ROWS_KERNEL = os.environ.get("RAC_SPLIT_ROWS_KERNEL", "1") == "1"
-# v_mfma_f32_16x16x32_bf16 instead of 32x32x16 in the weights-direct kernel for the latent maps (weight layout 3)
-MFMA16 = os.environ.get("RAC_MFMA16", "1") == "1"
-# narrowest layer (output channels) of the frozen model that runs split-precision
+SPLIT_GEMM_TRAIN = SPLIT_GEMM
+# narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
-# frozen model: pad the input convs' concatenated input to 32-channel chunks (split-precision pipe)
-PAD32_INPUT_CONVS = os.environ.get("RAC_PAD32_INPUT_CONVS", "1") == "1"
-PAD32_TRAIN = os.environ.get("RAC_PAD32_TRAIN", "1") == "1"  # ... in the training step too
-CONVBIAS_SPLIT = os.environ.get("RAC_CONVBIAS_SPLIT", "1") == "1"
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
 
-
-def tapinner_ok(H: int, W: int, Cin: int, k: int, M: int, N: int) -> bool:
-    return (k > 1 and Cin % 32 == 0 and H * W <= 128 and 128 % (H * W) == 0
-            and _cdiv(M, 128) * _cdiv(N, 128) >= TAPINNER_MIN_TILES)
+_AMAX = {"buf": None, "used": 0, "one": None}
+_AMAX_SLOTS = 1 << 14
 
 
-def split_weight_layout(H: int, W: int, Cin: int, k: int, M: int, N: int) -> int:
-    """Weight layout (w_layout of rac_conv2d_fwd_split) for a conv of this shape."""
-    direct = W_DIRECT and N % 32 == 0 and Cin % 32 == 0 and 1 < k <= 5
-    if H * W > 128:  # maps larger than a tile: whole image rows per tile + halo, fragment-order weights only
-        if not (direct and ROWS_KERNEL and W <= 128):
-            return 0
-        if MFMA16:  # R image rows per tile: R | H, R * W <= 128 and a multiple of 16 (96 = 6 rows of a 12x16 map)
-            tm = max([r * W for r in range(1, 128 // W + 1) if H % r == 0 and (r * W) % 16 == 0], default=0)
-            return 3 if (tm and (tm + 2 * (k // 2) * W) * 4 <= 1024) else 0
-        rows_ok = 128 % W == 0 and H % (128 // W) == 0 and (128 + 2 * (k // 2) * W) * 4 <= 1024
-        return 2 if rows_ok else 0
-    if direct and MFMA16 and ((128 // (H * W)) * H * W) % 16 == 0 and _cdiv(M, 128) * _cdiv(N, 128) >= TAPINNER_MIN_TILES:
-        # the 16x16x32 form (higher sustained clock); its tile is any whole number of images that is a multiple of 16
-        # rows, e.g. 96 = two 6x8 maps of the reference's default 48x64 frames
-        return 3
-    if not tapinner_ok(H, W, Cin, k, M, N):
-        return 0
-    return 2 if direct else 1
+def _amax_arena(device):
+    buf = _AMAX["buf"]
+    if buf is None or buf.device != torch.device(device) or _AMAX["used"] >= _AMAX_SLOTS:
+        buf = _AMAX["buf"] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.int32)
+        _AMAX["used"] = 0
+    return buf
 
 
-def frag_order16(w: torch.Tensor) -> torch.Tensor:
-    """[Cout][k][k][Cin] memory -> contiguous [Cout/32][Cin/32][k*k][nb][q][co mod 16][8] (weight layout 3: the
-    operand registers of v_mfma_f32_16x16x32_bf16, lane = 16 q + co mod 16, co = 32 tile + 16 nb + .., ci = 32 chunk
-    + 8 q + j)."""
-    co, ci, k, _ = w.shape
-    mem = w.permute(0, 2, 3, 1).reshape(co // 32, 2, 16, k * k, ci // 32, 4, 8)  # nt, nb, lr, tap, cc, q, j
-    return mem.permute(0, 4, 3, 1, 5, 2, 6).contiguous()
+def amax_of(x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Device slot (1-element int32 view) holding the bit pattern of max |x| over x0 (and x1)."""
+    buf = _amax_arena(x0.device)
+    k = _AMAX["used"]
+    _AMAX["used"] = k + 1
+    slot = buf[k:k + 1]
+    call("rac_absmax", ptr(x0), x0.numel(), ptr(x1), x1.numel() if x1 is not None else 0, ptr(slot), stream_ptr())
+    return slot
 
 
-_W_LAYOUT_FN = {1: chunk_major, 2: frag_order, 3: frag_order16}
+def amax_one(device) -> torch.Tensor:
+    """Slot for tensors bounded by 1 in magnitude (ConvLSTM hidden states h = o * tanh(c); frames and masks)."""
+    one = _AMAX["one"]
+    if one is None or one.device != torch.device(device):
+        one = _AMAX["one"] = torch.tensor([0x3F800000], device=device, dtype=torch.int32)
+    return one
 
 
-def weight_frag_parts(weight: torch.Tensor, transposed: bool = False, layout: int = 2) -> torch.Tensor:
-    """bf16 parts of a channels_last conv weight in MFMA fragment order (w_layout 2), one pass over the weight;
-    `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient.
-    Equals split_parts(frag_order(w)) resp. split_parts(frag_order(transposed_weight(w)))."""
-    co, ci, k, _ = weight.shape
-    w = weight_mem(weight.detach())
-    n = w.numel()
-    parts = torch.empty((3, n), device=w.device, dtype=torch.bfloat16)
-    call("rac_weight_frag_split", ptr(w), ptr(parts), co, ci, k, 1 if transposed else 0, n, layout, stream_ptr())
-    return parts
+def tag_amax(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
+    """Remember a tensor's max-|x| slot on the tensor object (producers that know a bound, or consumers that already
+    measured it, save the next consumer a reduction pass)."""
+    t._rac_amax = slot
+    return t
 
 
-def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None, shift=None,
-                  stats=None, split_k=1, slab_stride=0, w_layout=0, stats_rows=0):
+def amax_for(t: torch.Tensor) -> torch.Tensor:
+    slot = getattr(t, "_rac_amax", None)
+    if slot is None:
+        slot = amax_of(t)
+        t._rac_amax = slot
+    return slot
+
+
+_SPLIT_OK = {}
+
+
+def split_supported(H: int, W: int, k: int, Cin: int, Cout: int, a_split: int = 0) -> bool:
+    key = (H, W, k, Cin, Cout, a_split)
+    ok = _SPLIT_OK.get(key)
+    if ok is None:
+        ok = _SPLIT_OK[key] = bool(_lib.load().rac_conv2d_split_supported(H, W, k, Cin, Cout, a_split))
+    return ok
+
+
+def weight_parts(weight: torch.Tensor, transposed: bool = False):
+    """(fp16 parts of weight * 2^k in MFMA fragment order, amax slot), cached on the parameter until it changes;
+    `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient."""
+    def amax():
+        slot = torch.zeros(1, device=weight.device, dtype=torch.int32)
+        w = weight_mem(weight.detach())
+        call("rac_absmax", ptr(w), w.numel(), None, 0, ptr(slot), stream_ptr())
+        return slot
+
+    def build():
+        co, ci, k, _ = weight.shape
+        w = weight_mem(weight.detach())
+        slot = _derived(weight, "_rac_amax_w", amax)
+        n = w.numel()
+        parts = torch.empty((2, n), device=w.device, dtype=torch.float16)
+        call("rac_weight_frag_split", ptr(w), ptr(slot), ptr(parts), co, ci, k, 1 if transposed else 0, n, stream_ptr())
+        return parts, slot
+    return _derived(weight, "_rac_parts_t" if transposed else "_rac_parts", build)
+
+
+def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
+                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
-                    a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(p0), a1=ptr(p1), w=ptr(pw), out0=ptr(out),
+                    a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
                     stats_rows=stats_rows)
     prof = PROFILE
@@ -362,9 +337,7 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    a0_ps = 0 if w_layout >= 2 else p0.shape[1]  # layouts 2 / 3: p0 / p1 are the fp32 maps themselves
-    a1_ps = 0 if (w_layout >= 2 or p1 is None) else p1.shape[1]
-    call("rac_conv2d_fwd_split", C.byref(args), a0_ps, a1_ps, pw.shape[1], w_layout, stream_ptr())
+    call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], ptr(wslot), stream_ptr())
     if timed:
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
@@ -373,7 +346,7 @@ def _split_launch(p0, p1, pw, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, b
 
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
                        want_slabs=False, groups=1):
-    """FWD conv over [x0 | x1] on the bf16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
+    """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
@@ -381,47 +354,31 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     Cout, Cin, k, _ = weight.shape
     assert Cin == C0 + C1
     M = B * H * W
-    cm = split_weight_layout(H, W, Cin, k, M, Cout)
-    if cm >= 2:  # the weights-direct kernels read fp32 activations and split them on the way into LDS
-        p0, p1 = x0.contiguous(), (x1.contiguous() if x1 is not None else None)
-    else:
-        p0 = split_parts(x0)
-        p1 = split_parts(x1) if x1 is not None else None
-    if cm >= 2:
-        pw = _derived(weight, f"_rac_split_l{cm}", lambda: weight_frag_parts(weight, layout=cm))
-    elif cm:
-        pw = _derived(weight, f"_rac_split_l{cm}", lambda: split_parts(_W_LAYOUT_FN[cm](weight.detach())))
-    else:
-        pw = split_weight(weight)
+    x0 = x0 if x0.is_contiguous() else x0.contiguous()
+    if x1 is not None and not x1.is_contiguous():
+        x1 = x1.contiguous()
+    a0 = amax_for(x0)
+    a1 = amax_for(x1) if x1 is not None else None
+    pw, wslot = weight_parts(weight)
+    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0)
     if want_slabs:
         split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
         out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
-        _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
-                      slab_stride=M * Cout, w_layout=cm)
+        _split_launch(x0, x1, a0, a1, pw, wslot, out, split_k=split, slab_stride=M * Cout, **kw)
         return out, split, M * Cout
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
     fused = act != ACT_NONE or scale is not None
     split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
     if split == 1:
-        _split_launch(p0, p1, pw, out, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, act=act, bias=bias, scale=scale,
-                      shift=shift, stats=stats, w_layout=cm,
-                      stats_rows=(M // groups if (groups > 1 and stats is not None) else 0))
+        _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, stats=stats,
+                      stats_rows=(M // groups if (groups > 1 and stats is not None) else 0), **kw)
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
-        _split_launch(p0, p1, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, split_k=split,
-                      slab_stride=M * Cout, w_layout=cm)
+        _split_launch(x0, x1, a0, a1, pw, wslot, slabs, split_k=split, slab_stride=M * Cout, **kw)
         call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
         if stats is not None:
             call("rac_col_stats", ptr(out), ptr(stats), M, Cout, groups, stream_ptr())
     return out
-
-
-def transposed_weight(weight: torch.Tensor) -> torch.Tensor:
-    """(Cin, Cout, k, k) channels_last tensor with taps flipped: the weight of the conv that IS the data gradient
-    (dgrad(dy, W) == fwd(dy, Wt)); cached until the parameter changes."""
-    def build():
-        return weight.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous(memory_format=torch.channels_last)
-    return _derived(weight, "_rac_transposed", build)
 
 
 def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
@@ -430,20 +387,12 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
     Co, Cin, k, _ = weight.shape
     assert Co == Cout and Cin == C0 + C1
     M = B * H * W
-    cm = split_weight_layout(H, W, Cout, k, M, Cin)
-    if cm >= 2:
-        pw = _derived(weight, f"_rac_transposed_split_l{cm}",
-                      lambda: weight_frag_parts(weight, transposed=True, layout=cm))
-    elif cm:
-        pw = _derived(weight, f"_rac_transposed_split_l{cm}",
-                      lambda: split_parts(_W_LAYOUT_FN[cm](transposed_weight(weight))))  # (Cin, Cout, k, k)
-    else:
-        pw = _derived(weight, "_rac_transposed_split", lambda: split_parts(weight_mem(transposed_weight(weight))))
-    pd = dy.contiguous() if cm >= 2 else split_parts(dy)  # layout 2: fp32 activations, split inside the kernel
+    dy = dy if dy.is_contiguous() else dy.contiguous()
+    pw, wslot = weight_parts(weight, transposed=True)
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
-    _split_launch(pd, None, pw, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout, split_k=split,
-                  slab_stride=M * Cin, w_layout=cm)
+    _split_launch(dy, None, amax_for(dy), None, pw, wslot, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout,
+                  split_k=split, slab_stride=M * Cin)
     dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
     if C1:
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
@@ -454,12 +403,11 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
 
 
 # Deferred, time-batched weight gradients: inside `deferred_wgrad()` the split-precision wgrad of a weight that is
-# applied at every time step (the ConvLSTM gate convs) is not launched per step; its (dy, x0, x1) triples are kept and
-# ONE launch over all steps' pixels runs when the context exits (K = T*B*H*W instead of B*H*W per launch: one
-# read-modify-write of the gradient instead of T, longer K loops).  Same sum, different association across steps.
+# applied at every time step (the ConvLSTM gate convs, the input convs) is not launched per step; its (dy, x0, x1)
+# triples are kept and ONE launch over all steps' pixels runs when the context exits (one read-modify-write of the
+# gradient instead of T, longer K loops).  Same sum, different association across steps.
 _DEFERRED = None
 DEFER_WGRAD = os.environ.get("RAC_DEFER_WGRAD", "1") == "1"
-WGRAD_DIRECT = os.environ.get("RAC_WGRAD_DIRECT", "1") == "1"
 
 
 @contextlib.contextmanager
@@ -484,7 +432,7 @@ def deferred_wgrad(on_ready=None):
 
 
 def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
-    """weight.grad += dW on the split-precision pipe (transposed bf16 parts of dy and of the dx-shifted inputs).
+    """weight.grad += dW on the split-precision pipe.
     `defer`: inside `deferred_wgrad()` only record the operands (the caller must not modify them afterwards)."""
     if defer and _DEFERRED is not None:
         _DEFERRED.setdefault(id(weight), (weight, []))[1].append((dy, x0, x1))
@@ -493,47 +441,16 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
 
 
 def _wgrad_split_batch(items, weight):
-    dy, x0, x1 = items[0]
-    T = len(items)
-    B, H, W, Cout = dy.shape
-    Co, Cin, k, _ = weight.shape
-    C0 = x0.shape[3]
-    C1 = x1.shape[3] if x1 is not None else 0
-    ci_real = Cin
-    if x1 is None and C0 > Cin:  # x0 carries zero pad channels (32-channel chunks): gradient of the padded weight
-        Cin = C0
-    P = B * H * W
-    ld = T * P
-    dev = dy.device
-    dyt = torch.empty((3, Cout, ld), device=dev, dtype=torch.bfloat16)
-    x0t = torch.empty((k, 3, C0, ld), device=dev, dtype=torch.bfloat16)
-    x1t = torch.empty((k, 3, C1, ld), device=dev, dtype=torch.bfloat16) if C1 else None
-    sp = stream_ptr()
-    # inputs in MFMA fragment order (loaded straight into registers by the kernel) where the channel counts allow
-    xl = 1 if (WGRAD_DIRECT and C0 % 32 == 0 and C1 % 32 == 0 and W % 8 == 0 and (W // 8) & (W // 8 - 1) == 0) else 0
-    if xl and MFMA16 and Cout % 128 == 0 and P % 32 == 0:
-        xl = 2  # 16x16x32 form: dy^T in tile order (the kernel's LDS image), same x^T fragment order
-    for t, (dy_t, x0_t, x1_t) in enumerate(items):
-        assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
-        call("rac_transpose_split", ptr(dy_t), ptr(dyt), P, Cout, W, 1, ld, 2 if xl == 2 else 0, t * P, sp)
-        call("rac_transpose_split", ptr(x0_t), ptr(x0t), P, C0, W, k, ld, min(xl, 1), t * P, sp)
-        if C1:
-            call("rac_transpose_split", ptr(x1_t), ptr(x1t), P, C1, W, k, ld, min(xl, 1), t * P, sp)
-    if Cin != ci_real:
-        g = torch.zeros((Cout, k, k, Cin), device=dev, dtype=torch.float32)
-    else:
-        g = weight_mem(grad_buffer(weight))
-    args = ConvArgs(mode=WGRAD, B=B * T, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=0, split_k=0, accumulate=1,
-                    a_split=C0, o_split=0, slab_stride=0, a0=ptr(x0t), a1=ptr(x1t), w=ptr(dyt), out0=ptr(g), out1=None,
-                    bias=None, scale=None, shift=None, stats=None)
-    call("rac_conv2d_wgrad_split", C.byref(args), xl, sp)
-    if Cin != ci_real:
-        call("rac_unpad_add", ptr(g), Cin, ptr(weight_mem(grad_buffer(weight))), ci_real, Cout * k * k, sp)
+    # interim: exact-fp32 MFMA weight gradient per step (the fp16-split kernel replaces this)
+    for dy, x0, x1 in items:
+        if x1 is None and x0.shape[3] > weight.shape[1]:
+            wgrad_padded_acc(dy, x0, weight)
+        else:
+            conv_wgrad_acc(dy, x0, x1, weight)
 
 
 def wgrad_split_ok(x0, x1, W: int) -> bool:
-    c0 = x0.shape[3]
-    return SPLIT_GEMM_TRAIN and W % 8 == 0 and c0 % 8 == 0 and (x1 is None or (c0 % 128 == 0 and x1.shape[3] % 8 == 0))
+    return SPLIT_GEMM_TRAIN
 
 
 # --------------------------------------------------------------------------- #
@@ -588,10 +505,9 @@ class ConvBias(torch.autograd.Function):
         padded = ci % 4 != 0 and x1 is None and x0.shape[3] == ci + pad4(ci)
         w = padded_weight(weight) if padded else weight
         B, H, W, _ = x0.shape
-        # the weights-direct split-precision kernels where the shape allows (the NormConvLSTM gate convs, the heads)
-        ctx.split = (CONVBIAS_SPLIT and act == ACT_NONE and not padded and (SPLIT_GEMM if frozen else SPLIT_GEMM_TRAIN)
-                     and x0.shape[3] % 32 == 0 and weight.shape[0] >= 128
-                     and split_weight_layout(H, W, ci, weight.shape[2], B * H * W, weight.shape[0]) >= 2)
+        # the split-precision kernels where the shape allows (the NormConvLSTM gate convs)
+        ctx.split = (SPLIT_GEMM and act == ACT_NONE and not padded and x0.shape[3] % 32 == 0 and weight.shape[0] >= 128
+                     and split_supported(H, W, weight.shape[2], ci, weight.shape[0], x0.shape[3] if x1 is not None else 0))
         if ctx.split:
             y = conv_forward_split(x0, x1, w, bias)
         else:
@@ -690,8 +606,8 @@ class VggLayer(torch.autograd.Function):
         if not training:
             scale, shift = folded
             c0 = x0.shape[3]
-            if (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT and weight.shape[1] % 8 == 0 and c0 % 8 == 0
-                    and (x1 is None or c0 % 32 == 0)):
+            if (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT
+                    and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, c0 if x1 is not None else 0)):
                 y = conv_forward_split(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
             else:
                 y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
@@ -701,12 +617,8 @@ class VggLayer(torch.autograd.Function):
         G = ctx.groups = int(groups)  # time steps batched along B: one BatchNorm call of the reference per group
         stats = zeros64((G, 2, Cout), dev)
         c0 = x0.shape[3]
-        # "1": every wide layer; "latent": only the layers whose maps fit the tap-inner kernels (H*W divides 128)
-        ctx.split = (SPLIT_VGG_TRAIN != "0" and Cout >= SPLIT_MIN_COUT_TRAIN and c0 >= 64 and weight.shape[1] % 8 == 0
-                     and c0 % 8 == 0
-                     and (x1 is None or c0 % 128 == 0) and x0.shape[2] % 8 == 0
-                     and (SPLIT_VGG_TRAIN == "1" or (weight.shape[1] % 32 == 0 and Cout % 32 == 0
-                                                     and 128 % (x0.shape[1] * x0.shape[2]) == 0)))
+        ctx.split = (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT_TRAIN and c0 >= 64
+                     and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, c0 if x1 is not None else 0))
         if ctx.split:
             raw = conv_forward_split(x0, x1, weight, None, stats=stats, groups=G)
         else:
@@ -803,8 +715,8 @@ class TileCat(torch.autograd.Function):
         ct = sum(ns) + c0 + c1
         pad = pad4(ct)
         hw = H * W
-        whole = hw <= 128 and (128 % hw == 0 or (MFMA16 and ((128 // hw) * hw) % 16 == 0))  # whole-image tiles exist
-        if (SPLIT_GEMM if frozen else (SPLIT_GEMM_TRAIN and PAD32_TRAIN)) and PAD32_INPUT_CONVS and ct >= 128 and whole:
+        whole = hw <= 128 and ((128 // hw) * hw) % 16 == 0  # whole-image tiles exist
+        if SPLIT_GEMM and ct >= 128 and whole and c0 % 32 == 0:
             pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
@@ -838,7 +750,8 @@ class LstmCell(torch.autograd.Function):
         # `grad_mode` = torch.is_grad_enabled() at the call site: needs_input_grad mirrors requires_grad even
         # under torch.no_grad(), and grad mode is always off inside forward()
         need_bwd = grad_mode and any(ctx.needs_input_grad)
-        if g % 32 == 0 and ((SPLIT_GEMM and not need_bwd) or (SPLIT_GEMM_TRAIN and need_bwd)):
+        ctx.split = SPLIT_GEMM and split_supported(H, W, weight.shape[2], 2 * g, 4 * g, g)
+        if ctx.split:
             slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True)
         else:
             slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
@@ -863,12 +776,12 @@ class LstmCell(torch.autograd.Function):
              ptr(dc_prev), M, g, stream_ptr())
         dx = dh_prev = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            if SPLIT_GEMM_TRAIN and g % 32 == 0:
+            if ctx.split:
                 dx, dh_prev = conv_dgrad_split(dgates, weight, g, g)
             else:
                 dx, dh_prev = conv_dgrad(dgates, weight, g, g)
         if weight.requires_grad:
-            if wgrad_split_ok(x, h_prev, W):
+            if ctx.split:
                 conv_wgrad_split_acc(dgates, x, h_prev, weight, defer=True)
             else:
                 conv_wgrad_acc(dgates, x, h_prev, weight)

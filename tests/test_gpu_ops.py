@@ -321,84 +321,101 @@ def test_cem_step_tail(dev, golden_dir):
         np.testing.assert_allclose(cost.cpu().numpy(), g[key].astype(np.float64), rtol=2e-6)
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2, 3])
-@pytest.mark.parametrize("case", [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3),
-                                  (5, 4, 8, 32, 64, 160, 3), (4, 8, 8, 64, 64, 1024, 3), (5, 6, 8, 64, 64, 128, 5)])
-def test_conv_split_precision_bf16x6(dev, case, layout, monkeypatch):
-    """Three bf16 parts per operand, six part-products: fp32-level accuracy on the bf16 matrix pipe.  All three
-    kernels: tap-outer (layout 0, any shape), tap-inner with chunk-major weights through LDS (1), tap-inner with
-    fragment-order weights loaded straight into the MFMA registers (2) and its 16x16x32 form (3)."""
+def frag_order16(w: torch.Tensor) -> torch.Tensor:
+    """[Cout][k][k][Cin] memory -> contiguous [Cout/32][Cin/32][k*k][nb][q][co mod 16][8]: the operand registers of
+    v_mfma_f32_16x16x32_f16, lane = 16 q + co mod 16, co = 32 tile + 16 nb + .., ci = 32 chunk + 8 q + j."""
+    co, ci, k, _ = w.shape
+    mem = w.permute(0, 2, 3, 1).reshape(co // 32, 2, 16, k * k, ci // 32, 4, 8)  # nt, nb, lr, tap, cc, q, j
+    return mem.permute(0, 4, 3, 1, 5, 2, 6).contiguous()
+
+
+def split_f16x2(x: torch.Tensor):
+    """The two fp16 parts of x * 2^k with max |x| * 2^k in [2^14, 2^15) -- the operand format of csrc/rac_split16.hip."""
+    amax = float(x.abs().max())
+    k = 14 - int(np.floor(np.log2(amax))) if amax > 0 else 0
+    v = x.double() * 2.0 ** k
+    h1 = v.float().half()
+    h2 = (v.float() - h1.float()).half()
+    return h1, h2, k
+
+
+SPLIT_CASES = [(2, 8, 8, 64, 64, 256, 5), (3, 8, 8, 128, 128, 512, 3), (20, 8, 8, 64, 0, 96, 3),
+               (5, 4, 8, 32, 64, 160, 3), (4, 8, 8, 64, 64, 1024, 3), (5, 6, 8, 64, 64, 128, 5)]
+
+
+@pytest.mark.parametrize("case", SPLIT_CASES)
+def test_conv_split_precision_f16x2(dev, case):
+    """Two fp16 parts per scaled operand, three part-products, fp32 accumulation: as close to fp64 as the exact-fp32
+    MFMA kernel, whatever the magnitude of the operands (the power-of-two scales come from device-side maxima)."""
     from robot_aware_control_amd import ops
-    monkeypatch.setattr(ops, "TAPINNER_MIN_TILES", 0 if layout else 1 << 30)
-    monkeypatch.setattr(ops, "W_DIRECT", layout >= 2)
-    monkeypatch.setattr(ops, "MFMA16", layout == 3)
     B, H, W, C0, C1, Cout, k = case
-    if 128 % (H * W) != 0:  # 6x8 maps (48x64 frames): only the tap-outer kernel and the 16x16x32 form (96-row tiles)
-        if layout in (1, 2):
-            pytest.skip("whole-image tiles of 128 rows need H*W to divide 128")
-    assert ops.split_weight_layout(H, W, C0 + C1, k, B * H * W, Cout) == layout
     Cin = C0 + C1
-    # exactness of the fragment layout: small integers live entirely in the first bf16 part
+    assert ops.split_supported(H, W, k, Cin, Cout, C0 if C1 else 0) and H * W <= 128
+    # exactness of the fragment layouts and of the scaling: small integers live entirely in the first part
     g = np.random.Generator(np.random.Philox(key=[9, 9]))
     xi = torch.from_numpy(g.integers(-3, 4, (B, Cin, H, W)).astype(np.float32))
     wi = torch.from_numpy(g.integers(-3, 4, (Cout, Cin, k, k)).astype(np.float32))
     x0, x1 = to_map(xi[:, :C0], dev), (to_map(xi[:, C0:], dev) if C1 else None)
     y = ops.conv_forward_split(x0, x1, cl_weight(wi).to(dev))
     assert torch.equal(from_map(y), F.conv2d(xi, wi, None, 1, k // 2))
-    # accuracy on real-valued data: compare both GPU paths with an fp64 reference
+    # accuracy on real-valued data against fp64, next to the exact-fp32 MFMA path; operands of very different
+    # magnitude (gradients are ~1e-6, pre-activations ~1e2) and a heavy-tailed tensor (one outlier 1e4 x the rest)
     x = rnd(1, B, Cin, H, W)
     w = rnd(2, Cout, Cin, k, k) * (1.0 / np.sqrt(Cin * k * k))
     b = rnd(3, Cout, scale=0.1)
-    ref = F.conv2d(x.double(), w.double(), b.double(), 1, k // 2)
-    x0, x1 = to_map(x[:, :C0], dev), (to_map(x[:, C0:], dev) if C1 else None)
-    wd, bd = cl_weight(w).to(dev), b.to(dev)
-    parts = ops.split_parts(x0)
-    assert torch.equal(parts.float().sum(0).view_as(x0), x0)  # p1 + p2 + p3 == x exactly
-    e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
-    e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
-    assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (e_split, e_fp32)
-    # data gradient = forward conv with the transposed, tap-flipped weight (same two kernels)
-    if Cout % 32 == 0:
-        gy = rnd(4, B, Cout, H, W)
-        xr = x.double().requires_grad_(True)
-        F.conv2d(xr, w.double(), None, 1, k // 2).backward(gy.double())
-        d0, d1 = ops.conv_dgrad_split(to_map(gy, dev), wd, C0, C1)
-        got = torch.cat([from_map(d0)] + ([from_map(d1)] if C1 else []), 1)
-        assert relerr(got, xr.grad) < 2e-6
+    for xs, ws, spike in ((1.0, 1.0, False), (3e-7, 40.0, False), (5e3, 1e-3, False), (1.0, 1.0, True)):
+        xv, wv, bv = x * xs, w * ws, b * (xs * ws)
+        if spike:
+            xv = xv.clone()
+            xv[0, 0, 0, 0] = 1e4
+        ref = F.conv2d(xv.double(), wv.double(), bv.double(), 1, k // 2)
+        x0, x1 = to_map(xv[:, :C0], dev), (to_map(xv[:, C0:], dev) if C1 else None)
+        wd, bd = cl_weight(wv).to(dev), bv.to(dev)
+        e_split = relerr(from_map(ops.conv_forward_split(x0, x1, wd, bd)), ref)
+        e_fp32 = relerr(from_map(ops.conv_forward(x0, x1, wd, bd, allow_split=False)), ref)
+        assert e_split < 2e-6 and e_split < 4 * e_fp32 + 2e-7, (xs, ws, spike, e_split, e_fp32)
+    # data gradient = forward conv with the transposed, tap-flipped weight (same kernels)
+    gy = rnd(4, B, Cout, H, W) * 1e-5
+    xr = x.double().requires_grad_(True)
+    F.conv2d(xr, w.double(), None, 1, k // 2).backward(gy.double())
+    d0, d1 = ops.conv_dgrad_split(to_map(gy, dev), cl_weight(w).to(dev), C0, C1)
+    got = torch.cat([from_map(d0)] + ([from_map(d1)] if C1 else []), 1)
+    assert relerr(got, xr.grad) < 2e-6
 
 
 @pytest.mark.parametrize("shape", [(64, 96, 3), (128, 64, 5), (32, 64, 3)])
 def test_weight_frag_split(dev, shape):
-    """One-pass fragment-order split of a weight == permute + split, for the forward and the data-gradient weight;
-    vectorised rac_split_bf16x3 == scalar one."""
+    """rac_absmax + rac_weight_frag_split == scale by 2^k, split into two fp16 parts, permute into MFMA fragment
+    order (forward and data-gradient weight); the parts carry 22 bits of every weight."""
     from robot_aware_control_amd import ops
     co, ci, k = shape
-    w = cl_weight(rnd(5, co, ci, k, k)).to(dev)
-    assert torch.equal(ops.weight_frag_parts(w), ops.split_parts(ops.frag_order(w)))
-    assert torch.equal(ops.weight_frag_parts(w, transposed=True), ops.split_parts(ops.frag_order(ops.transposed_weight(w))))
-    assert torch.equal(ops.weight_frag_parts(w, layout=3), ops.split_parts(ops.frag_order16(w)))
-    assert torch.equal(ops.weight_frag_parts(w, transposed=True, layout=3),
-                       ops.split_parts(ops.frag_order16(ops.transposed_weight(w))))
-    x = rnd(6, 4099, scale=3.0).to(dev)  # odd length: scalar kernel; first 4096: vector kernel
-    pa, pb = ops.split_parts(x), ops.split_parts(x[:4096].clone())
-    assert torch.equal(pa[:, :4096], pb)
-    assert torch.equal(pb.float().sum(0), x[:4096])
+    w = cl_weight(rnd(5, co, ci, k, k) * 0.02).to(dev)
+    h1, h2, kexp = split_f16x2(w.cpu())
+    parts, slot = ops.weight_parts(w)
+    assert int(slot.cpu()) == int(w.abs().max().cpu().view(torch.int32))
+    assert torch.equal(parts[0].cpu(), frag_order16(h1).flatten()) and torch.equal(parts[1].cpu(), frag_order16(h2).flatten())
+    wt = w.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous(memory_format=torch.channels_last)
+    pt, _ = ops.weight_parts(w, transposed=True)
+    t1, t2, _ = split_f16x2(wt.cpu())
+    assert torch.equal(pt[0].cpu(), frag_order16(t1).flatten()) and torch.equal(pt[1].cpu(), frag_order16(t2).flatten())
+    back = (h1.double() + h2.double()) * 2.0 ** -kexp
+    assert float(((back - w.cpu().double()).abs() / w.cpu().double().abs().clamp_min(1e-30)).max()) <= 2.0 ** -21
+    # the maximum accumulates over calls and over two arrays
+    a, b = rnd(6, 4096, scale=3.0).to(dev), rnd(7, 512, scale=5.0).to(dev)
+    s2 = ops.amax_of(a, b)
+    assert int(s2.cpu()) == int(torch.maximum(a.abs().max(), b.abs().max()).cpu().view(torch.int32))
 
 
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 96, 3), (1, 32, 32, 64, 0, 128, 3), (3, 16, 16, 32, 0, 64, 5),
                                   (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3), (1, 64, 64, 64, 64, 64, 3),
                                   (2, 12, 16, 64, 0, 96, 3), (1, 24, 32, 32, 32, 64, 3)])
-@pytest.mark.parametrize("m16", [False, True])
-def test_conv_split_rows_kernel(dev, case, m16, monkeypatch):
-    """Weights-direct kernel on maps larger than a tile (whole image rows per tile + halo) against fp64, forward and
-    data gradient, and bit-identical sums with the tap-outer kernel's exactness test (small integers)."""
+def test_conv_split_rows_kernel(dev, case):
+    """The split-precision kernel for maps larger than a tile (whole image rows per tile + halo) against fp64, forward
+    and data gradient, and exact on small integers."""
     from robot_aware_control_amd import ops
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
-    monkeypatch.setattr(ops, "MFMA16", m16)  # 32x32x16 (weight layout 2) or 16x16x32 (layout 3) form of the kernel
-    if not m16 and (128 % W != 0 or H % (128 // W) != 0):
-        pytest.skip("the 32x32x16 form needs tiles of exactly 128 pixels")  # 12x16 maps (48x64 frames): 96-row tiles
-    assert ops.split_weight_layout(H, W, Cin, k, B * H * W, Cout) == (3 if m16 else 2) and H * W > 128
+    assert ops.split_supported(H, W, k, Cin, Cout, C0 if C1 else 0) and H * W > 128
     g = np.random.Generator(np.random.Philox(key=[11, 9]))
     xi = torch.from_numpy(g.integers(-3, 4, (B, Cin, H, W)).astype(np.float32))
     wi = torch.from_numpy(g.integers(-3, 4, (Cout, Cin, k, k)).astype(np.float32))
@@ -424,18 +441,15 @@ def test_conv_split_rows_kernel(dev, case, m16, monkeypatch):
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3)])
-@pytest.mark.parametrize("direct", [0, 1, 2])
-def test_wgrad_split_precision(dev, case, direct, monkeypatch):
-    """Weight gradient from transposed bf16 parts (dx-shifted input copies, dy as whole-vector offsets); both
-    kernels: inputs through LDS, and inputs in fragment order loaded straight into the MFMA registers."""
+def test_wgrad_split_precision(dev, case):
+    """Weight gradient on the split-precision pipe against fp64, next to the exact-fp32 MFMA kernel; accumulation into
+    .grad; the deferred (time-batched) form."""
     from robot_aware_control_amd import ops
-    monkeypatch.setattr(ops, "WGRAD_DIRECT", direct > 0)   # 0: inputs through LDS, 1: direct (32x32x16),
-    monkeypatch.setattr(ops, "MFMA16", direct == 2)        # 2: direct on 16x16x32 where Cout % 128 == 0
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
     x = rnd(1, B, Cin, H, W)
     w = (rnd(2, Cout, Cin, k, k) * 0.02).requires_grad_(True)
-    gy = rnd(4, B, Cout, H, W)
+    gy = rnd(4, B, Cout, H, W) * 1e-4
     F.conv2d(x.double(), w.double(), None, 1, k // 2).backward(gy.double())  # fp64 reference... via float weight
     ref = w.grad.double()
     x0, x1 = to_map(x[:, :C0], dev), (to_map(x[:, C0:], dev) if C1 else None)
@@ -448,7 +462,7 @@ def test_wgrad_split_precision(dev, case, direct, monkeypatch):
     assert e_split < 3e-6 and e_split < 4 * e_fp32 + 3e-7, (e_split, e_fp32)
     ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)  # accumulates
     assert relerr(wd.grad.cpu(), 2 * ref) < 3e-6
-    # deferred: the time steps' operands laid side by side along the pixel axis, ONE launch when the context exits
+    # deferred: the time steps' operands in ONE launch when the context exits
     wd3 = cl_weight(w.detach()).to(dev).requires_grad_(True)
     with ops.deferred_wgrad():
         ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd3, defer=True)

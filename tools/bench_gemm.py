@@ -40,64 +40,30 @@ ms = e0.elapsed_time(e1) / iters
 print(f"{mode} B={B} g={g} k={k} tile={os.environ.get('RAC_IGEMM_TILE','auto')} split={os.environ.get('RAC_SPLIT','auto')}: "
       f"{ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s  ({flop / ms / 1e9 / 157.3 * 100:.1f}% of fp32 MFMA peak)", flush=True)
 
-if mode == "fwd" and os.environ.get("RAC_BENCH_SPLIT"):
-    def run2():
-        return ops.conv_forward_split(x, h, w, want_slabs=True)
+def timeit(fn, label, nflop):
     for _ in range(3):
-        run2()
+        fn()
     torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
-        run2()
+        fn()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
-    print(f"fwd-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective  "
-          f"({flop / ms / 1e9 / 157.3 * 100:.1f}% of the fp32 MFMA peak, {6 * flop / ms / 1e9 / 2500 * 100:.1f}% of bf16 peak x6)", flush=True)
-    wl = int(os.environ.get('RAC_W_LAYOUT', '3'))
-    pw = ops.split_parts({1: ops.chunk_major, 2: ops.frag_order, 3: ops.frag_order16}[wl](w))
-    px, ph = (x, h) if wl >= 2 else (ops.split_parts(x), ops.split_parts(h))  # layouts 2 / 3 read fp32 activations
-    aps = 0 if wl >= 2 else px.shape[1]
-    import ctypes as C
-    from robot_aware_control_amd._lib import ConvArgs, call, ptr, stream_ptr
-    out = torch.empty((B, H, W, 4 * g), device=dev)
-    args = ConvArgs(mode=0, B=B, H=H, W=W, ksize=k, Cin=2 * g, Cout=4 * g, act=0, split_k=1, accumulate=0, a_split=g, o_split=0, slab_stride=0,
-                    a0=ptr(px), a1=ptr(ph), w=ptr(pw), out0=ptr(out), out1=None, bias=None, scale=None, shift=None, stats=None)
-    for _ in range(2):
-        call("rac_conv2d_fwd_split", C.byref(args), aps, aps, pw.shape[1], wl, stream_ptr())
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        call("rac_conv2d_fwd_split", C.byref(args), aps, aps, pw.shape[1], wl, stream_ptr())
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"  kernel only: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective", flush=True)
+    print(f"{label} B={B} g={g} k={k}: {ms:.3f} ms  {nflop / ms / 1e9:.1f} TFLOP/s algorithmic "
+          f"({3 * nflop / ms / 1e9 / 2500 * 100:.1f}% of the fp16 MFMA peak at 3 products)", flush=True)
 
-if mode == "wgrad" and os.environ.get("RAC_BENCH_SPLIT"):
-    def run3():
-        return ops.conv_wgrad_split_acc(dy, x, h, w)
-    for _ in range(3):
-        run3()
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        run3()
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"wgrad-split(bf16x6) B={B} g={g} k={k}: {ms:.3f} ms  {flop / ms / 1e9:.1f} TFLOP/s effective (incl. transposes)", flush=True)
 
-if mode == "wgrad" and os.environ.get("RAC_BENCH_SPLIT"):
+if os.environ.get("RAC_BENCH_SPLIT"):
     T = int(os.environ.get("RAC_BENCH_T", "1"))
-    items = [(dy, x, h)] * T
-    for _ in range(2):
-        ops._wgrad_split_batch(items, w)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        ops._wgrad_split_batch(items, w)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    print(f"wgrad-split(bf16x6) B={B} x T={T} g={g} k={k}: {ms:.3f} ms  {T * flop / ms / 1e9:.1f} TFLOP/s effective incl. transposes", flush=True)
+    if mode == "fwd":
+        ops.tag_amax(h, ops.amax_one(dev))
+        timeit(lambda: ops.conv_forward_split(x, h, w, want_slabs=True), "fwd-split(f16x2, incl. absmax)", flop)
+        ops.amax_for(x)
+        timeit(lambda: ops.conv_forward_split(x, h, w, want_slabs=True), "fwd-split(f16x2, kernel only)", flop)
+    elif mode == "dgrad":
+        ops.amax_for(dy)
+        timeit(lambda: ops.conv_dgrad_split(dy, w, g, g), "dgrad-split(f16x2 + slab reduce)", flop)
+    else:
+        items = [(dy, x, h)] * T
+        timeit(lambda: ops._wgrad_split_batch(items, w), f"wgrad-split(f16x2) T={T}", T * flop)
