@@ -118,6 +118,34 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
                          int64_t w_part_stride, const uint32_t* w_amax, void* stream);
 
+/* Weight gradient dw[co][ky][kx][ci] (+)= sum_{steps, pixels} dy[p][co] x[p+tap][ci] on the same pipe (the backward of
+ * the conv2d call sites above; aten::conv2d backward w.r.t. the weight).  Operands are the fp32 NHWC tensors as the
+ * forward pass saw them (x = virtual concat [x0 | x1] at a_split), one triple per time step: T steps are summed in
+ * ONE launch (one read-modify-write of dw).  *_amax = rac_absmax slots of the operands (one common scale per
+ * operand kind is taken from the maximum over the steps).  nsplit > 1 splits the pixel range: part 0 goes to dw, parts
+ * 1.. to `slabs` (nsplit - 1 arrays of slab_stride elements) which the caller then adds with rac_slab_accumulate --
+ * deterministic, no atomics.  Needs ksize 3 or 5, Cout % 16 == 0, channel counts % 8 == 0, a_split % 64 == 0. */
+#define RAC_WGRAD_MAX_STEPS 16
+typedef struct rac_wgrad_args {
+  int32_t B, H, W;       /* images per step and their size */
+  int32_t ksize, Cin, Cout, a_split;
+  int32_t T;             /* time steps, 1 .. RAC_WGRAD_MAX_STEPS */
+  int32_t nsplit;        /* K splits, <= T * ceil(B*H / 32) */
+  int32_t accumulate;    /* 1: dw += result, 0: dw = result */
+  const float* dy[RAC_WGRAD_MAX_STEPS];
+  const float* x0[RAC_WGRAD_MAX_STEPS];
+  const float* x1[RAC_WGRAD_MAX_STEPS];       /* NULL: single source */
+  const uint32_t* dy_amax[RAC_WGRAD_MAX_STEPS];
+  const uint32_t* x0_amax[RAC_WGRAD_MAX_STEPS];
+  const uint32_t* x1_amax[RAC_WGRAD_MAX_STEPS];
+  float* dw;             /* [Cout][k][k][Cin] */
+  float* slabs;          /* workspace for nsplit > 1 */
+  int64_t slab_stride;
+} rac_wgrad_args;
+int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream);
+/* out[i] += sum_s slabs[s*slab_stride + i]  (fixed order) */
+int rac_slab_accumulate(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------------ *
  * BatchNorm2d (training statistics) + LeakyReLU(0.2)
  *   src/prediction/models/vgg_64.py:12-14 (nn.BatchNorm2d, nn.LeakyReLU(0.2))

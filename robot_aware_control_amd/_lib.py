@@ -30,6 +30,20 @@ class ConvArgs(C.Structure):
     ]
 
 
+WGRAD_MAX_STEPS = 16
+
+
+class WgradArgs(C.Structure):
+    """struct rac_wgrad_args (include/rac_hip.h)."""
+    _fields_ = [
+        ("B", i32), ("H", i32), ("W", i32), ("ksize", i32), ("Cin", i32), ("Cout", i32), ("a_split", i32),
+        ("T", i32), ("nsplit", i32), ("accumulate", i32),
+        ("dy", vp * WGRAD_MAX_STEPS), ("x0", vp * WGRAD_MAX_STEPS), ("x1", vp * WGRAD_MAX_STEPS),
+        ("dy_amax", vp * WGRAD_MAX_STEPS), ("x0_amax", vp * WGRAD_MAX_STEPS), ("x1_amax", vp * WGRAD_MAX_STEPS),
+        ("dw", vp), ("slabs", vp), ("slab_stride", i64),
+    ]
+
+
 # name -> argtypes (return type is always int unless listed in _RET)
 _SIGS = {
     "rac_conv2d": [C.POINTER(ConvArgs), vp],
@@ -37,6 +51,8 @@ _SIGS = {
     "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, vp, vp],
+    "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
+    "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
     "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp],
     "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],

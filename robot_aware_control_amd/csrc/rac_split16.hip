@@ -557,7 +557,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 // max |x| of one or two fp32 arrays as a bit pattern (non-negative floats order like unsigned integers):
 // *amax = max(*amax, bits(max |x|)).  The slot must hold 0 (or an earlier maximum) on entry.
 // ---------------------------------------------------------------------------------------------------------
-__global__ void absmax_kernel(const float4* x0, long n0v, const float4* x1, long n1v, unsigned* amax) {
+__global__ __launch_bounds__(256) void absmax_kernel(const float4* x0, long n0v, const float4* x1, long n1v,
+                                                     unsigned* amax) {
+  __shared__ unsigned sh[4];
   unsigned m = 0;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n0v + n1v; i += stride) {
@@ -568,7 +570,13 @@ __global__ void absmax_kernel(const float4* x0, long n0v, const float4* x1, long
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(amax, m);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+    // one atomic per workgroup, and only if it can raise the slot (all adders hit ONE address)
+    if (m > __hip_atomic_load(amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(amax, m);
+  }
 }
 
 // Conv weight [Cout][taps][Cin] fp32 -> fp16 parts of (w * scale) in MFMA fragment order:
@@ -607,6 +615,238 @@ __global__ void weight_frag16_kernel(const float* w, const unsigned* w_amax, uns
   *reinterpret_cast<u32x4*>(out + ps + o) = q[1];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient   dw[co][ky][kx][ci] (+)= sum_p dy[p][co] * x[p + (ky - pad, kx - pad)][ci]
+// as a GEMM over pixels (M = co, N = ci per tap, K = pixels), both operands read in their natural NHWC layout:
+// no transposed or shifted copies exist anywhere.
+//   * K walks pixel COLUMNS: one K block = the 32 pixels (image, y) x {one column c} of 32 consecutive image rows
+//     (any order of the K index is allowed as long as both operands use the same one).  All pixels of a block share
+//     their x coordinate, so a horizontal tap kx is either valid for the whole block or skipped -- no masks, and the
+//     border taps cost no MFMAs.
+//   * a workgroup = (128 co) x (64 ci) x (one kernel row ky, all KS kernel columns): it stages the dy tile of column c
+//     and keeps a ring of input columns c - pad .. c + pad (+1 being loaded), so ONE staged input column serves every
+//     horizontal tap; the vertical shift ky is folded into the staging address (rows outside the image are zeros).
+//   * fp32 -> two fp16 parts on the way into LDS ([pixel][channel] rows of 256 B, 32-byte segments XOR-swizzled by
+//     the row), and ds_read_b64_tr_b16 hands the MFMA its K-major fragments: the transposition is free.
+//   * time steps (and images) are just more K: up to 16 (dy, x0, x1) triples per launch, one read-modify-write of dw.
+// Deterministic: no atomics; a K split writes slabs that rac_slab_accumulate adds in a fixed order.
+// ---------------------------------------------------------------------------------------------------------
+struct Wgrad16P {
+  int Bimg, H, W, Cin, Cout, C0, T;
+  int R, G;      // image rows (Bimg * H) and 32-row groups per step
+  int nsplit, accumulate;
+  const float* dy[RAC_WGRAD_MAX_STEPS];
+  const float* x0[RAC_WGRAD_MAX_STEPS];
+  const float* x1[RAC_WGRAD_MAX_STEPS];
+  const unsigned* dy_amax[RAC_WGRAD_MAX_STEPS];
+  const unsigned* x0_amax[RAC_WGRAD_MAX_STEPS];
+  const unsigned* x1_amax[RAC_WGRAD_MAX_STEPS];
+  float* dw;
+  float* slabs;
+  long slab_stride;
+};
+
+typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+#define RAC_LDS_PTR(T, base, off) reinterpret_cast<__attribute__((address_space(3))) T*>( \
+    (__attribute__((address_space(3))) unsigned char*)(base) + (off))
+
+// the 16x16x32 operand of lane (i = l & 15, g = l >> 4): column i of pixel rows 8g .. 8g+7 of a [row][256 B] image
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int addr) {
+  const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds, addr));
+  const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds, addr + 1024));
+  f16x8 r;
+  r[0] = (_Float16)lo[0], r[1] = (_Float16)lo[1], r[2] = (_Float16)lo[2], r[3] = (_Float16)lo[3];
+  r[4] = (_Float16)hi[0], r[5] = (_Float16)hi[1], r[6] = (_Float16)hi[2], r[7] = (_Float16)hi[3];
+  return r;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
+  constexpr int PAD = KS / 2, NR = 2 * PAD + 2;
+  constexpr int DYB = 16384, XSLOT = 8192, X_BASE = 2 * DYB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64;
+  const int ky = blockIdx.z % KS, split = blockIdx.z / KS;
+  const bool first = ci0 < p.C0;
+  const int Cs = first ? p.C0 : p.Cin - p.C0;
+  const int cl0 = first ? ci0 : ci0 - p.C0;
+
+  unsigned amd = 0, amx = 0;
+  for (int t = 0; t < p.T; ++t) {
+    amd = max(amd, *p.dy_amax[t]);
+    amx = max(amx, *p.x0_amax[t]);
+    if (p.x1_amax[t]) amx = max(amx, *p.x1_amax[t]);
+  }
+  const int kd = scale_exp(amd), kxs = scale_exp(amx);
+  const float sd = pow2f(kd), sx = pow2f(kxs);
+
+  const int NG = p.T * p.G;
+  const int gpb = (NG + p.nsplit - 1) / p.nsplit;
+  const int g_begin = split * gpb;
+  const int g_end = min(NG, g_begin + gpb);
+  const int S = max(0, g_end - g_begin) * p.W;  // column steps of this workgroup
+
+  // ---- staging roles: row kk = tid >> 3 of the 32-row block; dy: 16 channels (segment tid & 7), x: 8 channels ----
+  const int skk = tid >> 3, ssub = tid & 7;
+  const int ssw = (skk & 3) | (((skk >> 3) & 1) << 2);
+  const int dy_lds = skk * 256 + ((ssub ^ ssw) * 32);                       // + buf * DYB + part * 8192
+  const int x_lds = X_BASE + skk * 256 + (((ssub >> 1) ^ ssw) * 32) + (ssub & 1) * 16;  // part 1: segment ^ 4 -> ^ 128
+  const bool dy_ch_ok = co0 + ssub * 16 < p.Cout;
+  const bool x_ch_ok = cl0 + ssub * 8 < Cs;
+  // loader cursors (uniform): dy column e_d, x column e_x, as (group, column) pairs
+  int dg = g_begin, dc = 0, xg = g_begin, xc = 0;
+  u32x4 rd[4], rx[2];
+  auto issue_dy = [&]() {
+    const int t = dg / p.G, gr = dg - t * p.G;
+    const int r = gr * 32 + skk;
+    const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
+    const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + ssub * 16) * 4u;
+    const bool ok = (r < p.R) & dy_ch_ok;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+    if (++dc == p.W) dc = 0, ++dg;
+  };
+  auto issue_x = [&]() {
+    const int t = xg / p.G, gr = xg - t * p.G;
+    const int r = gr * 32 + skk;
+    const int y = r % p.H + ky - PAD;
+    const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
+    const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+    const bool ok = (r < p.R) & ((unsigned)y < (unsigned)p.H) & x_ch_ok;
+    rx[0] = load16(rs, ok ? off : OOB);
+    rx[1] = load16(rs, ok ? off + 16u : OOB);
+    if (++xc == p.W) xc = 0, ++xg;
+  };
+  auto store_dy = [&](int buf) {
+    u32x4 q0[2], q1[2];
+    split8h(rd[0], rd[1], sd, q0);
+    split8h(rd[2], rd[3], sd, q1);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
+      *reinterpret_cast<u32x4*>(d) = q0[part];
+      *reinterpret_cast<u32x4*>(d + 16) = q1[part];
+    }
+  };
+  auto store_x = [&](int slot) {
+    u32x4 q[2];
+    split8h(rx[0], rx[1], sx, q);
+    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + x_lds) = q[0];
+    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + (x_lds ^ 128)) = q[1];
+  };
+
+  // ---- fragment addresses (lane constants) ----
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  const int fsw = fq | ((fg & 1) << 2);
+  const int lane_base = (8 * fg + fq) * 256 + fp * 8;
+  int offA[4], offB[2][2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) offA[t] = lane_base + (((wm * 4 + t) ^ fsw) * 32);
+#pragma unroll
+  for (int part = 0; part < 2; ++part)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) offB[part][u] = X_BASE + lane_base + (((part * 4 + wn * 2 + u) ^ fsw) * 32);
+
+  f32x4 acc[KS][4][2];
+#pragma unroll
+  for (int k = 0; k < KS; ++k)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) acc[k][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (S > 0) {
+    // prologue: input columns 0 .. PAD and the dy tile of column 0
+    for (int e = 0; e <= PAD && e < S; ++e) {
+      issue_x();
+      store_x(e);
+    }
+    issue_dy();
+    store_dy(0);
+    __syncthreads();
+    int c = 0, sm = 0;  // column of the current step inside its group, step index mod NR
+    for (int s = 0; s < S; ++s) {
+      const bool more_dy = s + 1 < S, more_x = s + PAD + 1 < S;
+      if (more_dy) issue_dy();
+      if (more_x) issue_x();
+      const int dbuf = (s & 1) * DYB;
+      f16x8 fa[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if ((unsigned)(c + k - PAD) >= (unsigned)p.W) continue;  // uniform: the tap leaves the image row
+        int sl = sm + k - PAD;
+        sl += sl < 0 ? NR : 0;
+        sl -= sl >= NR ? NR : 0;
+        f16x8 fb[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 2; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+      }
+      if (more_dy) store_dy((s + 1) & 1);
+      if (more_x) {
+        int sl = sm + PAD + 1;
+        sl -= sl >= NR ? NR : 0;
+        store_x(sl);
+      }
+      __syncthreads();
+      c = (c + 1 == p.W) ? 0 : c + 1;
+      sm = (sm + 1 == NR) ? 0 : sm + 1;
+    }
+  }
+
+  // ---- epilogue: rows (co) = 4 (lane >> 4) + reg of each 16-row block, column (ci) = lane & 15 ----
+  const float id = pow2f(-kd), ix = pow2f(-kxs);
+  const int lr = lane & 15, lq = lane >> 4;
+  float* dst = split == 0 ? p.dw : p.slabs + (long)(split - 1) * p.slab_stride;
+  const bool add = split == 0 && p.accumulate;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int cil = cl0 + wn * 32 + u * 16 + lr;  // channel inside its source
+    if (cil >= Cs) continue;
+    const int ci = (first ? 0 : p.C0) + cil;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wm * 64 + t * 16 + 4 * lq + r;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const long idx = (((long)co * KS + ky) * KS + k) * p.Cin + ci;
+          const float v = acc[k][t][u][r] * id * ix;
+          dst[idx] = add ? dst[idx] + v : v;
+        }
+      }
+  }
+}
+
+// out[i] += sum_s slabs[s * stride + i]
+__global__ void slab_accumulate_kernel(const float4* slabs, int n_slabs, long stride4, float4* out, long n4) {
+  const long st = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += st) {
+    float4 a = out[i];
+    for (int s = 0; s < n_slabs; ++s) {
+      const float4 b = slabs[s * stride4 + i];
+      a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+    out[i] = a;
+  }
+}
+
 }  // namespace rac
 
 using namespace rac;
@@ -615,8 +855,8 @@ extern "C" int rac_absmax(const float* x0, int64_t n0, const float* x1, int64_t 
   RAC_REQUIRE(x0 && n0 > 0 && n1 >= 0 && (n1 == 0 || x1) && amax, "rac_absmax: bad args");
   RAC_REQUIRE(n0 % 4 == 0 && n1 % 4 == 0 && aligned16(x0) && (!x1 || aligned16(x1)),
               "rac_absmax: element counts must be multiples of 4, pointers 16-byte aligned");
-  long nb = ((n0 + n1) / 4 + 255) / 256;
-  if (nb > 1024) nb = 1024;
+  long nb = ((n0 + n1) / 4 + 1023) / 1024;  // >= 4 vectors per thread
+  if (nb > 512) nb = 512;
   hipLaunchKernelGGL(absmax_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(x0), (long)(n0 / 4), reinterpret_cast<const float4*>(x1),
                      (long)(n1 / 4), amax);
@@ -717,4 +957,67 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
   hipLaunchKernelGGL(conv16_tile_kernel, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
+}
+
+extern "C" int rac_slab_accumulate(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, int64_t n,
+                                   void* stream) {
+  RAC_REQUIRE(slabs && out && n_slabs >= 1 && n > 0 && slab_stride >= n, "rac_slab_accumulate: bad args");
+  RAC_REQUIRE(n % 4 == 0 && slab_stride % 4 == 0 && aligned16(slabs) && aligned16(out), "rac_slab_accumulate: alignment");
+  long nb = (n / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(slab_accumulate_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(slabs), n_slabs, (long)(slab_stride / 4),
+                     reinterpret_cast<float4*>(out), (long)(n / 4));
+  return check_launch("rac_slab_accumulate");
+}
+
+extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
+  RAC_REQUIRE(a && a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->dw, "rac_conv2d_wgrad_split: bad args");
+  RAC_REQUIRE(a->ksize == 3 || a->ksize == 5, "rac_conv2d_wgrad_split: ksize must be 3 or 5");
+  RAC_REQUIRE(a->T >= 1 && a->T <= RAC_WGRAD_MAX_STEPS, "rac_conv2d_wgrad_split: 1 <= T <= RAC_WGRAD_MAX_STEPS");
+  Wgrad16P p{};
+  p.Bimg = a->B, p.H = a->H, p.W = a->W, p.Cin = a->Cin, p.Cout = a->Cout, p.T = a->T;
+  bool two = false;
+  for (int t = 0; t < a->T; ++t) {
+    RAC_REQUIRE(a->dy[t] && a->x0[t] && a->dy_amax[t] && a->x0_amax[t], "rac_conv2d_wgrad_split: null operand");
+    RAC_REQUIRE(aligned16(a->dy[t]) && aligned16(a->x0[t]) && (!a->x1[t] || aligned16(a->x1[t])),
+                "rac_conv2d_wgrad_split: alignment");
+    RAC_REQUIRE(!a->x1[t] || a->x1_amax[t], "rac_conv2d_wgrad_split: x1 needs its amax slot");
+    RAC_REQUIRE(t == 0 || (a->x1[t] != nullptr) == two, "rac_conv2d_wgrad_split: every step needs the same sources");
+    two = a->x1[t] != nullptr;
+    p.dy[t] = a->dy[t], p.x0[t] = a->x0[t], p.x1[t] = a->x1[t];
+    p.dy_amax[t] = a->dy_amax[t], p.x0_amax[t] = a->x0_amax[t], p.x1_amax[t] = a->x1[t] ? a->x1_amax[t] : nullptr;
+  }
+  p.C0 = (two && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
+  RAC_REQUIRE(two == (p.C0 < a->Cin), "rac_conv2d_wgrad_split: a_split must split Cin exactly when x1 is given");
+  RAC_REQUIRE(a->Cout % 16 == 0 && p.C0 % 8 == 0 && (a->Cin - p.C0) % 8 == 0,
+              "rac_conv2d_wgrad_split: Cout % 16 == 0 and input channel counts % 8 == 0");
+  RAC_REQUIRE(!two || p.C0 % 64 == 0, "rac_conv2d_wgrad_split: a_split must be a multiple of 64");
+  p.R = a->B * a->H;
+  p.G = cdiv(p.R, 32);
+  const long rowbytes = (long)p.R * a->W * 4;
+  RAC_REQUIRE(rowbytes * a->Cout < 0xFFFFFF00L && rowbytes * (p.C0 > a->Cin - p.C0 ? p.C0 : a->Cin - p.C0) < 0xFFFFFF00L,
+              "rac_conv2d_wgrad_split: operand larger than 4 GiB");
+  p.nsplit = a->nsplit >= 1 ? a->nsplit : 1;
+  RAC_REQUIRE(p.nsplit <= a->T * p.G && p.nsplit <= 1024, "rac_conv2d_wgrad_split: more K splits than 32-row groups");
+  const long n = (long)a->Cout * a->ksize * a->ksize * a->Cin;
+  RAC_REQUIRE(p.nsplit == 1 || (a->slabs && a->slab_stride >= n), "rac_conv2d_wgrad_split: slabs for the K split");
+  p.accumulate = a->accumulate;
+  p.dw = a->dw, p.slabs = a->slabs, p.slab_stride = a->slab_stride;
+  const int ct = cdiv(a->Cout, 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
+  dim3 grid(ct, nt, a->ksize * p.nsplit);
+  typedef void (*fn_t)(Wgrad16P);
+  const fn_t fn = a->ksize == 5 ? (fn_t)wgrad16_kernel<5> : (fn_t)wgrad16_kernel<3>;
+  const int lds = 2 * 16384 + (a->ksize + 1) * 8192;
+  static bool attr_done[2] = {false, false};
+  if (!attr_done[a->ksize == 5]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) {
+      set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+      return RAC_ELAUNCH;
+    }
+    attr_done[a->ksize == 5] = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("rac_conv2d_wgrad_split");
 }

@@ -139,7 +139,8 @@ class _LstmCell(nn.Module):
         self.gates = _Conv(2 * g, 4 * g, k)
 
     def forward(self, x, state):
-        return ops.LstmCell.apply(x, state[0], state[1], self.gates.weight, self.gates.bias, torch.is_grad_enabled())
+        h, c = ops.LstmCell.apply(x, state[0], state[1], self.gates.weight, self.gates.bias, torch.is_grad_enabled())
+        return ops.tag_amax(h, ops.amax_one(h.device)), c  # |h| = |o * tanh(c)| < 1
 
 
 class _GroupNorm(nn.Module):
@@ -172,7 +173,8 @@ class _NormLstmCell(nn.Module):
         g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE))
         c_raw, act = ops.NormCellCore.apply(g_ih, g_hh, c_prev)
         c = self.c_norm(c_raw)
-        return ops.LstmOut.apply(act, c), c
+        h = ops.LstmOut.apply(act, c)
+        return ops.tag_amax(h, ops.amax_one(h.device)), c  # |h| = |o * tanh(c)| < 1
 
 
 class _ConvLSTM(nn.Module):
@@ -191,8 +193,9 @@ class _ConvLSTM(nn.Module):
         b = self.batch_size if batch_size is None else batch_size
         dev = next(self.parameters()).device
         h, w = self._hw
-        return [(torch.zeros(b, h, w, self.hid_ch, device=dev), torch.zeros(b, h, w, self.hid_ch, device=dev))
-                for _ in self.lstm]
+        one = ops.amax_one(dev)
+        return [(ops.tag_amax(torch.zeros(b, h, w, self.hid_ch, device=dev), one),
+                 torch.zeros(b, h, w, self.hid_ch, device=dev)) for _ in self.lstm]
 
     def forward(self, x):
         for i, cell in enumerate(self.lstm):

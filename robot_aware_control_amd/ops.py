@@ -25,7 +25,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, call, ptr, stream_ptr
+from ._lib import ConvArgs, WgradArgs, call, ptr, stream_ptr
 
 FWD, DGRAD, WGRAD = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
@@ -287,6 +287,17 @@ def tag_amax(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def amax_tag(t):
+    return None if t is None else getattr(t, "_rac_amax", None)
+
+
+def retag(t, slot):
+    """Saved tensors come back from autograd as new Python objects: put the slot measured in forward() back on."""
+    if t is not None and slot is not None:
+        t._rac_amax = slot
+    return t
+
+
 def amax_for(t: torch.Tensor) -> torch.Tensor:
     slot = getattr(t, "_rac_amax", None)
     if slot is None:
@@ -440,17 +451,73 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
     _wgrad_split_batch([(dy, x0, x1)], weight)
 
 
+def wgrad_split_ok(x0, x1, weight) -> bool:
+    """Shapes rac_conv2d_wgrad_split takes (anything else goes to the exact-fp32 MFMA kernel)."""
+    co, _, k, _ = weight.shape
+    c0 = x0.shape[3]
+    c1 = x1.shape[3] if x1 is not None else 0
+    return SPLIT_GEMM and k in (3, 5) and co % 16 == 0 and c0 % 8 == 0 and c1 % 8 == 0 and (c1 == 0 or c0 % 64 == 0)
+
+
+def plan_wgrad_split(tiles: int, groups: int) -> int:
+    """K splits of a weight-gradient launch: 512 workgroups run at a time (2 per CU); pick the split whose last round
+    is fullest (each extra split costs a slab write + read of the gradient)."""
+    forced = os.environ.get("RAC_WGRAD_SPLITK")
+    if forced:
+        return max(1, min(int(forced), groups))
+    best, best_eff = 1, 0.0
+    for ns in range(1, min(groups, 64) + 1):
+        rounds = tiles * ns / 512.0
+        eff = rounds / -(-rounds // 1) - 0.03 * (ns - 1) if rounds > 1 else rounds - 0.002 * (ns - 1)
+        if eff > best_eff + 1e-9:
+            best, best_eff = ns, eff
+    return best
+
+
 def _wgrad_split_batch(items, weight):
-    # interim: exact-fp32 MFMA weight gradient per step (the fp16-split kernel replaces this)
-    for dy, x0, x1 in items:
-        if x1 is None and x0.shape[3] > weight.shape[1]:
-            wgrad_padded_acc(dy, x0, weight)
-        else:
-            conv_wgrad_acc(dy, x0, x1, weight)
-
-
-def wgrad_split_ok(x0, x1, W: int) -> bool:
-    return SPLIT_GEMM_TRAIN
+    """weight.grad += sum over the recorded (dy, x0, x1) triples: ONE launch of the column-walking split-precision
+    kernel per 16 time steps (operands in their natural NHWC layout; no transposed copies)."""
+    dy, x0, x1 = items[0]
+    B, H, W, Cout = dy.shape
+    Co, Cin, k, _ = weight.shape
+    C0 = x0.shape[3]
+    if not wgrad_split_ok(x0, x1, weight):
+        for dy_t, x0_t, x1_t in items:
+            if x1_t is None and x0_t.shape[3] > Cin:
+                wgrad_padded_acc(dy_t, x0_t, weight)
+            else:
+                conv_wgrad_acc(dy_t, x0_t, x1_t, weight)
+        return
+    ci_real = Cin
+    if x1 is None and C0 > Cin:  # x0 carries zero pad channels (32-channel chunks): gradient of the padded weight
+        Cin = C0
+    sp = stream_ptr()
+    dev = dy.device
+    if Cin != ci_real:
+        g = torch.zeros((Cout, k, k, Cin), device=dev, dtype=torch.float32)
+    else:
+        g = weight_mem(grad_buffer(weight))
+    n = Cout * k * k * Cin
+    tiles = _cdiv(Cout, 128) * (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
+    keep = []
+    for lo in range(0, len(items), _lib.WGRAD_MAX_STEPS):
+        chunk = items[lo:lo + _lib.WGRAD_MAX_STEPS]
+        T = len(chunk)
+        ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
+        slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
+        a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns, accumulate=1,
+                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n)
+        for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
+            assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
+            a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
+            a.dy_amax[t], a.x0_amax[t] = ptr(amax_for(dy_t)), ptr(amax_for(x0_t))
+            a.x1_amax[t] = ptr(amax_for(x1_t)) if x1_t is not None else None
+        call("rac_conv2d_wgrad_split", C.byref(a), sp)
+        if ns > 1:
+            call("rac_slab_accumulate", ptr(slabs), ns - 1, n, ptr(g), n, sp)
+        keep.append(slabs)
+    if Cin != ci_real:
+        call("rac_unpad_add", ptr(g), Cin, ptr(weight_mem(grad_buffer(weight))), ci_real, Cout * k * k, sp)
 
 
 # --------------------------------------------------------------------------- #
@@ -501,6 +568,7 @@ class ConvBias(torch.autograd.Function):
             if not frozen:
                 ctx.save_for_backward(x0, None, weight, bias, None)
                 ctx.act, ctx.padded, ctx.split = act, False, False
+                ctx.amax = (amax_tag(x0), None)
             return y
         padded = ci % 4 != 0 and x1 is None and x0.shape[3] == ci + pad4(ci)
         w = padded_weight(weight) if padded else weight
@@ -514,11 +582,13 @@ class ConvBias(torch.autograd.Function):
             y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
         ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
         ctx.act, ctx.padded = act, padded
+        ctx.amax = (amax_tag(x0), amax_tag(x1))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x0, x1, weight, bias, y = ctx.saved_tensors
+        retag(x0, ctx.amax[0]), retag(x1, ctx.amax[1])
         dy = dy.contiguous()
         if ctx.act != ACT_NONE:
             d = torch.empty_like(dy)
@@ -543,7 +613,7 @@ class ConvBias(torch.autograd.Function):
         if weight.requires_grad:
             if ctx.padded:
                 wgrad_padded_acc(dy, x0, weight)
-            elif ctx.split and wgrad_split_ok(x0, x1, x0.shape[2]):
+            elif ctx.split:
                 conv_wgrad_split_acc(dy, x0, x1, weight, defer=True)  # time-batched inside deferred_wgrad()
             else:
                 conv_wgrad_acc(dy, x0, x1, weight)
@@ -631,11 +701,13 @@ class VggLayer(torch.autograd.Function):
         y = torch.empty_like(raw)
         call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, G, stream_ptr())
         ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
+        ctx.amax = (amax_tag(x0), amax_tag(x1))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x0, x1, weight, gamma, beta, raw, aff = ctx.saved_tensors
+        retag(x0, ctx.amax[0]), retag(x1, ctx.amax[1])
         dy = dy.contiguous()
         Cout = weight.shape[0]
         M = raw.numel() // Cout
@@ -659,7 +731,7 @@ class VggLayer(torch.autograd.Function):
         if weight.requires_grad:
             if ctx.padded:
                 wgrad_padded_acc(draw, x0, weight)
-            elif ctx.split and wgrad_split_ok(x0, x1, x0.shape[2]):
+            elif ctx.split:
                 conv_wgrad_split_acc(draw, x0, x1, weight)
             else:
                 conv_wgrad_acc(draw, x0, x1, weight)
@@ -673,7 +745,7 @@ class MaxPool2(torch.autograd.Function):
         y = torch.empty((B, H // 2, W // 2, Cc), device=x.device, dtype=torch.float32)
         call("rac_maxpool2_fwd", ptr(x), ptr(y), B, H, W, Cc, stream_ptr())
         ctx.save_for_backward(x)
-        return y
+        return retag(y, amax_tag(x))  # max |y| <= max |x|: the input's slot is a valid bound
 
     @staticmethod
     def backward(ctx, dy):
@@ -691,7 +763,7 @@ class Upsample2(torch.autograd.Function):
         y = torch.empty((B, 2 * h, 2 * w, Cc), device=x.device, dtype=torch.float32)
         call("rac_upsample2_fwd", ptr(x), ptr(y), B, h, w, Cc, stream_ptr())
         ctx.shape = (B, h, w, Cc)
-        return y
+        return retag(y, amax_tag(x))
 
     @staticmethod
     def backward(ctx, dy):
@@ -762,11 +834,13 @@ class LstmCell(torch.autograd.Function):
              B * H * W, g, stream_ptr())
         if need_bwd:
             ctx.save_for_backward(x, h_prev, c_prev, weight, bias, act, c)
+            ctx.amax = (amax_tag(x), amax_tag(h_prev))
         return h, c
 
     @staticmethod
     def backward(ctx, dh, dc):
         x, h_prev, c_prev, weight, bias, act, c = ctx.saved_tensors
+        retag(x, ctx.amax[0]), retag(h_prev, ctx.amax[1])
         B, H, W, g = x.shape
         M = B * H * W
         dgates = torch.empty_like(act)
