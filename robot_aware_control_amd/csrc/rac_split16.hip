@@ -115,11 +115,20 @@ __device__ __forceinline__ void conv16_epilogue_store(const Conv16P& p, float v,
   p.out0[idx] = v;
 }
 
+// WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
+// columns (half the LDS fragment reads and tap-shift selects per MFMA, twice the weight loads per wave).
+// FULL: the tile is 128 rows (8x8 / 4x8 / ... maps): no per-block liveness tests inside the loop.
+template <int WM, bool FULL>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
+  constexpr int WN = 4 / WM;   // waves along the columns
+  constexpr int RB = 8 / WM;   // 16-row blocks per wave
+  constexpr int NT = WM;       // 32-column weight tiles per wave
+  constexpr int NB = 2 * NT;   // 16-column blocks per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 15, lq = lane >> 4;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
   if (p.xcd_group) {
@@ -131,8 +140,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     by = grp % nt;
     bz = grp / nt;
   }
-  const int TM = p.tile_m;
-  const int nmb = TM >> 4;  // live 16-row blocks of the wave's 8
+  const int TM = FULL ? 128 : p.tile_m;
+  const int nmb = FULL ? 8 : TM >> 4;  // live 16-row blocks of the tile's 8
   const int m0 = bx * TM, n0 = by * SBN;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
@@ -149,10 +158,10 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 
   const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
   const bool a_ok = (srow < TM) & (m0 + srow < p.M);
-  unsigned amask[8];  // per 16-row block: one bit per tap for the shifted pixel's validity
+  unsigned amask[RB];  // per 16-row block: one bit per tap for the shifted pixel's validity
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int r = t * 16 + lr;
+  for (int t = 0; t < RB; ++t) {
+    const int r = (wm * RB + t) * 16 + lr;
     const int im = r / p.HW;
     const int q = r - im * p.HW;
     const int y = q / p.W, x = q - y * p.W;
@@ -163,20 +172,26 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
     amask[t] = mk;
   }
-  const int abase = lq * T16_CP + lr * 16;  // block t adds t * 256
+  const int abase = lq * T16_CP + (wm * RB * 16 + lr) * 16;  // block t adds t * 256
   const int zrow = lq * T16_CP + 128 * 16;
-  const int ntile = (n0 >> 5) + wid;
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
-  const unsigned b_off0 = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
-  auto load_b = [&](u32x4(&rb)[4], int kc) {
+  unsigned b_off[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ntile = (n0 >> 5) + wn * NT + j;
+    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+  }
+  auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
     const int so = kc * 2048;
 #pragma unroll
-    for (int part = 0; part < 2; ++part)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        rb[part * 2 + nb] = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off0 + part * w_pstride + nb * 1024u), so, 0));
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          rb[(j * 2 + part) * 2 + nb] = __builtin_bit_cast(
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), so, 0));
   };
   u32x4 ra[4];  // fp32 activations: [chunk i][half]
   auto issue_a = [&](int cc) {
@@ -203,11 +218,11 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
   };
 
-  f32x4 acc[8][2];
+  f32x4 acc[RB][NB];
 #pragma unroll
-  for (int i = 0; i < 8; ++i)
+  for (int i = 0; i < RB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kc_begin < kc_end) {
     int cc = kc_begin / p.taps;
@@ -215,14 +230,17 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     int ky = tap / p.ks, kx = tap - ky * p.ks;
     int cur = 0;
     bool fresh = true;
-    u32x4 b0[4], b1[4], b2[4];
+    // weights two steps ahead in three register sets.  (Measured alternatives, M = 1024 / 64 000 gate GEMM: A fragments
+    // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; this
+    // form 437 / 477.)
+    u32x4 b0[4 * NT], b1[4 * NT], b2[4 * NT];
     issue_a(cc);
     load_b(b0, kc_begin);
     load_b(b1, kc_begin + 1);
     store_a(0);
     __syncthreads();
 
-    auto step = [&](const u32x4(&rb)[4], int kc) {
+    auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
       const bool last_tap = tap == p.taps - 1;
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
@@ -233,18 +251,21 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       // would have used, so that the read group stays conflict-free
       const int zr = zrow + cur * T16_ABUF + ((lr + drow) & 15) * 16;
       const unsigned bit = 1u << tap;
-      f16x8 fb[2][2];
+      f16x8 fb[NB][2];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int part = 0; part < 2; ++part) fb[nb][part] = __builtin_bit_cast(f16x8, rb[part * 2 + nb]);
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+          for (int part = 0; part < 2; ++part)
+            fb[j * 2 + nb][part] = __builtin_bit_cast(f16x8, rb[(j * 2 + part) * 2 + nb]);
+#pragma unroll
+      for (int h = 0; h < RB / 4; ++h) {
         f16x8 fa[4][2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
-          if (mb >= nmb) continue;  // wave-uniform
+          if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
           const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
           for (int part = 0; part < 2; ++part)
@@ -253,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            if (4 * h + t >= nmb) continue;
+          for (int nb = 0; nb < NB; ++nb) {
+            if (!FULL && wm * RB + 4 * h + t >= nmb) continue;
             acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
           }
       }
@@ -288,8 +309,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const float ia = pow2f(-ka), iw = pow2f(-kw);
   const bool slab = p.split_k > 1;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = n0 + wid * 32 + nb * 16 + lr;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + wn * NT * 32 + nb * 16 + lr;
     const bool nok = n < p.N;
     float bias = 0.f, sc = 1.f, sh = 0.f;
     if (!slab && nok) {
@@ -301,11 +322,11 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
+    for (int mb = 0; mb < RB; ++mb) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + mb * 16 + 4 * lq + r;
-        if (mb >= nmb || m >= p.M || !nok) continue;
+        const int m = m0 + (wm * RB + mb) * 16 + 4 * lq + r;
+        if (wm * RB + mb >= nmb || m >= p.M || !nok) continue;
         const float v = acc[mb][nb][r] * ia * iw;
         if (slab) {
           p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
@@ -955,7 +976,12 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
   p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
   constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
-  hipLaunchKernelGGL(conv16_tile_kernel, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
+  static const char* wm_env = getenv("RAC_TILE_WM");  // A/B: wave arrangement of the tile kernel
+  const int wm = wm_env ? atoi(wm_env) : 2;
+  typedef void (*tile_fn)(Conv16P);
+  static const tile_fn fns[2][2] = {{conv16_tile_kernel<1, false>, conv16_tile_kernel<1, true>},
+                                    {conv16_tile_kernel<2, false>, conv16_tile_kernel<2, true>}};
+  hipLaunchKernelGGL(fns[wm == 2][p.tile_m == 128], grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
 }
 

@@ -134,6 +134,19 @@ def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> in
 # bench.py sets PROFILE = {"match": (mode, ksize, Cin, Cout), "events": []} to time ONE kernel shape with
 # HIP events on the launch stream (torch.cuda.Event records on the current stream = the launch stream).
 PROFILE = None
+# RAC_SHAPE_LOG=<file>: every conv launch appends (kernel family, mode, k, M, N, K, algorithmic FLOP, pipe peak) here and
+# the list is written to <file> at exit; tools/shape_profile.py joins it with a rocprofv3 kernel trace (same launch
+# order) into the per-shape roofline table kept under profiles/.
+SHAPE_LOG = [] if os.environ.get("RAC_SHAPE_LOG") else None
+if SHAPE_LOG is not None:
+    import atexit
+    import json as _json
+    atexit.register(lambda: _json.dump(SHAPE_LOG, open(os.environ["RAC_SHAPE_LOG"], "w")))
+
+
+def _log_shape(family, mode, k, M, N, K, peak):
+    SHAPE_LOG.append({"family": family, "mode": ("fwd", "dgrad", "wgrad")[mode], "k": k, "M": M, "N": N, "K": K,
+                      "flop": 2.0 * M * N * K, "peak": peak})
 
 
 def conv_raw(mode: int, a0, a1, w, out0, out1=None, *, B, H, W, ksize, Cin, Cout, act=ACT_NONE, split_k=1,
@@ -158,6 +171,11 @@ def _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, sp
                     accumulate=accumulate, a_split=a_split, o_split=o_split, slab_stride=slab_stride,
                     a0=ptr(a0), a1=ptr(a1), w=ptr(w), out0=ptr(out0), out1=ptr(out1), bias=ptr(bias),
                     scale=ptr(scale), shift=ptr(shift), stats=ptr(stats), stats_rows=stats_rows)
+    if SHAPE_LOG is not None:
+        M, N, K = B * H * W, (Cout if mode == FWD else Cin), (Cin if mode == FWD else Cout) * ksize * ksize
+        if mode == WGRAD:
+            M, N, K = Cout, Cin * ksize * ksize, B * H * W
+        _log_shape("igemm", mode, ksize, M, N, K, 157.3)
     call("rac_conv2d", C.byref(args), stream_ptr())
 
 
@@ -248,7 +266,7 @@ SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = SPLIT_GEMM
 # narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
-SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "128"))
+SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "64"))
 
 _AMAX = {"buf": None, "used": 0, "one": None}
 _AMAX_SLOTS = 1 << 14
@@ -333,6 +351,7 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
         n = w.numel()
         parts = torch.empty((2, n), device=w.device, dtype=torch.float16)
         call("rac_weight_frag_split", ptr(w), ptr(slot), ptr(parts), co, ci, k, 1 if transposed else 0, n, stream_ptr())
+        parts._rac_transposed = transposed
         return parts, slot
     return _derived(weight, "_rac_parts_t" if transposed else "_rac_parts", build)
 
@@ -348,6 +367,9 @@ def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, 
     if timed:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    if SHAPE_LOG is not None:
+        _log_shape("conv16", DGRAD if getattr(pw, "_rac_transposed", False) else FWD, k, B * H * W, Cout, Cin * k * k,
+                   2500.0 / 3)
     call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], ptr(wslot), stream_ptr())
     if timed:
         e1.record()
@@ -512,6 +534,8 @@ def _wgrad_split_batch(items, weight):
             a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
             a.dy_amax[t], a.x0_amax[t] = ptr(amax_for(dy_t)), ptr(amax_for(x0_t))
             a.x1_amax[t] = ptr(amax_for(x1_t)) if x1_t is not None else None
+        if SHAPE_LOG is not None:
+            _log_shape("wgrad16", WGRAD, k, Cout, Cin * k * k, T * B * H * W, 2500.0 / 3)
         call("rac_conv2d_wgrad_split", C.byref(a), sp)
         if ns > 1:
             call("rac_slab_accumulate", ptr(slabs), ns - 1, n, ptr(g), n, sp)
