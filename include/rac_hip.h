@@ -116,7 +116,10 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
  * parts of rac_weight_frag_split, a_amax0 / a_amax1 the maxima of a0 / a1 (a_amax1 may be NULL), w_amax as given to
  * rac_weight_frag_split.  The data gradient of a conv is this call on dy with the transposed parts. */
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
-                         int64_t w_part_stride, const uint32_t* w_amax, void* stream);
+                         int64_t w_part_stride, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
+/* `*_amax` OUTPUT arguments (here and on rac_affine_act, rac_bn_bwd_apply, rac_tilecat_fwd, rac_slab_reduce,
+ * rac_lstm_cell_bwd; nullable): the kernel folds max |v| of the tensor it writes into the slot as rac_absmax would,
+ * which saves the consumer conv a reduction pass over it (split_k > 1 writes raw slabs: no out_amax there). */
 
 /* Weight gradient dw[co][ky][kx][ci] (+)= sum_{steps, pixels} dy[p][co] x[p+tap][ci] on the same pipe (the backward of
  * the conv2d call sites above; aten::conv2d backward w.r.t. the weight).  Operands are the fp32 NHWC tensors as the
@@ -162,7 +165,7 @@ int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, cons
                     float* mean, float* invstd, int32_t C, int32_t groups, void* stream);
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c]) */
 int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
-                   int32_t C, int32_t groups, void* stream);
+                   int32_t C, int32_t groups, uint32_t* y_amax, void* stream);
 /* sums = fp64 [2][C]: sum dz, sum dz*xhat  with z = x*scale+shift, dz = dy*(z>0?1:0.2), xhat=(x-mean)*invstd.
  * `sums` must be zero on entry. */
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
@@ -170,7 +173,7 @@ int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const
 /* dx = scale*(dz - sum_dz/M - xhat*sum_dzx/M); dgamma += sum_dzx; dbeta += sum_dz */
 int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                      const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
-                     int32_t C, int32_t groups, void* stream);
+                     int32_t C, int32_t groups, uint32_t* dx_amax, void* stream);
 
 /* MaxPool2d(2,2) / nearest x2 upsample on NHWC maps: vgg_64.py:120,126-128 / :221,235-240 */
 int rac_maxpool2_fwd(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
@@ -183,7 +186,7 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
  * action / robot-state tiling + channel concat in front of the three input convs) */
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
                     const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
-                    int32_t HW, void* stream); /* `pad` trailing zero channels */
+                    int32_t HW, uint32_t* out_amax, void* stream); /* `pad` trailing zero channels */
 /* dst[r][0:C] = src[r][0:C], dst[r][C:Cpad] = 0  -- 16-byte aligned rows for the vector-load conv path
  * (weights of the convs whose channel count is not a multiple of 4: first encoder layer, the three input convs) */
 int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t R, void* stream);
@@ -196,7 +199,7 @@ int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* strea
 
 /* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
-                    int64_t n, int32_t N, void* stream);
+                    int64_t n, int32_t N, uint32_t* out_amax, void* stream);
 /* as rac_slab_reduce for [M][N] slabs, but columns [0,o_split) go to out0 (row stride o_split) and the rest to
  * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat */
 int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
@@ -214,7 +217,8 @@ int rac_lstm_cell_fwd(const float* gate_slabs, int32_t n_slabs, int64_t slab_str
                       void* stream);
 /* dgates[M][4g] (pre-activation grads), dc_prev[M][g]; dc_next may be NULL (zero). */
 int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev,
-                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, void* stream);
+                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, uint32_t* dgates_amax,
+                      void* stream);
 
 /* ------------------------------------------------------------------------ *
  * NormConvLSTMCell (--lstm_group_norm True, lstm.py:151-198): GroupNorm(16, C) on NHWC maps and the

@@ -50,28 +50,28 @@ _SIGS = {
     "rac_absmax": [vp, i64, vp, i64, vp, vp],
     "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
-    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, vp, vp],
+    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
     "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
-    "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp],
+    "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp, vp],
     "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
-    "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
+    "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
     "rac_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "rac_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_bwd": [vp, vp, i32, i32, i32, i32, vp],
-    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
+    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp],
     "rac_pad_rows": [vp, i32, vp, i32, i64, vp],
     "rac_unpad_add": [vp, i32, vp, i32, i64, vp],
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
     "rac_colsum_acc": [vp, vp, i64, i32, vp],
-    "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp],
+    "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp, vp],
     "rac_slab_reduce2": [vp, i32, i64, vp, vp, i64, i32, i32, vp],
     "rac_col_stats": [vp, vp, i64, i32, i32, vp],
     "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
-    "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "rac_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "rac_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],

@@ -48,4 +48,29 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// max |v| bookkeeping for the split-precision convs (include/rac_hip.h, rac_absmax): a kernel that produces a
+// tensor folds the bit pattern of its max |v| into a device slot -- wave reduce, then at most one atomic per wave and
+// only if it can raise the slot.  Every lane of the wave must call amax_commit.
+__device__ __forceinline__ unsigned absbits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu; }
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned* slot) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+}
+
+// Workgroup form for the streaming kernels (every thread of the workgroup must call it): one conditional atomic per
+// workgroup -- thousands of waves hitting ONE address cost tens of microseconds.
+__device__ __forceinline__ void amax_commit_block(unsigned m, unsigned* slot) {
+  __shared__ unsigned amax_sh[16];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) amax_sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int w = 1; w < nw; ++w) m = max(m, amax_sh[w]);
+    if (m > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, m);
+  }
+}
+
 }  // namespace rac

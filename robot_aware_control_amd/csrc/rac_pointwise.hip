@@ -3,6 +3,8 @@
 // bias gradients and the fused Adam step.  fp32 NHWC maps ([M = B*H*W][C]).
 // Elementwise kernels move 16 B per lane when C % 4 == 0 and grid-stride over
 // at most 2048 workgroups (256 CUs x 8).
+#include <stdlib.h>
+
 #include "rac_common.h"
 
 namespace rac {
@@ -18,6 +20,11 @@ void set_error(const char* fmt, ...) {
 static inline int grid_for(long work_items) {
   long b = (work_items + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+// grid of a kernel that also commits a max |v| slot: fewer, longer workgroups (one atomic each on ONE address)
+static inline int grid_for_amax(long work_items, const void* amax) {
+  const int g = grid_for(work_items);
+  return amax && g > 512 ? 512 : g;  // measured on the cfg2 train step: 512 -> 34.5 ms, 2048 -> 35.5, 128 -> 38-40
 }
 
 // ------------------------------------------------------------------ BatchNorm
@@ -63,21 +70,30 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 // scale / shift are [G][C]; `ge` = elements (vectors) per group
 __global__ void affine_act_kernel4(const f32x4* x, const f32x4* scale, const f32x4* shift, int act, f32x4* y, long n4,
-                                   int C4, long ge) {
+                                   int C4, long ge, unsigned* amax) {
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % C4) + (int)(i / ge) * C4;
     f32x4 v = x[i], s = scale[c], t = shift[c], o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = act_apply(v[e] * s[e] + t[e], act);
+    for (int e = 0; e < 4; ++e) {
+      o[e] = act_apply(v[e] * s[e] + t[e], act);
+      mx = max(mx, absbits(o[e]));
+    }
     y[i] = o;
   }
+  if (amax) amax_commit_block(mx, amax);
 }
 __global__ void affine_act_kernel1(const float* x, const float* scale, const float* shift, int act, float* y, long n,
-                                   int C, long ge) {
+                                   int C, long ge, unsigned* amax) {
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % C) + (int)(i / ge) * C;
-    y[i] = act_apply(x[i] * scale[c] + shift[c], act);
+    const float o = act_apply(x[i] * scale[c] + shift[c], act);
+    mx = max(mx, absbits(o));
+    y[i] = o;
   }
+  if (amax) amax_commit_block(mx, amax);
 }
 
 // Per-channel reductions over M rows.  grid = (row blocks, 64-channel groups), block = 4 row lanes x 64 channel
@@ -117,9 +133,10 @@ __global__ void bn_bwd_reduce_kernel(const float* dy, const float* x, const floa
 
 __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float* scale, const float* shift,
                                     const float* mean, const float* invstd, const double* sums, float* dx,
-                                    float* dgamma, float* dbeta, long Mg, int C, int G) {
+                                    float* dgamma, float* dbeta, long Mg, int C, int G, unsigned* amax) {
   const long ge = Mg * C, n = ge * G;
   const double invM = 1.0 / (double)Mg;
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C), g = (int)(i / ge);
     const int gc = g * C + c;
@@ -129,8 +146,11 @@ __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float
     float xh = (xv - mean[gc]) * invstd[gc];
     const double* sg = sums + (long)g * 2 * C;
     float m1 = (float)(sg[c] * invM), m2 = (float)(sg[C + c] * invM);
-    dx[i] = sc * (dz - m1 - xh * m2);
+    const float o = sc * (dz - m1 - xh * m2);
+    mx = max(mx, absbits(o));
+    dx[i] = o;
   }
+  if (amax) amax_commit_block(mx, amax);
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       double a = 0., b = 0.;
@@ -227,10 +247,12 @@ __global__ void upsample2_bwd_kernel(const T* dy, T* dx, int B, int h, int w, in
 
 // ------------------------------------------------------------ tiling / slices
 __global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1, const float* v2, int n2,
-                               const float* m0, int c0, const float* m1, int c1, int pad, float* out, int B, int HW) {
+                               const float* m0, int c0, const float* m1, int c1, int pad, float* out, int B, int HW,
+                               unsigned* amax) {
   const int Cv = n0 + n1 + n2 + c0 + c1;
   const int Ct = Cv + pad;
   const long n = (long)B * HW * Ct;
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     int c = (int)(i % Ct);
     long q = i / Ct;  // b*HW + p
@@ -248,8 +270,10 @@ __global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1,
       v = m1[q * c1 + (c - n0 - n1 - n2 - c0)];
     else
       v = 0.f;
+    mx = max(mx, absbits(v));
     out[i] = v;
   }
+  if (amax) amax_commit_block(mx, amax);
 }
 
 __global__ void pad_rows_kernel(const float* src, int C, float* dst, int Cpad, long R) {
@@ -296,12 +320,15 @@ __global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int
 }
 
 __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out,
-                                   long n, int N) {
+                                   long n, int N, unsigned* amax) {
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     float a = bias ? bias[i % N] : 0.f;
     for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + i];
+    mx = max(mx, absbits(a));
     out[i] = a;
   }
+  if (amax) amax_commit_block(mx, amax);
 }
 
 __global__ void col_stats_kernel(const float* x, double* stats, long Mg, int C, int rows_per_block, int bpg) {
@@ -386,8 +413,9 @@ __global__ void lstm_cell_fwd_kernel(const float* slabs, int n_slabs, long slab_
 }
 
 __global__ void lstm_cell_bwd_kernel(const float* dh, const float* dc_next, const float* act, const float* c_prev,
-                                     const float* c_new, float* dgates, float* dc_prev, long M, int g) {
+                                     const float* c_new, float* dgates, float* dc_prev, long M, int g, unsigned* amax) {
   const long n = M * g;
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long m = i / g;
     int c = (int)(i - m * g);
@@ -397,12 +425,13 @@ __global__ void lstm_cell_bwd_kernel(const float* dh, const float* dc_next, cons
     float dhv = dh ? dh[i] : 0.f;
     float dc = dhv * go * (1.f - tc * tc) + (dc_next ? dc_next[i] : 0.f);
     float* d = dgates + m * 4 * g + c;
-    d[0] = dc * gg * gi * (1.f - gi);
-    d[g] = dc * c_prev[i] * gf * (1.f - gf);
-    d[2 * g] = dhv * tc * go * (1.f - go);
-    d[3 * g] = dc * gi * (1.f - gg * gg);
+    const float d0 = dc * gg * gi * (1.f - gi), d1 = dc * c_prev[i] * gf * (1.f - gf),
+                d2 = dhv * tc * go * (1.f - go), d3 = dc * gi * (1.f - gg * gg);
+    d[0] = d0, d[g] = d1, d[2 * g] = d2, d[3 * g] = d3;
+    mx = max(max(mx, absbits(d0)), max(max(absbits(d1), absbits(d2)), absbits(d3)));
     dc_prev[i] = dc * gf;
   }
+  if (amax) amax_commit_block(mx, amax);
 }
 
 __global__ void reparam_fwd_kernel(const float* mu, const float* lv, const float* eps, float* z, long n) {
@@ -461,15 +490,15 @@ int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, cons
 }
 
 int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
-                   int32_t C, int32_t groups, void* stream) {
+                   int32_t C, int32_t groups, uint32_t* y_amax, void* stream) {
   RAC_REQUIRE(x && scale && shift && y && M > 0 && C > 0 && groups >= 1 && M % groups == 0, "rac_affine_act: bad args");
   long n = (long)M * C;
   if (C % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(scale) && aligned16(shift)) {
-    hipLaunchKernelGGL(affine_act_kernel4, dim3(grid_for(n / 4)), dim3(256), 0, ST(stream), (const f32x4*)x,
-                       (const f32x4*)scale, (const f32x4*)shift, act, (f32x4*)y, n / 4, C / 4, n / 4 / groups);
+    hipLaunchKernelGGL(affine_act_kernel4, dim3(grid_for_amax(n / 4, y_amax)), dim3(256), 0, ST(stream), (const f32x4*)x,
+                       (const f32x4*)scale, (const f32x4*)shift, act, (f32x4*)y, n / 4, C / 4, n / 4 / groups, y_amax);
   } else {
-    hipLaunchKernelGGL(affine_act_kernel1, dim3(grid_for(n)), dim3(256), 0, ST(stream), x, scale, shift, act, y, n, C,
-                       n / groups);
+    hipLaunchKernelGGL(affine_act_kernel1, dim3(grid_for_amax(n, y_amax)), dim3(256), 0, ST(stream), x, scale, shift, act, y, n, C,
+                       n / groups, y_amax);
   }
   return check_launch("rac_affine_act");
 }
@@ -509,13 +538,13 @@ int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const
 
 int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                      const float* invstd, const double* sums, float* dx, float* dgamma, float* dbeta, int64_t M,
-                     int32_t C, int32_t groups, void* stream) {
+                     int32_t C, int32_t groups, uint32_t* dx_amax, void* stream) {
   RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && dx && M > 0 && C > 0 && groups >= 1 &&
                   M % groups == 0,
               "rac_bn_bwd_apply: bad args");
   RAC_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rac_bn_bwd_apply: dgamma/dbeta must come together");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)M * C)), dim3(256), 0, ST(stream), dy, x, scale, shift,
-                     mean, invstd, sums, dx, dgamma, dbeta, (long)(M / groups), C, groups);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_amax((long)M * C, dx_amax)), dim3(256), 0, ST(stream), dy, x, scale, shift,
+                     mean, invstd, sums, dx, dgamma, dbeta, (long)(M / groups), C, groups, dx_amax);
   return check_launch("rac_bn_bwd_apply");
 }
 
@@ -563,14 +592,14 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
 
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
                     const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
-                    int32_t HW, void* stream) {
+                    int32_t HW, uint32_t* out_amax, void* stream) {
   RAC_REQUIRE(out && B > 0 && HW > 0 && pad >= 0, "rac_tilecat_fwd: bad args");
   RAC_REQUIRE((n0 == 0 || v0) && (n1 == 0 || v1) && (n2 == 0 || v2) && (c0 == 0 || m0) && (c1 == 0 || m1),
               "rac_tilecat_fwd: null source with non-zero width");
   long n = (long)B * HW * (n0 + n1 + n2 + c0 + c1 + pad);
   RAC_REQUIRE(n > 0, "rac_tilecat_fwd: empty");
-  hipLaunchKernelGGL(tilecat_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1,
-                     c1, pad, out, B, HW);
+  hipLaunchKernelGGL(tilecat_kernel, dim3(grid_for_amax(n, out_amax)), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1,
+                     c1, pad, out, B, HW, out_amax);
   return check_launch("rac_tilecat_fwd");
 }
 
@@ -604,10 +633,10 @@ int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* strea
 }
 
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
-                    int64_t n, int32_t N, void* stream) {
+                    int64_t n, int32_t N, uint32_t* out_amax, void* stream) {
   RAC_REQUIRE(slabs && out && n_slabs >= 1 && n > 0 && N > 0, "rac_slab_reduce: bad args");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), slabs, n_slabs,
-                     (long)slab_stride, bias, out, (long)n, N);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for_amax(n, out_amax)), dim3(256), 0, ST(stream), slabs, n_slabs,
+                     (long)slab_stride, bias, out, (long)n, N, out_amax);
   return check_launch("rac_slab_reduce");
 }
 
@@ -648,10 +677,11 @@ int rac_lstm_cell_fwd(const float* gate_slabs, int32_t n_slabs, int64_t slab_str
 }
 
 int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, const float* c_prev,
-                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, void* stream) {
+                      const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g, uint32_t* dgates_amax,
+                      void* stream) {
   RAC_REQUIRE(act && c_prev && c_new && dgates && dc_prev && M > 0 && g > 0, "rac_lstm_cell_bwd: bad args");
-  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for((long)M * g)), dim3(256), 0, ST(stream), dh, dc_next, act,
-                     c_prev, c_new, dgates, dc_prev, (long)M, g);
+  hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3(grid_for_amax((long)M * g, dgates_amax)), dim3(256), 0, ST(stream), dh, dc_next, act,
+                     c_prev, c_new, dgates, dc_prev, (long)M, g, dgates_amax);
   return check_launch("rac_lstm_cell_bwd");
 }
 

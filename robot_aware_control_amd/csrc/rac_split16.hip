@@ -88,6 +88,7 @@ struct Conv16P {
   const unsigned short* w;    // fp16 parts, fragment order [part][Cout/32][Cin/32][tap][nb 2][lane 64][8]
   long w_ps;                  // part stride in elements
   const unsigned *a_amax0, *a_amax1, *w_amax;  // bit patterns of max |x| of the operands (a_amax1 may be null)
+  unsigned* out_amax;         // max |out| is folded in here (fused epilogue only; may be null)
   float* out0;
   const float *bias, *scale, *shift;
   double* stats;
@@ -102,8 +103,8 @@ struct Conv16P {
 // wave-uniform byte offset.
 constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
 
-__device__ __forceinline__ void conv16_epilogue_store(const Conv16P& p, float v, float bias, float sc, float sh,
-                                                      float& s1, float& s2, long idx) {
+__device__ __forceinline__ float conv16_epilogue_store(const Conv16P& p, float v, float bias, float sc, float sh,
+                                                       float& s1, float& s2, long idx) {
   v += bias;
   s1 += v;
   s2 += v * v;
@@ -113,6 +114,7 @@ __device__ __forceinline__ void conv16_epilogue_store(const Conv16P& p, float v,
   else if (p.act == RAC_ACT_SIGMOID)
     v = sigmoid_acc(v);
   p.out0[idx] = v;
+  return v;
 }
 
 // WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   // ---- epilogue: undo the two scales, then as rac_conv2d FWD; col = l & 15 (+16 nb), rows 4 (l >> 4) + reg ----
   const float ia = pow2f(-ka), iw = pow2f(-kw);
   const bool slab = p.split_k > 1;
+  unsigned mx = 0;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = n0 + wn * NT * 32 + nb * 16 + lr;
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
           p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
           continue;
         }
-        conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n);
+        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n)));
       }
     }
     if (p.stats && !slab) {
@@ -347,6 +350,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       }
     }
   }
+  if (p.out_amax && !slab) amax_commit(mx, p.out_amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 
   const float ia = pow2f(-ka), iw = pow2f(-kw);
   const bool slab = p.split_k > 1;
+  unsigned mx = 0;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb) {
     const int n = n0 + wn * 32 + nb * 16 + lr;
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
           continue;
         }
-        conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n);
+        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n)));
       }
     }
     if (p.stats && !slab) {
@@ -572,6 +577,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       }
     }
   }
+  if (p.out_amax && !slab) amax_commit(mx, p.out_amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -915,7 +921,7 @@ extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, i
 }
 
 extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
-                                    int64_t w_part_stride, const uint32_t* w_amax, void* stream) {
+                                    int64_t w_part_stride, const uint32_t* w_amax, uint32_t* out_amax, void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0 && a_amax0 && w_amax,
               "rac_conv2d_fwd_split: bad args");
@@ -931,7 +937,7 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.a0 = a->a0, p.a1 = a->a1;
   p.w = reinterpret_cast<const unsigned short*>(a->w);
   p.w_ps = w_part_stride;
-  p.a_amax0 = a_amax0, p.a_amax1 = a_amax1, p.w_amax = w_amax;
+  p.a_amax0 = a_amax0, p.a_amax1 = a_amax1, p.w_amax = w_amax, p.out_amax = out_amax;
   p.out0 = a->out0;
   p.bias = a->bias, p.scale = a->scale, p.shift = a->shift, p.stats = a->stats;
   p.stats_rows = a->stats ? a->stats_rows : 0;

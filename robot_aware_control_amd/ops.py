@@ -211,7 +211,7 @@ def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=N
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         conv_raw(FWD, x0, x1, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0,
                  split_k=split, slab_stride=M * Cout)
-        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
+        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, None, stream_ptr())
         if stats is not None:
             call("rac_col_stats", ptr(out), ptr(stats), M, Cout, groups, stream_ptr())
     return out
@@ -234,7 +234,7 @@ def conv_dgrad(dy, weight, C0: int, C1: int = 0, transposed_head: bool = False):
         if C1:
             call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
         else:
-            call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
+            call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
     else:
         conv_raw(DGRAD, dy, None, weight, dx0, dx1, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout,
                  o_split=C0 if C1 else 0)
@@ -288,6 +288,14 @@ def amax_of(x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor
     slot = buf[k:k + 1]
     call("rac_absmax", ptr(x0), x0.numel(), ptr(x1), x1.numel() if x1 is not None else 0, ptr(slot), stream_ptr())
     return slot
+
+
+def amax_slot(device) -> torch.Tensor:
+    """A zeroed slot for a kernel that folds the max |v| of its output in (`*_amax` output arguments of the C ABI)."""
+    buf = _amax_arena(device)
+    k = _AMAX["used"]
+    _AMAX["used"] = k + 1
+    return buf[k:k + 1]
 
 
 def amax_one(device) -> torch.Tensor:
@@ -357,7 +365,7 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
 
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
-                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0):
+                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
@@ -370,7 +378,7 @@ def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, 
     if SHAPE_LOG is not None:
         _log_shape("conv16", DGRAD if getattr(pw, "_rac_transposed", False) else FWD, k, B * H * W, Cout, Cin * k * k,
                    2500.0 / 3)
-    call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], ptr(wslot), stream_ptr())
+    call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], ptr(wslot), ptr(out_amax), stream_ptr())
     if timed:
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
@@ -402,16 +410,18 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
     fused = act != ACT_NONE or scale is not None
     split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
+    slot = amax_slot(x0.device)  # the kernel that writes `out` also leaves its max |v| for the next conv
     if split == 1:
         _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, stats=stats,
-                      stats_rows=(M // groups if (groups > 1 and stats is not None) else 0), **kw)
+                      stats_rows=(M // groups if (groups > 1 and stats is not None) else 0), out_amax=slot, **kw)
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         _split_launch(x0, x1, a0, a1, pw, wslot, slabs, split_k=split, slab_stride=M * Cout, **kw)
-        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, stream_ptr())
+        call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, ptr(slot),
+             stream_ptr())
         if stats is not None:
             call("rac_col_stats", ptr(out), ptr(stats), M, Cout, groups, stream_ptr())
-    return out
+    return tag_amax(out, slot)
 
 
 def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
@@ -431,7 +441,7 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
         call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
         return dx0, dx1
-    call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, stream_ptr())
+    call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
     return dx0, None
 
 
@@ -723,7 +733,9 @@ class VggLayer(torch.autograd.Function):
         call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
              n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, G, stream_ptr())
         y = torch.empty_like(raw)
-        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, G, stream_ptr())
+        slot = amax_slot(dev)
+        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, G, ptr(slot), stream_ptr())
+        tag_amax(y, slot)
         ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
         ctx.amax = (amax_tag(x0), amax_tag(x1))
         return y
@@ -743,7 +755,8 @@ class VggLayer(torch.autograd.Function):
         want_affine = gamma.requires_grad
         call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums),
              ptr(draw), ptr(grad_buffer(gamma)) if want_affine else None,
-             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, G, stream_ptr())
+             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, G, ptr(tag_amax(draw, amax_slot(dy.device))._rac_amax),
+             stream_ptr())
         C0 = x0.shape[3]
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
@@ -815,8 +828,10 @@ class TileCat(torch.autograd.Function):
         if SPLIT_GEMM and ct >= 128 and whole and c0 % 32 == 0:
             pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
+        slot = amax_slot(m0.device)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
-             ptr(out), B, H * W, stream_ptr())
+             ptr(out), B, H * W, ptr(slot), stream_ptr())
+        tag_amax(out, slot)
         ctx.meta = (sum(ns), c0, c1)
         return out
 
@@ -869,9 +884,12 @@ class LstmCell(torch.autograd.Function):
         M = B * H * W
         dgates = torch.empty_like(act)
         dc_prev = torch.empty_like(c)
-        call("rac_lstm_cell_bwd", ptr(dh.contiguous()) if dh is not None else None,
-             ptr(dc.contiguous()) if dc is not None else None, ptr(act), ptr(c_prev), ptr(c), ptr(dgates),
-             ptr(dc_prev), M, g, stream_ptr())
+        dh = dh.contiguous() if dh is not None else None  # locals: the copies must outlive the launch
+        dc = dc.contiguous() if dc is not None else None
+        slot = amax_slot(act.device)
+        call("rac_lstm_cell_bwd", ptr(dh), ptr(dc), ptr(act), ptr(c_prev), ptr(c), ptr(dgates), ptr(dc_prev), M, g,
+             ptr(slot), stream_ptr())
+        tag_amax(dgates, slot)
         dx = dh_prev = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if ctx.split:
