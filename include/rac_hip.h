@@ -114,7 +114,9 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
 /* FWD conv (as rac_conv2d mode RAC_CONV_FWD; epilogue fields bias, scale/shift, act, stats, split_k slabs behave the
  * same) with a->a0 / a->a1 the fp32 NHWC activations (split into parts on the way into LDS), a->w the fragment-order
  * parts of rac_weight_frag_split, a_amax0 / a_amax1 the maxima of a0 / a1 (a_amax1 may be NULL), w_amax as given to
- * rac_weight_frag_split.  The data gradient of a conv is this call on dy with the transposed parts. */
+ * rac_weight_frag_split.  The data gradient of a conv is this call on dy with the transposed parts.
+ * a->Cout need not be a multiple of 32 (the 4-channel output head): the parts must then come from the weight with its
+ * rows zero-padded to the next multiple of 32; only Cout columns are computed into the output (row stride Cout). */
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
                          int64_t w_part_stride, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
 /* `*_amax` OUTPUT arguments (here and on rac_affine_act, rac_bn_bwd_apply, rac_tilecat_fwd, rac_slab_reduce,

@@ -96,6 +96,7 @@ struct Conv16P {
   int M, N, HW, P, taps, cchunks, nchunks, cps;
   int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
+  int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
 };
 
 // LDS image of the tile kernel: CHUNK-major [part 2][8-channel group 4][row 144][16 B]; rows 128..143 are zeros.
@@ -310,11 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   // ---- epilogue: undo the two scales, then as rac_conv2d FWD; col = l & 15 (+16 nb), rows 4 (l >> 4) + reg ----
   const float ia = pow2f(-ka), iw = pow2f(-kw);
   const bool slab = p.split_k > 1;
+  const int NS = p.n_store;
   unsigned mx = 0;
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     const int n = n0 + wn * NT * 32 + nb * 16 + lr;
-    const bool nok = n < p.N;
+    const bool nok = n < NS;
     float bias = 0.f, sc = 1.f, sh = 0.f;
     if (!slab && nok) {
       if (p.bias) bias = p.bias[n];
@@ -332,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         if (wm * RB + mb >= nmb || m >= p.M || !nok) continue;
         const float v = acc[mb][nb][r] * ia * iw;
         if (slab) {
-          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          p.out0[(long)bz * p.slab_stride + (long)m * NS + n] = v;
           continue;
         }
-        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n)));
+        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * NS + n)));
       }
     }
     if (p.stats && !slab) {
@@ -344,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lq == 0 && nok) {
-        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * NS : 0L);
         atomicAdd(sg + n, (double)s1);
-        atomicAdd(sg + p.N + n, (double)s2);
+        atomicAdd(sg + NS + n, (double)s2);
       }
     }
   }
@@ -359,14 +361,18 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 // its pixels plus `pad` image rows above and below (the halo; zeros outside the image) are staged per channel chunk
 // as one CONTIGUOUS pixel range of the input.  The y shift of a tap lands in the halo, only the x shift can leave
 // the row (one bit per kernel column and lane selects a zero row).  LDS image [part 2][8-channel group 4]
-// [staged row + 16 zero rows][16 B]; one buffer, two barriers per channel chunk; weights one chunk ahead.
-// NV = 16-byte staging vectors per thread and part; TN = 32-column groups per workgroup: 4 (waves 1 x 4, each 128
-// rows x 32 columns) or 2 (64-column workgroups for the 64-channel layers: waves 2 x 2, 64 rows x 32 columns).
+// [staged row + 16 zero rows][16 B], two buffers (the next chunk is stored while this one is read: one barrier
+// per channel chunk); weights one chunk-tap ahead.
+// NV = 16-byte staging vectors per thread and part.  Waves: WM along the rows x 4 / WM along the columns, NT
+// 32-column weight tiles each: (2, 2) 128-column workgroups, waves 64 rows x 64 columns; (2, 1) 64 columns (the
+// 64-channel layers); (4, 1) 32 columns (narrow heads: the 4-channel output head stores only N of them).
 // ---------------------------------------------------------------------------------------------------------
-template <int NV, int TN>
+template <int NV, int WM, int NT>
 __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
-  constexpr int MB = 2 * TN;    // 16-row blocks per wave
-  constexpr int BNW = TN * 32;  // columns per workgroup
+  constexpr int WN = 4 / WM;
+  constexpr int MB = 8 / WM;            // 16-row blocks per wave
+  constexpr int NB = 2 * NT;            // 16-column blocks per wave
+  constexpr int BNW = WN * NT * 32;     // columns per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     by = grp % nt;
     bz = grp / nt;
   }
-  const int wn = wid % TN, wm = wid / TN;
+  const int wn = wid % WN, wm = wid / WN;
   const int TM = p.tile_m;
   const int nmb = TM >> 4;
   const int m0 = bx * TM, n0 = by * BNW;
@@ -396,9 +402,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int nrows = TM + 2 * halo;       // staged pixel rows (a multiple of 16)
   const int cplane = (nrows + 16) * 16;  // one 8-channel group: staged rows + 16 zero rows
   const int pplane = 4 * cplane;
-  if (tid < 2 * 4 * 16)
-    *reinterpret_cast<u32x4*>(lds_raw + (tid >> 6) * pplane + ((tid >> 4) & 3) * cplane + (nrows + (tid & 15)) * 16) =
-        u32x4{0u, 0u, 0u, 0u};
+  const int abuf = 2 * pplane;           // one buffer
+  {  // zero rows of both buffers: 2 buffers x 2 parts x 4 groups x 16 rows = 256 vectors
+    const int pl = tid >> 4, r = tid & 15;
+    *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * abuf + ((pl >> 2) & 1) * pplane + (pl & 3) * cplane +
+                              (nrows + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
 
   const int y_tile = (m0 % p.HW) / p.W;
   int s_off[NV], s_row[NV], s_grp[NV];
@@ -424,18 +433,24 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   }
   const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;  // block t adds t * 256
   const int zrow = lq * cplane + nrows * 16;
-  const int ntile = (n0 >> 5) + wn;
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
-  const unsigned b_off0 = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
-  auto load_b = [&](u32x4(&rb)[4], int kc) {
+  unsigned b_off[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ntile = (n0 >> 5) + wn * NT + j;
+    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+  }
+  auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
     const int so = kc * 2048;
 #pragma unroll
-    for (int part = 0; part < 2; ++part)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
-        rb[part * 2 + nb] = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off0 + part * w_pstride + nb * 1024u), so, 0));
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          rb[(j * 2 + part) * 2 + nb] = __builtin_bit_cast(
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), so, 0));
   };
   u32x4 ra[2 * NV];
   auto issue_a = [&](int cc) {
@@ -451,54 +466,60 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       ra[2 * i + 1] = load16(a_rsrc, s_ok[i] ? oa + 16u : OOB);
     }
   };
-  auto store_a = [&]() {
+  auto store_a = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       if (s_off[i] < 0) continue;
       u32x4 q[2];
       split8h(ra[2 * i], ra[2 * i + 1], sa, q);
 #pragma unroll
-      for (int part = 0; part < 2; ++part) *reinterpret_cast<u32x4*>(lds_raw + part * pplane + s_off[i]) = q[part];
+      for (int part = 0; part < 2; ++part)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * abuf + part * pplane + s_off[i]) = q[part];
     }
   };
 
-  f32x4 acc[MB][2];
+  f32x4 acc[MB][NB];
 #pragma unroll
   for (int i = 0; i < MB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (kc_begin < kc_end) {
     int cc = kc_begin / p.taps;
     int tap = kc_begin - cc * p.taps;
     int ky = tap / p.ks, kx = tap - ky * p.ks;
+    int cur = 0;
     bool fresh = true;
-    u32x4 b0[4], b1[4];
+    u32x4 b0[4 * NT], b1[4 * NT];
     issue_a(cc);
     load_b(b0, kc_begin);
-    store_a();
+    store_a(0);
     __syncthreads();
 
-    auto step = [&](const u32x4(&rb)[4], int kc) {
+    auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
       const bool last_tap = tap == p.taps - 1;
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
       const int drow = (ky - p.pad) * p.W + (kx - p.pad);
-      const int shift = drow * 16 + abase;
-      const int zr = zrow + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
+      const int shift = drow * 16 + cur * abuf + abase;
+      const int zr = zrow + cur * abuf + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
       const unsigned bit = 1u << kx;
-      f16x8 fb[2][2];
+      f16x8 fb[NB][2];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb)
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int part = 0; part < 2; ++part) fb[nb][part] = __builtin_bit_cast(f16x8, rb[part * 2 + nb]);
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int h = 0; h < MB / 4; ++h) {
-        f16x8 fa[4][2];
+          for (int part = 0; part < 2; ++part)
+            fb[j * 2 + nb][part] = __builtin_bit_cast(f16x8, rb[(j * 2 + part) * 2 + nb]);
+      constexpr int HB = MB < 4 ? MB : 4;  // fragment reads in groups of up to 4 blocks
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int mb = 4 * h + t;
+      for (int h = 0; h < MB / HB; ++h) {
+        f16x8 fa[HB][2];
+#pragma unroll
+        for (int t = 0; t < HB; ++t) {
+          const int mb = HB * h + t;
           if (wm * MB + mb >= nmb) continue;  // wave-uniform: past the tile's rows
           const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
@@ -506,17 +527,17 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
             fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < HB; ++t)
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb) {
-            if (wm * MB + 4 * h + t >= nmb) continue;
-            acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
+          for (int nb = 0; nb < NB; ++nb) {
+            if (wm * MB + HB * h + t >= nmb) continue;
+            acc[HB * h + t][nb] = mma3(fa[t], fb[nb], acc[HB * h + t][nb]);
           }
       }
       if (last_tap && more) {
+        store_a(cur ^ 1);
         __syncthreads();
-        store_a();
-        __syncthreads();
+        cur ^= 1;
         fresh = true;
       }
       cc = last_tap ? cc + 1 : cc;
@@ -537,11 +558,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 
   const float ia = pow2f(-ka), iw = pow2f(-kw);
   const bool slab = p.split_k > 1;
+  const int NS = p.n_store;  // columns stored = row stride of the output (== N except for padded narrow heads)
   unsigned mx = 0;
 #pragma unroll
-  for (int nb = 0; nb < 2; ++nb) {
-    const int n = n0 + wn * 32 + nb * 16 + lr;
-    const bool nok = n < p.N;
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + wn * NT * 32 + nb * 16 + lr;
+    const bool nok = n < NS;
     float bias = 0.f, sc = 1.f, sh = 0.f;
     if (!slab && nok) {
       if (p.bias) bias = p.bias[n];
@@ -559,10 +581,10 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
         if (wm * MB + mb >= nmb || m >= p.M || !nok) continue;
         const float v = acc[mb][nb][r] * ia * iw;
         if (slab) {
-          p.out0[(long)bz * p.slab_stride + (long)m * p.N + n] = v;
+          p.out0[(long)bz * p.slab_stride + (long)m * NS + n] = v;
           continue;
         }
-        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * p.N + n)));
+        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * NS + n)));
       }
     }
     if (p.stats && !slab) {
@@ -571,9 +593,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
       if (lq == 0 && nok) {
-        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * p.N : 0L);
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * NS : 0L);
         atomicAdd(sg + n, (double)s1);
-        atomicAdd(sg + p.N + n, (double)s2);
+        atomicAdd(sg + NS + n, (double)s2);
       }
     }
   }
@@ -926,7 +948,8 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0 && a_amax0 && w_amax,
               "rac_conv2d_fwd_split: bad args");
   const int a_split = (a->a1 && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
-  RAC_REQUIRE(rac_conv2d_split_supported(a->H, a->W, a->ksize, a->Cin, a->Cout, a_split),
+  const int n_rows = (a->Cout + 31) / 32 * 32;  // weight rows: Cout zero-padded to whole 32-column tiles
+  RAC_REQUIRE(rac_conv2d_split_supported(a->H, a->W, a->ksize, a->Cin, n_rows, a_split),
               "rac_conv2d_fwd_split: shape not supported (k 3 or 5, channel counts %% 32 == 0, whole images or whole "
               "image rows per 128-pixel tile): use rac_conv2d");
   Conv16P p{};
@@ -943,21 +966,21 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.stats_rows = a->stats ? a->stats_rows : 0;
   p.HW = a->H * a->W;
   p.P = a->B * p.HW;
-  p.M = p.P, p.N = a->Cout;
+  p.M = p.P, p.N = n_rows, p.n_store = a->Cout;
   p.taps = a->ksize * a->ksize;
   p.a_split = a_split;
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
   RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
               "rac_conv2d_fwd_split: operand larger than 4 GiB");
-  RAC_REQUIRE(w_part_stride >= (long)p.Cout * p.taps * p.Cin && 2 * w_part_stride * 2 < 0xFFFFFF00L,
+  RAC_REQUIRE(w_part_stride >= (long)n_rows * p.taps * p.Cin && 2 * w_part_stride * 2 < 0xFFFFFF00L,
               "rac_conv2d_fwd_split: weight part stride");
-  RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.N, "rac_conv2d_fwd_split: slab_stride too small");
+  RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.n_store, "rac_conv2d_fwd_split: slab_stride too small");
   RAC_REQUIRE(p.stats_rows >= 0 && (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
               "rac_conv2d_fwd_split: stats_rows must divide B*H*W");
   p.cchunks = a->Cin / SBK;
   p.nchunks = p.taps * p.cchunks;
   p.cps = cdiv(p.nchunks, p.split_k);
-  RAC_REQUIRE((long)(a->Cout / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+  RAC_REQUIRE((long)(n_rows / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
   static const char* xg = getenv("RAC_XCD_GROUP");
   const bool want_xcd = xg ? atoi(xg) != 0 : true;
   if (p.HW > 128) {
@@ -967,14 +990,27 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
     const int nv = cdiv(nrows * 4, 256) < 2 ? 2 : cdiv(nrows * 4, 256);
     RAC_REQUIRE(nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
     typedef void (*rows_fn)(Conv16P);
-    static const rows_fn fns[2][3] = {
-        {conv16_rows_kernel<2, 4>, conv16_rows_kernel<3, 4>, conv16_rows_kernel<4, 4>},
-        {conv16_rows_kernel<2, 2>, conv16_rows_kernel<3, 2>, conv16_rows_kernel<4, 2>}};
-    const size_t lds_rows = (size_t)2 * 4 * (nrows + 16) * 16;
-    const int narrow = p.N <= 64 ? 1 : 0;
-    dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, narrow ? 64 : 128), p.split_k);
+    static const rows_fn fns[3][3] = {
+        {conv16_rows_kernel<2, 2, 2>, conv16_rows_kernel<3, 2, 2>, conv16_rows_kernel<4, 2, 2>},   // 128 columns
+        {conv16_rows_kernel<2, 2, 1>, conv16_rows_kernel<3, 2, 1>, conv16_rows_kernel<4, 2, 1>},   // 64 columns
+        {conv16_rows_kernel<2, 4, 1>, conv16_rows_kernel<3, 4, 1>, conv16_rows_kernel<4, 4, 1>}};  // 32 columns
+    const size_t lds_rows = (size_t)2 * 2 * 4 * (nrows + 16) * 16;
+    static bool rows_attr = false;
+    if (!rows_attr) {
+      for (int i = 0; i < 9; ++i) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i / 3][i % 3]),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * (256 + 16) * 16);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return RAC_ELAUNCH;
+        }
+      }
+      rows_attr = true;
+    }
+    const int width = p.N <= 32 ? 2 : (p.N <= 64 ? 1 : 0);
+    dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, width == 2 ? 32 : (width == 1 ? 64 : 128)), p.split_k);
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
-    hipLaunchKernelGGL(fns[narrow][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
+    hipLaunchKernelGGL(fns[width][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(image rows)");
   }
   p.tile_m = (128 / p.HW) * p.HW;  // whole images per workgroup

@@ -414,7 +414,10 @@ class SVGConvModel(nn.Module):
             mask_planes = mask if mask_planes is None else torch.cat([mask_planes, mask], 1)
         if mask_planes is not None:
             mask_planes = mask_planes.contiguous()
-        x_in = ops.PackInput.apply(image, None if zero_mask is None else zero_mask.contiguous(), mask_planes)
+        # one whole 32-channel chunk (zero padded) where the first layer can take the split-precision kernels
+        H, W = image.shape[-2], image.shape[-1]
+        pad_to = 32 if (ops.SPLIT_GEMM and ops.split_supported(H, W, 3, 32, 64)) else 0
+        x_in = ops.PackInput.apply(image, None if zero_mask is None else zero_mask.contiguous(), mask_planes, pad_to)
         return self.encoder(x_in, n_updates, groups)
 
     def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean):

@@ -667,7 +667,15 @@ class ConvTHead(torch.autograd.Function):
         assert Ci == Ciw
         weight_mem(weight)
         y = torch.empty((B, H, W, Cow), device=x.device, dtype=torch.float32)
-        conv_raw(DGRAD, x, None, weight, y, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, act=ACT_SIGMOID, bias=bias)
+        if SPLIT_GEMM and Cow <= 32 and split_supported(H, W, k, Ciw, 32):
+            # the transposed-conv forward IS a data gradient: forward conv with the (Cow, Ciw) tap-flipped weight, its
+            # Cow rows zero-padded to one 32-column tile; only the Cow real columns are computed into y
+            pw, wslot = weight_parts(padded_weight(weight, 32), transposed=True)
+            x = x if x.is_contiguous() else x.contiguous()
+            _split_launch(x, None, amax_for(x), None, pw, wslot, y, B=B, H=H, W=W, k=k, Cin=Ciw, Cout=Cow, C0=Ciw,
+                          act=ACT_SIGMOID, bias=bias)
+        else:
+            conv_raw(DGRAD, x, None, weight, y, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, act=ACT_SIGMOID, bias=bias)
         ctx.save_for_backward(x, weight, bias, y)
         return y
 
@@ -703,9 +711,11 @@ class VggLayer(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, weight, gamma, beta, rmean, rvar, training, n_updates, folded, groups=1):
         Cout = weight.shape[0]
-        padded = weight.shape[1] % 4 != 0 and x1 is None and x0.shape[3] == weight.shape[1] + pad4(weight.shape[1])
+        # x0 may carry trailing zero channels (the packed frame: to 16-byte rows, or to one whole 32-channel chunk so
+        # that the first layer runs split-precision): the conv then runs against the zero-padded weight
+        padded = x1 is None and x0.shape[3] != weight.shape[1]
         ctx.padded = padded
-        wfull, weight_used = weight, (padded_weight(weight) if padded else weight)
+        wfull, weight_used = weight, (padded_weight(weight, x0.shape[3]) if padded else weight)
         weight = weight_used
         if not training:
             scale, shift = folded
@@ -721,7 +731,7 @@ class VggLayer(torch.autograd.Function):
         G = ctx.groups = int(groups)  # time steps batched along B: one BatchNorm call of the reference per group
         stats = zeros64((G, 2, Cout), dev)
         c0 = x0.shape[3]
-        ctx.split = (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT_TRAIN and c0 >= 64
+        ctx.split = (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT_TRAIN
                      and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, c0 if x1 is not None else 0))
         if ctx.split:
             raw = conv_forward_split(x0, x1, weight, None, stats=stats, groups=G)
@@ -761,15 +771,16 @@ class VggLayer(torch.autograd.Function):
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None
         if ctx.needs_input_grad[0] or (x1 is not None and ctx.needs_input_grad[1]):
+            wuse = padded_weight(weight, C0) if ctx.padded else weight
             if ctx.split:
-                dx0, dx1 = conv_dgrad_split(draw, weight, C0, C1)
+                dx0, dx1 = conv_dgrad_split(draw, wuse, C0, C1)
             else:
-                dx0, dx1 = conv_dgrad(draw, padded_weight(weight) if ctx.padded else weight, C0, C1)
+                dx0, dx1 = conv_dgrad(draw, wuse, C0, C1)
         if weight.requires_grad:
-            if ctx.padded:
+            if ctx.split:
+                conv_wgrad_split_acc(draw, x0, x1, weight)  # un-pads into weight.grad where x0 carries pad channels
+            elif ctx.padded:
                 wgrad_padded_acc(draw, x0, weight)
-            elif ctx.split:
-                conv_wgrad_split_acc(draw, x0, x1, weight)
             else:
                 conv_wgrad_acc(draw, x0, x1, weight)
         return dx0, dx1, None, None, None, None, None, None, None, None, None
@@ -1011,10 +1022,10 @@ class PackInput(torch.autograd.Function):
     (dynamics.py:578-582 + utils/image.py:5-19)."""
 
     @staticmethod
-    def forward(ctx, img, zero_mask, mask):
+    def forward(ctx, img, zero_mask, mask, pad_to=0):
         B, _, H, W = img.shape
         Cm = mask.shape[1] if mask is not None else 0
-        pad = pad4(3 + Cm)
+        pad = pad_to - (3 + Cm) if pad_to >= 3 + Cm else pad4(3 + Cm)
         out = torch.empty((B, H, W, 3 + Cm + pad), device=img.device, dtype=torch.float32)
         call("rac_pack_input", ptr(img), ptr(zero_mask), ptr(mask), Cm, pad, ptr(out), B, H * W, stream_ptr())
         ctx.save_for_backward(zero_mask)
@@ -1025,12 +1036,12 @@ class PackInput(torch.autograd.Function):
     def backward(ctx, dout):
         (zero_mask,) = ctx.saved_tensors
         if not ctx.needs_input_grad[0]:
-            return None, None, None
+            return None, None, None, None
         dout = dout.contiguous()
         B, H, W, _ = dout.shape
         dimg = torch.empty((B, 3, H, W), device=dout.device, dtype=torch.float32)
         call("rac_unpack_grad", ptr(dout), ctx.C, ptr(zero_mask), ptr(dimg), B, H * W, stream_ptr())
-        return dimg, None, None
+        return dimg, None, None, None
 
 
 class ZeroRegion(torch.autograd.Function):

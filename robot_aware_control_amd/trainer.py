@@ -101,6 +101,7 @@ class PredictionTrainer(object):
         self._video_sample_rng = np.random.RandomState(self._config.seed)
         self._grad_seeds = {}
         self._loss_host = None  # pinned staging buffer of the per-step loss readback
+        self.phase_events = None  # set to [] to record (name, cuda event) marks of every train step (bench.py)
         # the model / optimiser object graph is static from here on: keep the cyclic GC's full collections from
         # walking it (measured: one 33 ms host stall every ~10 train steps at cfg2, during which the GPU drains)
         if os.environ.get("RAC_GC_FREEZE", "1") == "1":
@@ -149,6 +150,12 @@ class PredictionTrainer(object):
         rw = cf.robot_pixel_weight if "dontcare" in cf.reconstruction_loss else 0.0
         bw = batch_weight if cf.reconstruction_loss in ("l1", "dontcare_l1") else None
         return ops.ReconLoss.apply(prediction, target, mask, bw, self._loss_kind(), rw)
+
+    def _mark(self, name):
+        if self.phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self.phase_events.append((name, e))
 
     def _seed(self, value: float, n: int = 1, first_only: bool = False):
         key = (value, n, first_only)
@@ -212,6 +219,7 @@ class PredictionTrainer(object):
             batch_weight[~mv.bool()] = 1.0
 
         ops.begin_step(x.device)
+        self._mark("start")
         self.model.zero_grad()
         bs = min(cf.batch_size, x.shape[1])
         self.model.init_hidden(bs)
@@ -280,6 +288,7 @@ class PredictionTrainer(object):
         # the step's loss scalars are final once the forward pass is enqueued: start their device->host copy now (into
         # pinned memory) and collect it after the optimiser step is enqueued, so that the host never waits for the
         # backward pass or Adam (the reference likewise reads its losses before loss.backward(), trainer.py:433-458)
+        self._mark("forward")
         with torch.no_grad():
             vals_dev = torch.stack([t.detach()[k] for _, t, k in log])
         if self._loss_host is None or self._loss_host.numel() < vals_dev.numel():
@@ -293,9 +302,13 @@ class PredictionTrainer(object):
         # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce
         with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
             torch.autograd.backward(roots, seeds)
+            self._mark("backward")
+        self._mark("weight_grads")
         if reducer is not None:
             reducer.finish()
+            self._mark("allreduce_exposed")
         self.optimizer.step()
+        self._mark("adam")
 
         copied.synchronize()  # the one host wait of the step (normally already satisfied)
         vals = vals_host.tolist()

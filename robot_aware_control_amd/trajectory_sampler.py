@@ -178,7 +178,11 @@ class TrajectorySampler(object):
                 curr = nxt
 
         # ---- gather the per-candidate costs: the only collective of a CEM iteration ----
+        if getattr(self, "time_gather", False):  # bench.py: time the collective alone (drain the rollouts first)
+            torch.cuda.synchronize()
+        t_gather = timer.time()
         sum_cost = gather_costs(sum_cost_dev[:n_local], N, world, rank)
+        self.last_gather_s = timer.time() - t_gather
 
         if not suppress_print:
             print("======= Samples Gathered  ======= | >>>> Time taken = %f " % (timer.time() - start_time))
