@@ -366,6 +366,7 @@ def main():
             dist.init_process_group(backend)
     torch.manual_seed(1234)
     np.random.seed(1234)
+    os.environ.setdefault("RAC_GC_FREEZE", "1")  # the benchmark process builds its objects once
 
     out = {"metric": "SVG train frames/sec + CEM candidate-rollouts/sec, 64x64", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",

@@ -293,7 +293,8 @@ int rac_psnr_ssim(const float* a, const float* b, const float* mask, float* sq_e
 /* CEM step tail (trajectory_sampler.py:149-169 + losses.py:224-263), fused:
  *   next = (1-m)*curr + m*rgb; next *= (1-next_mask) if next_mask;
  *   cost = -sqrt(sum (255*(next-goal))^2) [dontcare: robot|goal-mask pixels dropped, / #world pixels]
- *   sum_cost[n] += weight * (double)(float)cost      (fp64 accumulate, kept on the device)
+ *   sum_cost[n] += (double)(weight * cost)   (fp32 product as the reference's `w * cost`, losses.py:313-316; fp64
+ *                                             accumulate, kept on the device)
  * kind: 0 ImgL2Cost, 1 ImgDontcareCost.  cost_mask = thick robot mask of the next step (dontcare only). */
 int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask, const float* goal_img,
                       const float* cost_mask, const uint8_t* goal_mask, int32_t kind, float weight, int32_t add_cost,

@@ -460,8 +460,142 @@ def gen_cem():
         save(f"cem_{tag}", **out)
 
 
+def gen_dataset():
+    """The numeric (non-image) part of RoboNetDataset.__getitem__ (robonet_dataset.py:173-356) on a synthetic
+    trajectory: loaders, autograsp imputation, bounds, state / action preprocessing.  (The image transform is
+    torchvision's, which this container lacks: no golden for the resize.)"""
+    from src.dataset.robonet.robonet_dataset import RoboNetDataset, normalize, denormalize
+
+    class FP(dict):
+        attrs = {}
+    g = np.random.Generator(np.random.Philox(key=[5, 5]))
+    T = 9
+    fp = FP(states=g.random((T, 4), dtype=np.float32), actions=g.normal(0, 0.03, (T - 1, 4)).astype(np.float32),
+            qpos=g.normal(0, 1, (T, 5)).astype(np.float32),
+            low_bound=np.array([0.2, -0.3, 0.05, -1.5, -1.0], np.float32),
+            high_bound=np.array([0.7, 0.3, 0.35, 1.5, 1.0], np.float32))
+    out = {f"in_{k}": v for k, v in fp.items()}
+    # (impute_autograsp_action cannot be captured: __getitem__ hands _load_actions the SCALAR bounds low[4] / high[4]
+    # and robonet_dataset.py:184 indexes them with [-1] -> IndexError in the reference itself)
+    for tag, view, adim, impute in (("sawyer", "sawyer_sudri0_c0", 4, False), ("locobot", "locobot_c0", 4, False),
+                                    ("franka", "franka_c0", 4, False)):
+        ds = object.__new__(RoboNetDataset)
+        ds._config = argparse.Namespace(robot_dim=5, robot_joint_dim=7, preprocess_action="raw")
+        ds._action_dim, ds._impute_autograsp_action, ds._traj_robots = adim, impute, [view]
+        low, high = ds._load_bounds(fp, view, 0)
+        states = ds._load_states(fp, 2, 8)
+        actions = ds._load_actions(fp, low[4], high[4], 2, 7)
+        qpos = ds._load_qpos(fp, 2, 8)
+        plow, phigh = ds._preprocess_bounds(low, high, 0)
+        pstates = ds._preprocess_states(states, plow, phigh, view, 0)
+        pact = ds._preprocess_actions(pstates, actions, plow, phigh, 0)
+        out.update({f"{tag}_low": low, f"{tag}_high": high, f"{tag}_states": states, f"{tag}_actions": actions,
+                    f"{tag}_qpos": qpos, f"{tag}_pstates": pstates, f"{tag}_pactions": pact.numpy()})
+    x = g.normal(0, 1, (6, 5)).astype(np.float32)
+    out["norm"], out["denorm"] = normalize(x, fp["low_bound"], fp["high_bound"]), denormalize(x, fp["low_bound"], fp["high_bound"])
+    out["norm_in"] = x
+    save("dataset_item", **out)
+
+
+class _FakeSampler:
+    """Stands in for the simulator-backed TrajectorySampler of the push / pick CEM variants: a cost that is a
+    deterministic function of the candidate actions, so that the planner's own arithmetic is what gets pinned."""
+
+    def __init__(self, *a, **k):
+        self.calls = []
+
+    def generate_rollouts(self, act_seq, start, goal, opt_traj=None, ret_obs=False, suppress_print=True):
+        self.calls.append(act_seq.clone())
+        tgt = torch.linspace(-0.3, 0.4, act_seq.shape[-1])
+        cost = -((act_seq - tgt) ** 2).sum((1, 2)).double().numpy()
+        return {"sum_cost": cost, "optimal_sum_cost": 0.0}
+
+    generate_model_rollouts = generate_rollouts
+
+
+def gen_sim_cem():
+    """P6: the push / pick CEM variants' get_action (src/cem/push/cem.py:50-104, src/cem/pick/cem.py:50-104): initial
+    belief, clamps, gripper clamp, padding, refit -- with the simulator-backed sampler replaced by _FakeSampler."""
+    import src.cem.pick.cem as pick_cem
+    import src.cem.push.cem as push_cem
+    out = {}
+    for tag, mod in (("push", push_cem), ("pick", pick_cem)):
+        mod.TrajectorySampler = _FakeSampler
+        cfg = argparse.Namespace(sparse_cost=False, debug_cem=False, log_dir="/tmp/x")
+        pol = mod.CEMPolicy(cfg, physics="learned", horizon=4, opt_iter=3, action_candidates=40, topk=5, init_std=0.5)
+        torch.manual_seed(11)
+        mean = pol.get_action(State(), DemoGoalState(), 0, 0)
+        out[f"{tag}_mean"] = mean
+        for i, a in enumerate(pol.traj_sampler.calls):
+            out[f"{tag}_act{i}"] = a.numpy()
+    save("sim_cem", **out)
+
+
+def gen_host_costs():
+    """P4 host-side paths (losses.py:172-335): the numpy `_call` variants the MBRL loops use on environment
+    observations, `img_cost_threshold`, `img_cost_world_norm`, `return_info`.  (The reference still says `np.float`,
+    removed in numpy >= 1.24: aliased to the builtin for this run.)"""
+    if not hasattr(np, "float"):
+        np.float = float
+    g = np.random.Generator(np.random.Philox(key=[8, 1]))
+    a, b = g.integers(0, 256, (16, 16, 3)).astype(np.uint8), g.integers(0, 256, (16, 16, 3)).astype(np.uint8)
+    m1, m2 = g.random((16, 16)) < 0.2, g.random((16, 16)) < 0.2
+    s1, s2 = g.random(5), g.random(5)
+    out = dict(a=a, b=b, m1=m1, m2=m2, s1=s1, s2=s2)
+    for tag, rt, thr, wn in (("l2", "dense", None, True), ("l2_thr", "dense", 30, True), ("dc", "dontcare", None, True),
+                             ("dc_nonorm", "dontcare", None, False), ("dc_thr", "dontcare", 30, True)):
+        cf = argparse.Namespace(robot_cost_weight=0.5, world_cost_weight=2.0, reward_type=rt, img_cost_threshold=thr,
+                                img_cost_world_norm=wn)
+        cost = ref_losses.RobotWorldCost(cf)
+        tot, info = cost(State(img=a, state=s1, mask=m1), State(img=b, state=s2, mask=m2), return_info=True)
+        out[f"{tag}_total"], out[f"{tag}_robot"] = tot, info["robot_l2"]
+        out[f"{tag}_world"] = info["img_dontcare" if rt == "dontcare" else "img_l2"]
+    save("host_costs", **out)
+
+
+def gen_train_video():
+    """T2: PredictionTrainer._train_video window slicing (trainer.py:259-324), sequential and `--random_snippet`
+    (starts drawn from `_video_sample_rng = RandomState(seed)`, trainer.py:89), with `_train_step` recording what it
+    is handed.  Frame t of the video carries the value t, so a window is identified by its content."""
+    from src.prediction.trainer import PredictionTrainer
+    out = {}
+    for tag, snippet in (("seq", False), ("rand", True)):
+        tr = object.__new__(PredictionTrainer)
+        tr._config = argparse.Namespace(n_past=2, n_future=3, random_snippet=snippet, model_use_heatmap=False,
+                                        load_movement_info=False, experiment="train_robonet", model_use_mask=True,
+                                        model_use_robot_state=True)
+        tr._video_sample_rng = np.random.RandomState(4)
+        seen = []
+
+        def step(bd, seen=seen):
+            seen.append([int(bd["images"][0, 0, 0, 0, 0]), len(bd["images"]), len(bd["actions"]), len(bd["masks"]),
+                         int(bd["states"][0, 0, 0]), int(bd["qpos"][-1, 0, 0])])
+            return {"recon_loss": float(bd["images"][0, 0, 0, 0, 0]), "kld": 1.0}
+        tr._train_step = step
+        T, B = 17, 2
+        ar = torch.arange(T).float()
+        data = {"images": ar.view(T, 1, 1, 1, 1).expand(T, B, 3, 4, 4), "states": ar.view(T, 1, 1).expand(T, B, 5),
+                "actions": ar[:-1].view(T - 1, 1, 1).expand(T - 1, B, 5), "masks": ar.view(T, 1, 1, 1, 1).expand(T, B, 1, 4, 4),
+                "qpos": ar.view(T, 1, 1).expand(T, B, 5), "robot": ["a", "b"], "folder": ["f", "f"]}
+        for rep in range(2):  # two videos: the snippet generator keeps its state across calls
+            losses = tr._train_video(data)
+            out[f"{tag}_loss{rep}"] = np.array([losses["recon_loss"], losses["kld"]])
+        out[f"{tag}_windows"] = np.array(seen)
+        out[f"{tag}_steps"] = tr.steps_per_train_video
+    save("train_video", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep"]
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep", "dataset",
+                             "simcem", "trainvideo", "hostcosts"]
+    if "simcem" in which:
+        gen_sim_cem()
+    if "trainvideo" in which:
+        gen_train_video()
+    if "hostcosts" in which:
+        gen_host_costs()
+    if "dataset" in which:
+        gen_dataset()
     if "forward" in which:
         gen_forward()
     if "shape" in which:

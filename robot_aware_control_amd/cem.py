@@ -61,8 +61,7 @@ class CEMPolicy(object):
         `noise`: optional list of N(0,1) draws (N,T-1,2) per iteration (parity tests)."""
         T, A, N = self.horizon, self.action_dim, self.num_actions
         self.ep_num, self.step = ep_num, step
-        mean = torch.zeros(T - 1, A)
-        std = torch.ones(T - 1, A) * self.init_std
+        mean, std = self._init_belief(T, A)
         mean_top_costs = []
         rollouts = {}
         for i in range(self.optimization_iter):
@@ -89,6 +88,10 @@ class CEMPolicy(object):
                                    "std": std.numpy().copy()})
         self.mean_top_costs = mean_top_costs
         return mean.numpy()
+
+    def _init_belief(self, T, A):
+        """Initial action-sequence belief N(0, init_std) of shape (T-1, A) (cem.py:72-73)."""
+        return torch.zeros(T - 1, A), torch.ones(T - 1, A) * self.init_std
 
     def _get_rollouts(self, act_seq, start: State, goal: DemoGoalState, opt_traj=None, plot=False):
         return self.traj_sampler.generate_model_rollouts(act_seq, start, goal, ret_obs=self.plot_rollouts,
@@ -117,7 +120,16 @@ class SimCEMPolicy(CEMPolicy):
         super().__init__(cfg, model, horizon=horizon, opt_iter=opt_iter, action_candidates=action_candidates,
                          topk=topk, init_std=init_std, robot_model=robot_model)
         self.action_dim = action_dim
+        self.physics = physics
         self.clamp = 1.0
         self.null_candidate = False
         if action_dim == 4:
             self.gripper_clamp = (-0.01, 0.0)
+
+    def _init_belief(self, T, A):
+        mean, std = super()._init_belief(T, A)
+        if A == 4:  # pick variant (pick/cem.py:67-72): narrower x, gripper command in [-0.01, 0]
+            std[:, 0] = 0.2
+            mean[:, -1] = -0.005
+            std[:, -1] = 0.005
+        return mean, std

@@ -89,36 +89,70 @@ def _img_cost(kind, curr_img, goal_img, curr_mask=None, goal_mask=None):
     return acc.cpu().numpy().astype(np.float32)
 
 
+def _is_tensor(*xs):
+    return any(isinstance(x, torch.Tensor) for x in xs)
+
+
 class RobotL2Cost(Cost):
-    """losses.py:182-206; the model-rollout States carry no robot state, so this is 0 there."""
+    """losses.py:182-206: -||curr - goal||_2 (per row for batched tensors); 0 when a state is missing."""
     name = "robot_l2"
 
     def __call__(self, curr: State, goal: State):
         if curr.state is None or goal.state is None:
             return 0.0
-        a, b = np.asarray(torch.as_tensor(curr.state).cpu()), np.asarray(torch.as_tensor(goal.state).cpu())
-        d = (a - b) ** 2
-        return -np.sqrt(d.sum(-1))
+        if _is_tensor(curr.state, goal.state):
+            d = (torch.as_tensor(curr.state) - torch.as_tensor(goal.state)) ** 2
+            if d.dim() not in (1, 2):
+                raise NotImplementedError(f"Tensor shape {d.shape} not supported")
+            return -(d.sum(1) if d.dim() == 2 else d.sum()).sqrt().cpu().numpy()
+        return -np.linalg.norm(np.asarray(curr.state) - np.asarray(goal.state))
 
 
 class ImgL2Cost(Cost):
-    """losses.py:209-240: -||255 (curr - goal)||_2 per candidate."""
+    """losses.py:209-240: -||255 (curr - goal)||_2 per candidate on the GPU; numpy images (the callers in src/mbrl
+    that score environment observations): -||curr - goal||_2 or, with `img_cost_threshold`, -#(|diff| > threshold)."""
     name = "img_l2"
 
-    def __call__(self, curr: State, goal: State):
-        if curr.img is None or goal.img is None:
+    def _call(self, curr_img, goal_img):
+        if curr_img is None or goal_img is None:
             return 0
-        return _img_cost(0, curr.img, goal.img)
+        curr_img, goal_img = curr_img.astype(np.float64), goal_img.astype(np.float64)
+        threshold = self._config.img_cost_threshold
+        if threshold is None:
+            return -np.linalg.norm(curr_img - goal_img)
+        return -np.sum(np.abs(curr_img - goal_img) > threshold)
+
+    def __call__(self, curr: State, goal: State):
+        if _is_tensor(curr.img, goal.img):
+            if curr.img is None or goal.img is None:
+                return 0
+            return _img_cost(0, curr.img, goal.img)
+        return self._call(curr.img, goal.img)
 
 
 class ImgDontcareCost(Cost):
-    """losses.py:242-287: robot (curr|goal mask) pixels dropped, divided by #world pixels."""
+    """losses.py:242-287: robot (curr|goal mask) pixels dropped; tensors: / #world pixels; numpy: / #world pixels only
+    with `img_cost_world_norm`, optional `img_cost_threshold` counting."""
     name = "img_dontcare"
 
-    def __call__(self, curr: State, goal: State):
-        if curr.img is None or goal.img is None:
+    def _call(self, curr_img, goal_img, curr_mask, goal_mask):
+        if curr_img is None or goal_img is None:
             return 0
-        return _img_cost(1, curr.img, goal.img, curr.mask, goal.mask)
+        curr_img, goal_img = curr_img.astype(np.float64), goal_img.astype(np.float64)
+        total_mask = curr_mask | goal_mask
+        a, b = curr_img[~total_mask], goal_img[~total_mask]
+        threshold = self._config.img_cost_threshold
+        loss = np.linalg.norm(a - b) if threshold is None else np.sum(np.abs(a - b) > threshold)
+        if self._config.img_cost_world_norm:
+            loss = loss / np.sum(~total_mask)
+        return -loss
+
+    def __call__(self, curr: State, goal: State):
+        if _is_tensor(curr.img, goal.img):
+            if curr.img is None or goal.img is None:
+                return 0
+            return _img_cost(1, curr.img, goal.img, curr.mask, goal.mask)
+        return self._call(curr.img, goal.img, curr.mask, goal.mask)
 
 
 class RobotWorldCost(Cost):
@@ -133,8 +167,20 @@ class RobotWorldCost(Cost):
 
     def __call__(self, curr: State, goal: State, print_cost=False, return_info=False):
         total = 0
+        print_str, info = "", {}
         for w, c in ((self.robot_cost_weight, self.robot_cost), (self.world_cost_weight, self.world_cost)):
             if w == 0:
                 continue
-            total = total + w * c(curr, goal)
-        return total
+            cost = w * c(curr, goal)
+            scalar = type(cost) in (np.float64, float)
+            if return_info:
+                if not scalar:
+                    raise NotImplementedError()  # batched version: as the reference
+                info[c.name] = cost
+            if print_cost:
+                print_str += (f"{c.name}: {cost:.4f} ," if scalar else
+                              "".join(f" {c.name}: {v:.4f} ," for v in cost))
+            total = total + cost
+        if print_cost:
+            print(print_str)
+        return (total, info) if return_info else total

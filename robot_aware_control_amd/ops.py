@@ -466,7 +466,8 @@ def deferred_wgrad(on_ready=None):
         yield
         pending, _DEFERRED = _DEFERRED, None
         # largest first: their all-reduces are the longest and overlap the remaining launches
-        for weight, items in sorted(pending.values(), key=lambda wi: -wi[0].numel()):
+        # (ties broken by address: every data-parallel rank issues its all-reduces in the same order)
+        for weight, items in sorted(pending.values(), key=lambda wi: (-wi[0].numel(), wi[0].data_ptr())):
             _wgrad_split_batch(items, weight)
             if on_ready is not None:
                 on_ready(weight)

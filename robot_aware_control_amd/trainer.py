@@ -94,6 +94,7 @@ class PredictionTrainer(object):
         torch.cuda.set_device(device)
         self._device = config.device = device
         self._logger = logger
+        self.robot_model = None  # finetune_* experiments: predict_batch(batch) -> (states, masks)
         self._init_models(config)
         self._scheduled_sampling = config.scheduled_sampling
         self._step = 0
@@ -104,7 +105,7 @@ class PredictionTrainer(object):
         self.phase_events = None  # set to [] to record (name, cuda event) marks of every train step (bench.py)
         # the model / optimiser object graph is static from here on: keep the cyclic GC's full collections from
         # walking it (measured: one 33 ms host stall every ~10 train steps at cfg2, during which the GPU drains)
-        if os.environ.get("RAC_GC_FREEZE", "1") == "1":
+        if os.environ.get("RAC_GC_FREEZE", "0") == "1":  # opt-in (bench.py, the CLI): process-global and irreversible
             import gc
             gc.collect()
             gc.freeze()
@@ -192,8 +193,21 @@ class PredictionTrainer(object):
             if cf.load_movement_info:
                 batch["high_movement"] = data["high_movement"]
             if "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state):
-                raise NotImplementedError("finetune_* experiments need the CPU analytical robot model "
-                                          "(trainer.py:294-319), which is outside the accelerated path")
+                # finetune_*: states and masks of the window come from a robot model (trainer.py:294-319)
+                if getattr(cf, "preprocess_action", "raw") != "raw":
+                    batch["raw_actions"], batch["raw_states"] = data["raw_actions"][s:e - 1], data["raw_states"][s:e]
+                    batch["raw_low"], batch["raw_high"] = data["raw_low"], data["raw_high"]
+                batch["low"], batch["high"] = data["low"], data["high"]
+                if getattr(self, "robot_model", None) is None:
+                    raise NotImplementedError(
+                        "finetune_* windows take their robot states and masks from an analytical / learned robot model "
+                        "(trainer.py:294-319): set `trainer.robot_model` to an object with predict_batch(batch) -> "
+                        "(states, masks) -- the reference's LocobotAnalyticalModel, or robot_atlas.AtlasRobotModel")
+                out = self.robot_model.predict_batch(batch)
+                if getattr(cf, "model_use_heatmap", False):
+                    batch["states"], batch["masks"], batch["heatmaps"] = out
+                else:
+                    batch["states"], batch["masks"] = out
             losses = self._train_step(batch)
             for k, v in losses.items():
                 all_losses[k] += v / floor(T / window)
@@ -417,13 +431,18 @@ class PredictionTrainer(object):
         return losses
 
     # ----------------------------------------------------------- outer loops
-    def train(self, batch_generator=None, test_hook=None):
-        """Epoch loop with checkpoint cadence (trainer.py:736-792).  `batch_generator` yields time-first
-        batches in the layout of `process_batch` (robonet_dataset.py:434-451)."""
+    def train(self, batch_generator=None, test_hook=None, test_loader=None):
+        """Epoch loop with checkpoint and evaluation cadence (trainer.py:736-792).  `batch_generator` yields time-first
+        batches in the layout of `process_batch` (robonet_dataset.py:434-451); by default the loaders come from
+        `_setup_data`.  Every `eval_interval` epochs the model is evaluated on the test loader
+        (`_compute_epoch_metrics`, keys `test/*`) as the reference does."""
         cf = self._config
         self._step = self._load_checkpoint(cf.dynamics_model_ckpt)
-        gen = batch_generator if batch_generator is not None else self._setup_data()
-        epoch = 0
+        if batch_generator is None:
+            batch_generator, test_loader = self._setup_data()
+        gen = batch_generator
+        info = {}
+        self.eval_history = []
         for epoch in range(cf.niter):
             self.model.train()
             for _ in range(cf.epoch_size):
@@ -436,29 +455,42 @@ class PredictionTrainer(object):
                     self._wandb.log({f"train/{k}": v for k, v in info.items()}, step=self._step)
             if epoch % cf.checkpoint_interval == 0 and epoch > 0:
                 self._save_checkpoint()
-            if test_hook is not None and epoch % cf.eval_interval == 0:
+            if epoch % cf.eval_interval == 0:
                 self.model.eval()
-                test_hook(self, epoch)
+                if test_loader is not None:
+                    test_info = self._compute_epoch_metrics(test_loader, "test")
+                    self.eval_history.append((epoch, test_info))
+                    if self._wandb is not None:
+                        self._wandb.log(test_info, step=self._step)
+                if test_hook is not None:
+                    test_hook(self, epoch)
         self._save_checkpoint()
         return info
 
     def _setup_data(self):
-        """Dataloaders are I/O (h5py) and stay the reference's; `--data_root synthetic` feeds the
-        deterministic generator of robot_aware_control_amd.synthetic."""
+        """(infinite time-first batch generator, test loader).  `--data_root synthetic` feeds the deterministic
+        generator of robot_aware_control_amd.synthetic; anything else goes through this package's RoboNet data path
+        (data.py: same files, split and preprocessing as robonet_dataloaders.py:21-80, device prefetch)."""
         cf = self._config
+        from . import data as D
+        rank = dist.get_rank() if _dist_on() else 0
         if cf.data_root == "synthetic":
             from .synthetic import synth_video
 
             def gen():
-                seed = cf.seed
+                seed = cf.seed + 1000003 * rank  # every data-parallel rank trains on its own videos
                 while True:
                     seed += 1
                     yield synth_video(seed, cf.video_length, cf.batch_size, cf.image_height, cf.image_width,
                                       cf.robot_dim, cf.action_dim)
-            return gen()
-        from src.dataset.robonet.robonet_dataloaders import create_loaders, get_batch  # reference data layer
-        train_loader, *_ = create_loaders(cf)
-        return get_batch(train_loader, self._device)
+            n_eval = getattr(cf, "n_eval", cf.n_past + cf.n_future)
+            test = torch.utils.data.DataLoader(
+                D.SyntheticVideoDataset(2 * getattr(cf, "test_batch_size", cf.batch_size), max(n_eval, cf.video_length),
+                                        cf.image_height, cf.image_width, cf.robot_dim, cf.action_dim, seed=cf.seed + 7),
+                batch_size=getattr(cf, "test_batch_size", cf.batch_size))
+            return gen(), test
+        train_loader, test_loader = D.create_loaders(cf)
+        return D.get_batch(train_loader, self._device), test_loader
 
     def _save_checkpoint(self):
         """trainer.py:829-837."""

@@ -59,7 +59,7 @@ class TrajectorySampler(object):
         self.high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
         self.robot_model = robot_model
         self._robot_ctor = (cam_ext, franka_ik, wx250s_bot, push_height, default_pitch, default_roll)
-        if os.environ.get("RAC_GC_FREEZE", "1") == "1":  # see PredictionTrainer.__init__: no full-GC walks of the model
+        if os.environ.get("RAC_GC_FREEZE", "0") == "1":  # opt-in, see PredictionTrainer.__init__
             import gc
             gc.collect()
             gc.freeze()
@@ -131,7 +131,10 @@ class TrajectorySampler(object):
 
         # ---- candidate sharding over ranks (one process per GPU) ----
         world, rank = 1, 0
-        if dist.is_available() and dist.is_initialized() and getattr(cfg, "cem_shard", True):
+        # the debug outputs (predicted frames / per-step costs of the elites, indexed over ALL candidates) are not
+        # gathered: a call that asks for them rolls every candidate out on every rank
+        if (dist.is_available() and dist.is_initialized() and getattr(cfg, "cem_shard", True)
+                and not (ret_obs or ret_step_cost)):
             world, rank = dist.get_world_size(), dist.get_rank()
         lo, hi = shard_bounds(N, world, rank)
         n_local = hi - lo
@@ -164,11 +167,13 @@ class TrajectorySampler(object):
                 add = (not cfg.sparse_cost) or t == T - 1
                 nxt = torch.empty_like(curr)
                 before = sum_cost_dev[s - lo:e - lo].clone() if ret_step_cost else None
+                # locals: the (possibly copied) operands must outlive the raw-pointer launch
+                next_mask = masks[t + 1, s:e].contiguous() if (dontcare_in or dontcare_cost) else None
+                goal_mask = goal_masks[gi].contiguous() if (dontcare_cost and goal_masks is not None) else None
+                goal_img = goal_imgs[gi].contiguous()
                 _lib.call(
-                    "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(),
-                    _lib.ptr(masks[t + 1, s:e].contiguous()) if dontcare_in else None, goal_imgs[gi].data_ptr(),
-                    _lib.ptr(masks[t + 1, s:e].contiguous()) if dontcare_cost else None,
-                    _lib.ptr(goal_masks[gi].contiguous()) if (dontcare_cost and goal_masks is not None) else None,
+                    "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(), _lib.ptr(next_mask) if dontcare_in else None,
+                    goal_img.data_ptr(), _lib.ptr(next_mask) if dontcare_cost else None, _lib.ptr(goal_mask),
                     kind, w_world, 1 if (add and w_world != 0) else 0, nxt.data_ptr(),
                     sum_cost_dev[s - lo:e - lo].data_ptr(), n, H * W, _lib.stream_ptr())
                 if ret_obs:

@@ -1,3 +1,4 @@
-"""`from src.dataset.robonet.robonet_dataset import process_batch, get_batch` (reference robonet_dataset.py:434-467).
-The hdf5 dataset classes themselves are the reference's."""
-from robot_aware_control_amd.data import get_batch, process_batch  # noqa: F401
+"""`from src.dataset.robonet.robonet_dataset import RoboNetDataset, process_batch, get_batch, normalize, denormalize`
+(reference src/dataset/robonet/robonet_dataset.py)."""
+from robot_aware_control_amd.data import (RoboNetDataset, denormalize, get_batch, normalize,  # noqa: F401
+                                          process_batch)

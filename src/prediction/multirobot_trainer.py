@@ -5,6 +5,7 @@ scripts/train_multirobot_svg.sbatch:15).  Flags are those of src/config/__init__
 `python -m torch.distributed.run` it trains data-parallel, one process per GPU (RCCL)."""
 import os
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -29,7 +30,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
         dist.init_process_group("nccl")
-    torch.manual_seed(config.seed + int(os.environ.get("RANK", 0)))
+    rank = int(os.environ.get("RANK", 0))
+    torch.manual_seed(config.seed + rank)   # eps draws differ per data-parallel rank
+    np.random.seed(config.seed)             # scheduled-sampling coins: the SAME on every rank (same code path)
+    os.environ.setdefault("RAC_GC_FREEZE", "1")  # this process only trains: keep full GC passes off the step
     make_log_folder(config)
     trainer = PredictionTrainer(config)
     trainer.train()
