@@ -164,6 +164,27 @@ def gen_forward():
             save(f"fwd_{mode}_{tag}", **out)
 
 
+def gen_heatmap():
+    """M4 with `--model_use_heatmap True --model_use_future_heatmap True` (dynamics.py:476-487,578-582): the heatmap
+    planes sit between the image and the mask in the encoder input."""
+    cfg = orc.Cfg(g_dim=32, z_dim=8, batch_size=2, model_use_heatmap=True, model_use_future_heatmap=True,
+                  **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=13)
+    data = syn.synth_video(seed=6, T=2, B=2)
+    hm = torch.from_numpy(np.random.Generator(np.random.Philox(key=[6, 99])).random((2, 2, 1, 64, 64), dtype=np.float32))
+    eps = syn.synth_eps(seed=7, steps=1, B=2, z=8, h=8, w=8)
+    m = ref_model(cfg, sd, train=False)
+    m.init_hidden(2)
+    with torch.no_grad():
+        x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1)
+        hm_in, hm_next = torch.cat([hm[0], hm[1]], 1), hm[1].repeat(1, 2, 1, 1)
+        _EPS.extend([eps[0][0], eps[0][1]])
+        o = m(x_j, m_in, r, hm_in, a, x_i, m_next, r_i, hm_next, None)
+        assert not _EPS
+    assert m.encoder.c1[0].main[0].weight.shape[1] == 7
+    save("fwd_heatmap", x_pred=o[0], mu=o[2], mu_p=o[4], logvar_p=o[5], heatmaps=hm)
+
+
 def gen_shape_pin():
     """F6: 48x64 input -> 6x8 latent."""
     cfg = orc.Cfg(g_dim=32, z_dim=8, batch_size=1, image_height=48, image_width=64, **FLAGSETS["vanilla"])
@@ -587,7 +608,9 @@ def gen_train_video():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep", "dataset",
-                             "simcem", "trainvideo", "hostcosts"]
+                             "simcem", "trainvideo", "hostcosts", "heatmap"]
+    if "heatmap" in which:
+        gen_heatmap()
     if "simcem" in which:
         gen_sim_cem()
     if "trainvideo" in which:

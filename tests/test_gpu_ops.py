@@ -441,7 +441,7 @@ def test_conv_split_rows_kernel(dev, case):
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3)])
-def test_wgrad_split_precision(dev, case):
+def test_wgrad_split_precision(dev, case, monkeypatch):
     """Weight gradient on the split-precision pipe against fp64, next to the exact-fp32 MFMA kernel; accumulation into
     .grad; the deferred (time-batched) form."""
     from robot_aware_control_amd import ops
@@ -462,6 +462,17 @@ def test_wgrad_split_precision(dev, case):
     assert e_split < 3e-6 and e_split < 4 * e_fp32 + 3e-7, (e_split, e_fp32)
     ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)  # accumulates
     assert relerr(wd.grad.cpu(), 2 * ref) < 3e-6
+    # no atomics: the same operands give the same bits, K split (slabs + fixed-order accumulate) included
+    for forced in (None, "3"):
+        reps = []
+        for _ in range(2):
+            wr = cl_weight(w.detach()).to(dev).requires_grad_(True)
+            if forced:
+                monkeypatch.setenv("RAC_WGRAD_SPLITK", forced)
+            ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wr)
+            monkeypatch.delenv("RAC_WGRAD_SPLITK", raising=False)
+            reps.append(wr.grad.clone())
+        assert torch.equal(reps[0], reps[1]) and relerr(reps[0].cpu(), ref) < 3e-6
     # deferred: the time steps' operands in ONE launch when the context exits
     wd3 = cl_weight(w.detach()).to(dev).requires_grad_(True)
     with ops.deferred_wgrad():

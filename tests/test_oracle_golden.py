@@ -72,6 +72,25 @@ def test_forward(golden_dir, tag, mode):
         assert int(sd["decoder.upc5.0.main.1.num_batches_tracked"]) == 2
 
 
+def heatmap_case():
+    cfg = orc.Cfg(g_dim=32, z_dim=8, batch_size=2, model_use_heatmap=True, model_use_future_heatmap=True,
+                  **FLAGSETS["ra"])
+    return (cfg, orc.make_weights(cfg, seed=13), syn.synth_video(seed=6, T=2, B=2),
+            syn.synth_eps(seed=7, steps=1, B=2, z=8, h=8, w=8))
+
+
+def test_forward_heatmap(golden_dir):
+    """--model_use_heatmap / --model_use_future_heatmap: encoder input [img | heatmaps | masks] (dynamics.py:578-582)."""
+    g = load(golden_dir, "fwd_heatmap")
+    cfg, sd, data, eps = heatmap_case()
+    hm = torch.from_numpy(g["heatmaps"])
+    with torch.no_grad():
+        x_j, m_in, r, a, x_i, m_next, r_i = step_inputs(cfg, data, 1)
+        o = orc.svg_forward(sd, cfg, orc.init_hidden(cfg, 2), x_j, m_in, r, torch.cat([hm[0], hm[1]], 1), a, x_i, m_next,
+                            r_i, hm[1].repeat(1, 2, 1, 1), None, eps_prior=eps[0][0], eps_post=eps[0][1])
+    close(o[0], g["x_pred"]); close(o[2], g["mu"]); close(o[4], g["mu_p"]); close(o[5], g["logvar_p"])
+
+
 def test_shape_pin_48x64(golden_dir):
     g = load(golden_dir, "fwd_48x64")
     cfg = orc.Cfg(g_dim=32, z_dim=8, batch_size=1, image_height=48, image_width=64, **FLAGSETS["vanilla"])
