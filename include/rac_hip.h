@@ -300,6 +300,20 @@ int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask
                       const float* cost_mask, const uint8_t* goal_mask, int32_t kind, float weight, int32_t add_cost,
                       float* next_out, double* sum_cost, int32_t N, int32_t HW, void* stream);
 
+/* Robot-aware CEM inputs for ALL candidates on the device (replaces the per-candidate CPU loop of
+ * `robot_model.predict_batch(start_data, thick=True)`, src/cem/trajectory_sampler.py:86-109 over
+ * src/dataset/wx250s/wx250s_model.py:121-163 / locobot_model.py:100-140):
+ *   states[t][n] = normalised (x, y, push_height, 0, 0) with (x, y) = start + sum_{s<t} actions[s][n][0:2]   (t >= 1;
+ *                  t = 0: the start state), computed in the robot's own frame (`diff` = offset of that frame) with the
+ *                  reference's float32 / float64 promotion;
+ *   masks[t][n]  = atlas[nearest grid node of (x, y)]: robot masks rendered ONCE by the analytical model on a regular
+ *                  grid of end-effector positions (node (i, j) at (x0 + i dx, y0 + j dy); uint8 [ny][nx][HW]).
+ * actions [T][N][A] time-first, start_state / low / high [5]; outputs states [T+1][N][5], masks [T+1][N][HW] fp32. */
+int rac_cem_robot_inputs(const float* actions, const float* start_state, const float* low, const float* high,
+                         const uint8_t* atlas, int32_t nx, int32_t ny, float x0, float y0, float dx, float dy,
+                         float diff_x, float diff_y, float push_height, float* states, float* masks, int32_t T,
+                         int32_t N, int32_t A, int32_t HW, void* stream);
+
 /* torch.optim.Adam step (trainer.py:109-110,461), fused over one flat buffer. step >= 1. */
 int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, void* stream);

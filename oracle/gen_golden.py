@@ -574,6 +574,54 @@ def gen_host_costs():
     save("host_costs", **out)
 
 
+def gen_robot_states():
+    """8f-3: the state propagation of the analytical robot models' predict_batch
+    (src/dataset/wx250s/wx250s_model.py:57-163; locobot_model.py is the same with no frame offset), run through the
+    REAL reference code with the robot SDK's IK and the MuJoCo mask render replaced by inert stand-ins (neither
+    influences the states)."""
+    from src.dataset.wx250s.wx250s_model import WX250sAnalyticalModel
+    from src.dataset.locobot.locobot_model import LocobotAnalyticalModel, PUSH_HEIGHT as LOCO_PUSH_HEIGHT
+    g = np.random.Generator(np.random.Philox(key=[12, 3]))
+    T, N, H, W = 6, 7, 48, 64
+    low = torch.tensor([[0.015, -0.3, 0.1, 0, 0]], dtype=torch.float32)
+    high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
+    start = torch.from_numpy(g.random(5, dtype=np.float32))
+    actions = torch.from_numpy(np.clip(g.standard_normal((T, N, 5), dtype=np.float32) * 0.03, -0.05, 0.05))
+    out = dict(start=start, actions=actions, low=low[0], high=high[0])
+
+    class Env:
+        def generate_masks(self, qpos):
+            return [np.zeros((H, W), np.uint8) for _ in qpos]
+
+    class Arm:
+        def set_ee_pose_components(self, **k):
+            return k["custom_guess"], True
+
+    class Bot:
+        arm = Arm()
+
+    class IK:
+        def ik(self, eef, alpha=None, cur_arm_config=None):
+            return cur_arm_config
+    for tag, Model, qd in (("wx250s", WX250sAnalyticalModel, 6), ("locobot", LocobotAnalyticalModel, 5)):
+        m = object.__new__(Model)
+        m._config = argparse.Namespace(device=torch.device("cpu"), image_width=W, image_height=H, preprocess_action="raw",
+                                       model_use_heatmap=False)
+        m.env = m.env_thick = Env()
+        m._img_transform = lambda i: torch.zeros(1, H, W)
+        m.bot, m.ik_solver = Bot(), IK()
+        m.push_height, m.default_pitch, m.default_roll = 0.115, 1.3, 0.0
+        states = torch.zeros((T + 1, N, 5))
+        states[0] = start
+        data = {"states": states, "qpos": torch.zeros((T + 1, N, qd)), "actions": actions, "low": low.repeat(N, 1),
+                "high": high.repeat(N, 1)}
+        p_states, p_masks = m.predict_batch(data, thick=True)
+        assert p_masks.shape == (T + 1, N, 1, H, W)
+        out[f"{tag}_states"] = p_states
+    out["wx250s_push_height"], out["locobot_push_height"] = 0.115, LOCO_PUSH_HEIGHT
+    save("robot_states", **out)
+
+
 def gen_train_video():
     """T2: PredictionTrainer._train_video window slicing (trainer.py:259-324), sequential and `--random_snippet`
     (starts drawn from `_video_sample_rng = RandomState(seed)`, trainer.py:89), with `_train_step` recording what it
@@ -608,13 +656,15 @@ def gen_train_video():
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep", "dataset",
-                             "simcem", "trainvideo", "hostcosts", "heatmap"]
+                             "simcem", "trainvideo", "hostcosts", "heatmap", "robot"]
     if "heatmap" in which:
         gen_heatmap()
     if "simcem" in which:
         gen_sim_cem()
     if "trainvideo" in which:
         gen_train_video()
+    if "robot" in which:
+        gen_robot_states()
     if "hostcosts" in which:
         gen_host_costs()
     if "dataset" in which:

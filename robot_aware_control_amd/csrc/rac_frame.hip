@@ -276,6 +276,59 @@ __global__ void cem_step_tail_kernel(const f32x4* x4, const float* curr, const f
 using namespace rac;
 #define ST(s) reinterpret_cast<hipStream_t>(s)
 
+
+// ---- robot-aware CEM inputs on the device -----------------------------------------------------
+// For every candidate n and step t: the robot state the reference's analytical models predict
+// (src/dataset/wx250s/wx250s_model.py:57-80,121-163, locobot_model.py:50-116: the end effector moves by the planar
+// action, height = push_height, rotation / gripper 0, re-normalised) and the robot mask of that end-effector position,
+// looked up in an ATLAS of masks rendered once on a regular (x, y) grid of end-effector positions.
+// One workgroup per (t, n): thread 0 re-accumulates the <= T actions, all threads copy the H*W mask bytes as floats.
+struct RobotAtlasP {
+  const float* actions;   // [T][N][A] (time first), world-frame displacements
+  const float* start;     // [5] normalised start state (states[0] of every candidate)
+  const float* low;       // [5]
+  const float* high;      // [5]
+  const unsigned char* atlas;  // [ny][nx][HW]
+  float* states;          // [T+1][N][5]
+  float* masks;           // [T+1][N][HW]
+  int T, N, A, HW, nx, ny;
+  float x0, y0, inv_dx, inv_dy;  // grid: node (i, j) = (x0 + i / inv_dx, y0 + j / inv_dy) in the states' world frame
+  float diff_x, diff_y, push_height;
+};
+
+__global__ void robot_atlas_kernel(RobotAtlasP p) {
+  __shared__ int node;
+  const int n = blockIdx.x, t = blockIdx.y;
+  if (threadIdx.x == 0) {
+    // denormalise the start, shift into the robot's own frame (float32, as the numpy / torch code does)
+    float den[5];
+    for (int k = 0; k < 5; ++k) den[k] = p.start[k] * (p.high[k] - p.low[k]) + p.low[k];
+    float raw[5];
+    if (t == 0) {
+      raw[0] = (den[0] - p.diff_x) + p.diff_x, raw[1] = (den[1] - p.diff_y) + p.diff_y;
+      raw[2] = den[2], raw[3] = den[3], raw[4] = den[4];
+    } else {
+      const float* a = p.actions + (long)n * p.A;
+      const long st = (long)p.N * p.A;
+      // the first step adds in float32 (both operands are), the later ones in float64 (numpy's promotion)
+      double x = (double)((den[0] - p.diff_x) + a[0]), y = (double)((den[1] - p.diff_y) + a[1]);
+      for (int s = 1; s < t; ++s) x += (double)a[s * st], y += (double)a[s * st + 1];
+      raw[0] = (float)x + p.diff_x, raw[1] = (float)y + p.diff_y;
+      raw[2] = p.push_height, raw[3] = 0.f, raw[4] = 0.f;
+    }
+    float* o = p.states + ((long)t * p.N + n) * 5;
+    for (int k = 0; k < 5; ++k) o[k] = (raw[k] - p.low[k]) / (p.high[k] - p.low[k]);
+    int ix = (int)rintf((raw[0] - p.x0) * p.inv_dx), iy = (int)rintf((raw[1] - p.y0) * p.inv_dy);
+    ix = ix < 0 ? 0 : (ix >= p.nx ? p.nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= p.ny ? p.ny - 1 : iy);
+    node = iy * p.nx + ix;
+  }
+  __syncthreads();
+  const unsigned char* src = p.atlas + (long)node * p.HW;
+  float* dst = p.masks + ((long)t * p.N + n) * p.HW;
+  for (int i = threadIdx.x; i < p.HW; i += blockDim.x) dst[i] = src[i] ? 1.f : 0.f;
+}
+
 extern "C" {
 
 int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, int32_t pad, float* packed,
@@ -375,6 +428,19 @@ int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask
   hipLaunchKernelGGL(cem_step_tail_kernel, dim3(N), dim3(256), 0, ST(stream), (const f32x4*)x4, curr, next_mask,
                      goal_img, cost_mask, goal_mask, kind, weight, add_cost, next_out, sum_cost, HW);
   return check_launch("rac_cem_step_tail");
+}
+
+int rac_cem_robot_inputs(const float* actions, const float* start_state, const float* low, const float* high,
+                         const uint8_t* atlas, int32_t nx, int32_t ny, float x0, float y0, float dx, float dy,
+                         float diff_x, float diff_y, float push_height, float* states, float* masks, int32_t T,
+                         int32_t N, int32_t A, int32_t HW, void* stream) {
+  RAC_REQUIRE(actions && start_state && low && high && atlas && states && masks, "rac_cem_robot_inputs: null pointer");
+  RAC_REQUIRE(T >= 0 && N > 0 && A >= 2 && HW > 0 && nx > 0 && ny > 0 && dx > 0.f && dy > 0.f && T < 65535,
+              "rac_cem_robot_inputs: bad sizes");
+  RobotAtlasP p{actions, start_state, low, high, atlas, states, masks, T, N, A, HW, nx, ny, x0, y0, 1.f / dx, 1.f / dy,
+                diff_x, diff_y, push_height};
+  hipLaunchKernelGGL(robot_atlas_kernel, dim3(N, T + 1), dim3(256), 0, ST(stream), p);
+  return check_launch("rac_cem_robot_inputs");
 }
 
 }  // extern "C"
