@@ -118,7 +118,10 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
  * a->Cout need not be a multiple of 32 (the 4-channel output head): the parts must then come from the weight with its
  * rows zero-padded to the next multiple of 32; only Cout columns are computed into the output (row stride Cout). */
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
-                         int64_t w_part_stride, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
+                         int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
+/* w_cin (0 = a->Cin): input channels the weight parts were built with.  a->Cin < w_cin runs the conv over the first
+ * a->Cin input channels only (a channel prefix is a prefix of every tile's weight stream): the ConvLSTM cells' first
+ * step, whose hidden state is all zeros, skips the hidden half of K (and of the data gradient's N, through a->Cout). */
 /* `*_amax` OUTPUT arguments (here and on rac_affine_act, rac_bn_bwd_apply, rac_tilecat_fwd, rac_slab_reduce,
  * rac_lstm_cell_bwd; nullable): the kernel folds max |v| of the tensor it writes into the slot as rac_absmax would,
  * which saves the consumer conv a reduction pass over it (split_k > 1 writes raw slabs: no out_amax there). */

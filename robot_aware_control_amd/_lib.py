@@ -50,7 +50,7 @@ _SIGS = {
     "rac_absmax": [vp, i64, vp, i64, vp, vp],
     "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
-    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, vp, vp, vp],
+    "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
     "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],

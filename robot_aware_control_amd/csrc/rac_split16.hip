@@ -94,6 +94,7 @@ struct Conv16P {
   double* stats;
   long stats_rows;
   int M, N, HW, P, taps, cchunks, nchunks, cps;
+  int w_nchunks;  // chunk-taps per 32-column tile in the weight parts (>= nchunks: the conv may use a channel prefix)
   int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
   int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ntile = (n0 >> 5) + wn * NT + j;
-    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.w_nchunks * 2048u : 0u) + (unsigned)lane * 16u;
   }
   auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
     const int so = kc * 2048;
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int ntile = (n0 >> 5) + wn * NT + j;
-    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.w_nchunks * 2048u : 0u) + (unsigned)lane * 16u;
   }
   auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
     const int so = kc * 2048;
@@ -702,12 +703,11 @@ typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
 // the 16x16x32 operand of lane (i = l & 15, g = l >> 4): column i of pixel rows 8g .. 8g+7 of a [row][256 B] image
 __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int addr) {
+  typedef __fp16 h16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
   const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds, addr));
   const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds, addr + 1024));
-  f16x8 r;
-  r[0] = (_Float16)lo[0], r[1] = (_Float16)lo[1], r[2] = (_Float16)lo[2], r[3] = (_Float16)lo[3];
-  r[4] = (_Float16)hi[0], r[5] = (_Float16)hi[1], r[6] = (_Float16)hi[2], r[7] = (_Float16)hi[3];
-  return r;
+  // one register tuple: the two 64-bit reads land in the halves of the MFMA operand, no moves
+  return __builtin_bit_cast(f16x8, (h16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 template <int KS>
@@ -943,7 +943,8 @@ extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, i
 }
 
 extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
-                                    int64_t w_part_stride, const uint32_t* w_amax, uint32_t* out_amax, void* stream) {
+                                    int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax,
+                                    void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0 && a_amax0 && w_amax,
               "rac_conv2d_fwd_split: bad args");
@@ -972,15 +973,18 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
   RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
               "rac_conv2d_fwd_split: operand larger than 4 GiB");
-  RAC_REQUIRE(w_part_stride >= (long)n_rows * p.taps * p.Cin && 2 * w_part_stride * 2 < 0xFFFFFF00L,
+  if (w_cin <= 0) w_cin = a->Cin;
+  RAC_REQUIRE(w_cin >= a->Cin && w_cin % SBK == 0, "rac_conv2d_fwd_split: w_cin must be a multiple of 32, >= Cin");
+  RAC_REQUIRE(w_part_stride >= (long)n_rows * p.taps * w_cin && 2 * w_part_stride * 2 < 0xFFFFFF00L,
               "rac_conv2d_fwd_split: weight part stride");
   RAC_REQUIRE(p.split_k == 1 || a->slab_stride >= (long)p.M * p.n_store, "rac_conv2d_fwd_split: slab_stride too small");
   RAC_REQUIRE(p.stats_rows >= 0 && (p.stats_rows == 0 || ((long)a->B * a->H * a->W) % p.stats_rows == 0),
               "rac_conv2d_fwd_split: stats_rows must divide B*H*W");
   p.cchunks = a->Cin / SBK;
   p.nchunks = p.taps * p.cchunks;
+  p.w_nchunks = p.taps * (w_cin / SBK);
   p.cps = cdiv(p.nchunks, p.split_k);
-  RAC_REQUIRE((long)(n_rows / 32) * p.nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
+  RAC_REQUIRE((long)(n_rows / 32) * p.w_nchunks * 2048L < 0xFFFFFF00L, "rac_conv2d_fwd_split: weight part too large");
   static const char* xg = getenv("RAC_XCD_GROUP");
   const bool want_xcd = xg ? atoi(xg) != 0 : true;
   if (p.HW > 128) {

@@ -194,8 +194,12 @@ class _ConvLSTM(nn.Module):
         dev = next(self.parameters()).device
         h, w = self._hw
         one = ops.amax_one(dev)
-        return [(ops.tag_amax(torch.zeros(b, h, w, self.hid_ch, device=dev), one),
-                 torch.zeros(b, h, w, self.hid_ch, device=dev)) for _ in self.lstm]
+        out = []
+        for _ in self.lstm:
+            h0 = ops.tag_amax(torch.zeros(b, h, w, self.hid_ch, device=dev), one)
+            h0._rac_zero = True  # the first step's gate conv skips the hidden half of K (ops.is_zero)
+            out.append((h0, torch.zeros(b, h, w, self.hid_ch, device=dev)))
+        return out
 
     def forward(self, x):
         for i, cell in enumerate(self.lstm):

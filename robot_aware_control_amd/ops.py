@@ -365,7 +365,7 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
 
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
-                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None):
+                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
@@ -378,22 +378,33 @@ def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, 
     if SHAPE_LOG is not None:
         _log_shape("conv16", DGRAD if getattr(pw, "_rac_transposed", False) else FWD, k, B * H * W, Cout, Cin * k * k,
                    2500.0 / 3)
-    call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], ptr(wslot), ptr(out_amax), stream_ptr())
+    call("rac_conv2d_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], w_cin, ptr(wslot), ptr(out_amax),
+         stream_ptr())
     if timed:
         e1.record()
         prof["events"].append((e0, e1, B * H * W))
         prof["split"] = True
 
 
+def is_zero(t) -> bool:
+    """Tensors known to be all zeros (a ConvLSTM's initial state): convs skip their share of K."""
+    return t is not None and getattr(t, "_rac_zero", False)
+
+
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
                        want_slabs=False, groups=1):
     """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
-    `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel."""
+    `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel.
+    An all-zero x1 (`is_zero`) is skipped: the conv runs over the x0 channels of the same weight parts."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
+    Cout, Cin_w, k, _ = weight.shape
+    w_cin = 0
+    if is_zero(x1) and C0 % 32 == 0:
+        x1, w_cin = None, Cin_w
     C1 = x1.shape[3] if x1 is not None else 0
-    Cout, Cin, k, _ = weight.shape
-    assert Cin == C0 + C1
+    Cin = C0 + C1
+    assert Cin == Cin_w or w_cin
     M = B * H * W
     x0 = x0 if x0.is_contiguous() else x0.contiguous()
     if x1 is not None and not x1.is_contiguous():
@@ -401,7 +412,7 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     a0 = amax_for(x0)
     a1 = amax_for(x1) if x1 is not None else None
     pw, wslot = weight_parts(weight)
-    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0)
+    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, w_cin=w_cin)
     if want_slabs:
         split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
         out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
@@ -424,11 +435,14 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     return tag_amax(out, slot)
 
 
-def conv_dgrad_split(dy, weight, C0: int, C1: int = 0):
-    """Data gradient on the split-precision pipe: forward conv of dy with the transposed, tap-flipped weight."""
+def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
+    """Data gradient on the split-precision pipe: forward conv of dy with the transposed, tap-flipped weight.
+    `need1` False: only the first C0 input channels' gradient is computed (returns (dx0, None))."""
     B, H, W, Cout = dy.shape
     Co, Cin, k, _ = weight.shape
     assert Co == Cout and Cin == C0 + C1
+    if C1 and not need1 and C0 % 32 == 0:
+        Cin, C1 = C0, 0  # the first C0 rows of the transposed weight are a prefix of its parts
     M = B * H * W
     dy = dy if dy.is_contiguous() else dy.contiguous()
     pw, wslot = weight_parts(weight, transposed=True)
@@ -905,7 +919,7 @@ class LstmCell(torch.autograd.Function):
         dx = dh_prev = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             if ctx.split:
-                dx, dh_prev = conv_dgrad_split(dgates, weight, g, g)
+                dx, dh_prev = conv_dgrad_split(dgates, weight, g, g, need1=ctx.needs_input_grad[1])
             else:
                 dx, dh_prev = conv_dgrad(dgates, weight, g, g)
         if weight.requires_grad:

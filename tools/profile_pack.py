@@ -1,0 +1,107 @@
+"""Turn the rocprofv3 output of tools/run_profiles.sh into the files kept under profiles/.
+
+    python tools/profile_pack.py gpurun_out/<tag> <tag>
+
+  profiles/<tag>_train_shapes.md / _cem_shapes.md   per-shape roofline tables (tools/shape_profile.py)
+  profiles/<tag>_train_kernel_stats.csv / _cem_..    rocprofv3 --stats kernel summaries
+  profiles/<tag>_pmc_traffic.json                    L2<->fabric bytes per launch of the dominant kernels
+  profiles/<tag>_sq_summary.md                       MFMA-busy %, held clock, LDS bank conflicts, instruction mix
+
+HBM-side bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of a wide coalesced read
+(MI355X_MICROARCH.md, HBM section); FETCH / WRITE come from separate --pmc passes.  Effective clock = GRBM_GUI_ACTIVE
+/ 8 XCDs / kernel duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)."""
+import csv
+import glob
+import io
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNELS = ("conv16_tile_kernel", "conv16_rows_kernel", "wgrad16_kernel")
+
+
+def short(name):
+    return re.sub(r"\(.*", "", name.replace("rac::", "").replace("void ", ""))
+
+
+def counters(d):
+    agg = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k.startswith(KERNELS):
+                wg = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
+                agg[(k, wg)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+
+
+def main(src, tag):
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+    for wl, steps, title in (("train", 10, "cfg2 train step (3 priming + 2 warm-up + 5 timed steps profiled)"),
+                             ("cem", None, "cfg3 CEM")):
+        trace = os.path.join(src, f"stats_{wl}", "run_kernel_trace.csv")
+        shapes = os.path.join(src, f"{wl}_shapes.json")
+        stats = os.path.join(src, f"stats_{wl}", "run_kernel_stats.csv")
+        if os.path.exists(stats):
+            shutil.copy(stats, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
+        if os.path.exists(trace) and os.path.exists(shapes):
+            if steps is None:  # CEM: model steps profiled / 14 per iteration
+                n = sum(1 for r in json.load(open(shapes)) if r["family"] == "conv16" and r["k"] == 5)
+                steps = n / 3 / 14
+                title += f" ({n // 3} model steps profiled = {steps:.2f} iterations of 14; per-iteration numbers)"
+            md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shape_profile.py"), trace, shapes,
+                                 str(steps), title], capture_output=True, text=True, check=True).stdout
+            open(os.path.join(prof, f"{tag}_{wl}_shapes.md"), "w").write(md)
+    # ---- fabric traffic
+    res = {}
+    for name in ("gemm_train", "gemm_cem", "wgrad5", "wgrad3", "train"):
+        f, w = counters(os.path.join(src, f"pmc_FETCH_SIZE_{name}")), counters(os.path.join(src, f"pmc_WRITE_SIZE_{name}"))
+        rows = []
+        for key, c in f.items():
+            if key not in w:
+                continue
+            fk, wk = c.get("FETCH_SIZE", 0.0), w[key].get("WRITE_SIZE", 0.0)
+            rows.append({"kernel": key[0], "workgroups": key[1], "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB": wk,
+                         "hbm_side_bytes_per_launch": (2 * fk + wk) * 1024})
+        res[name] = sorted(rows, key=lambda r: -r["hbm_side_bytes_per_launch"])[:8]
+    res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes. Bytes = (2*FETCH_SIZE + "
+                    "WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a wide coalesced read). L2<->fabric bytes; "
+                    "Infinity-Cache hits are included. gemm_train / gemm_cem: tools/bench_gemm.py fwd at M=1024 / 64000; "
+                    "wgrad5 / wgrad3: the time-batched (T=5, B=16) ConvLSTM weight gradients.")
+    json.dump(res, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    # ---- SQ summary
+    out = io.StringIO()
+    out.write(f"# {tag}: SQ / GRBM counters of the conv kernels (tools/run_profiles.sh, separate --pmc passes)\n\n")
+    out.write("| run | kernel (workgroups) | MFMA busy | wave cycles: active / wait-inst / wait | LDS bank conflicts / LDS active "
+              "| VALU per MFMA | LDS instr per MFMA | VMEM reads per MFMA |\n|---|---|---|---|---|---|---|---|\n")
+    names = {1: "gate GEMM fwd M=1024 (bench_gemm)", 2: "gate GEMM fwd M=64000 (bench_gemm)", 3: "wgrad k=5, T=5 B=16",
+             4: "wgrad k=3, T=5 B=16", 5: "CEM iteration (bench.py --workload cem)"}
+    for i in range(1, 6):
+        a, b = counters(os.path.join(src, f"sq1_{i}")), counters(os.path.join(src, f"sq2_{i}"))
+        for key in sorted(a, key=lambda k: -a[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:3]:
+            c, d = a[key], b.get(key, {})
+            gui = c.get("GRBM_GUI_ACTIVE", 0) / 8
+            busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (1024 * gui) if gui else 0
+            wc = c.get("SQ_WAVE_CYCLES", 1)
+            mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 16  # 16 cycles per v_mfma_f32_16x16x32_f16
+            lds_act = d.get("SQ_LDS_IDX_ACTIVE", 0)
+            out.write(f"| {names[i]} | `{key[0]}` ({key[1]}) | {100 * busy:.1f} % | "
+                      f"{100 * c.get('SQ_ACTIVE_INST_ANY', 0) / wc:.0f} / {100 * c.get('SQ_WAIT_INST_ANY', 0) / wc:.0f} / "
+                      f"{100 * c.get('SQ_WAIT_ANY', 0) / wc:.0f} % | {c.get('SQ_LDS_BANK_CONFLICT', 0):.3g} / {lds_act:.3g} | "
+                      f"{(d.get('SQ_INSTS_VALU', 0) - mfma) / mfma if mfma else 0:.2f} | "
+                      f"{d.get('SQ_INSTS_LDS', 0) / mfma if mfma else 0:.3f} | {d.get('SQ_INSTS_VMEM_RD', 0) / mfma if mfma else 0:.3f} |\n")
+    out.write("\nMFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs): the share of matrix-pipe "
+              "cycles that carry an MFMA; the rest of the gap to the 2.5 PFLOP/s peak is the clock the chip holds under this "
+              "load (achieved TFLOP/s = 833.3 x busy x clock / 2.4 GHz; clocks in the shapes tables' durations).\n")
+    open(os.path.join(prof, f"{tag}_sq_summary.md"), "w").write(out.getvalue())
+    print("packed", tag)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
