@@ -235,8 +235,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     int cur = 0;
     bool fresh = true;
     // weights two steps ahead in three register sets.  (Measured alternatives, M = 1024 / 64 000 gate GEMM: A fragments
-    // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; this
-    // form 437 / 477.)
+    // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; skipping
+    // the MFMAs of row blocks that are all padding for a tap (10 % of a 5x5 conv on 8x8 maps) through three step
+    // variants: spills, 188 / 228 TF; this form 437 / 477.)
     u32x4 b0[4 * NT], b1[4 * NT], b2[4 * NT];
     issue_a(cc);
     load_b(b0, kc_begin);
@@ -1022,12 +1023,11 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
   p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
   constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
-  static const char* wm_env = getenv("RAC_TILE_WM");  // A/B: wave arrangement of the tile kernel
-  const int wm = wm_env ? atoi(wm_env) : 2;
-  typedef void (*tile_fn)(Conv16P);
-  static const tile_fn fns[2][2] = {{conv16_tile_kernel<1, false>, conv16_tile_kernel<1, true>},
-                                    {conv16_tile_kernel<2, false>, conv16_tile_kernel<2, true>}};
-  hipLaunchKernelGGL(fns[wm == 2][p.tile_m == 128], grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
+  // waves 2 x 2 (template argument 2); the 1 x 4 arrangement of the same kernel measured 10 % slower
+  if (p.tile_m == 128)
+    hipLaunchKernelGGL((conv16_tile_kernel<2, true>), grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL((conv16_tile_kernel<2, false>), grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
 }
 
