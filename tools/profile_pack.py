@@ -51,10 +51,10 @@ def main(src, tag):
         if os.path.exists(stats):
             shutil.copy(stats, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
         if os.path.exists(trace) and os.path.exists(shapes):
-            if steps is None:  # CEM: model steps profiled / 14 per iteration
-                n = sum(1 for r in json.load(open(shapes)) if r["family"] == "conv16" and r["k"] == 5)
-                steps = n / 3 / 14
-                title += f" ({n // 3} model steps profiled = {steps:.2f} iterations of 14; per-iteration numbers)"
+            if steps is None:  # CEM: model steps profiled (one cem_step_tail launch each) / 14 per iteration
+                n = sum(1 for r in csv.DictReader(open(trace)) if "cem_step_tail" in r["Kernel_Name"])
+                steps = n / 14
+                title += f" ({n} model steps profiled = {steps:.2f} iterations of 14; per-iteration numbers)"
             md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shape_profile.py"), trace, shapes,
                                  str(steps), title], capture_output=True, text=True, check=True).stdout
             open(os.path.join(prof, f"{tag}_{wl}_shapes.md"), "w").write(md)
