@@ -348,8 +348,11 @@ class PredictionTrainer(object):
     def _eval_video(self, data, autoregressive=False):
         """Evaluate a whole video in n_eval windows (trainer.py:490-564); ground-truth masks drive the rollout."""
         cf = self._config
-        if "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state):
-            raise NotImplementedError("finetune_* eval needs the CPU analytical robot model (trainer.py:520-543)")
+        finetune = "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state)
+        if finetune and getattr(self, "robot_model", None) is None:
+            raise NotImplementedError(
+                "finetune_* evaluation rolls out on the robot model's states and masks (trainer.py:520-543): set "
+                "`trainer.robot_model` (the reference's LocobotAnalyticalModel, or robot_atlas.AtlasRobotModel)")
         x = data["images"]
         T = len(x)
         window = cf.n_eval
@@ -360,6 +363,20 @@ class PredictionTrainer(object):
                      "masks": data["masks"][s:e], "pred_masks": data["masks"][s:e], "robot": data["robot"]}
             if getattr(cf, "model_use_heatmap", False):
                 batch["heatmaps"] = data["heatmaps"][s:e]
+            if finetune:
+                # predicted states / masks drive the rollout, the true masks score the world error (trainer.py:520-547)
+                for k in ("qpos",):
+                    if k in data:
+                        batch[k] = data[k][s:e]
+                if getattr(cf, "preprocess_action", "raw") != "raw":
+                    batch["raw_actions"], batch["raw_states"] = data["raw_actions"][s:e - 1], data["raw_states"][s:e]
+                    batch["raw_low"], batch["raw_high"] = data["raw_low"], data["raw_high"]
+                batch["low"], batch["high"] = data["low"], data["high"]
+                out = self.robot_model.predict_batch(batch)
+                if getattr(cf, "model_use_heatmap", False):
+                    batch["states"], batch["pred_masks"], batch["heatmaps"] = out
+                else:
+                    batch["states"], batch["pred_masks"] = out
             for k, v in self._eval_step(batch, autoregressive).items():
                 total[k] += v
         for k in total:

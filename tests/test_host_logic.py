@@ -101,6 +101,13 @@ def test_finetune_windows_use_the_robot_model():
             return torch.ones_like(bd["states"]), torch.ones_like(bd["masks"])
     tr.robot_model = Robot()
     assert tr._train_video(data)["recon_loss"] == 3 * 2 * 5 + 3 * 2 * 16
+    # evaluation (trainer.py:520-547): predicted states / masks drive the rollout, the TRUE masks score it
+    tr._config.n_eval = 3
+    tr._eval_step = lambda bd, autoreg: {"err": float(bd["states"].sum() + bd["pred_masks"].sum() + bd["masks"].sum())}
+    assert tr._eval_video(data, autoregressive=True)["err"] == 3 * 2 * 5 + 3 * 2 * 16
+    tr.robot_model = None
+    with pytest.raises(NotImplementedError):
+        tr._eval_video(data)
 
 
 def test_host_cost_paths_vs_reference(golden_dir):
