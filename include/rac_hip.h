@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 2
+#define RAC_ABI_VERSION 3
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -199,6 +199,8 @@ int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t 
 int rac_unpad_add(const float* src, int32_t Cpad, float* dst, int32_t C, int64_t R, void* stream);
 /* dst[m][0:n] = src[m][off:off+n]  (row strides Csrc / n) */
 int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t n, float* dst, int64_t M, void* stream);
+/* dst[m] = [a[m][0:Ca] | b[m][0:Cb]]  (a or b NULL: zeros) -- the gradient of the split above */
+int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, void* stream);
 /* out[c] += sum_m x[m][c]   (bias gradients) */
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream);
 
@@ -206,9 +208,10 @@ int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* strea
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
                     int64_t n, int32_t N, uint32_t* out_amax, void* stream);
 /* as rac_slab_reduce for [M][N] slabs, but columns [0,o_split) go to out0 (row stride o_split) and the rest to
- * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat */
-int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
-                     int32_t N, int32_t o_split, void* stream);
+ * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat, and of the merged
+ * mu | logvar head conv (lstm.py:273-274; n_slabs = 1 splits a finished [M][N] tensor) */
+int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out0,
+                     float* out1, int64_t M, int32_t N, int32_t o_split, void* stream);
 /* stats[c] += sum_m x[m][c]; stats[C+c] += sum_m x[m][c]^2  (fp64; BatchNorm statistics after a split-K combine) */
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, int32_t groups, void* stream);
 /* dx = dy * act'(.) expressed through the activation OUTPUT y (sigmoid: y(1-y); leaky: y>0 ? 1 : 0.2) */

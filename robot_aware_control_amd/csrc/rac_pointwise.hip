@@ -302,6 +302,17 @@ __global__ void slice_channels_kernel(const float* src, int Csrc, int off, int n
   }
 }
 
+// dst[m] = [a[m][0:Ca] | b[m][0:Cb]]; a null source contributes zeros
+__global__ void cat2_channels_kernel(const float* a, int Ca, const float* b, int Cb, float* dst, long M) {
+  const int C = Ca + Cb;
+  const long n = M * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    long m = i / C;
+    int c = (int)(i - m * C);
+    dst[i] = c < Ca ? (a ? a[m * Ca + c] : 0.f) : (b ? b[m * Cb + (c - Ca)] : 0.f);
+  }
+}
+
 // grid = (row blocks, 64-channel groups): bias gradients of the 4g-wide gate tensors have few rows (B*64) and many
 // channels, so both dimensions are needed to fill the chip.
 __global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int rows_per_block) {
@@ -367,13 +378,13 @@ __global__ void act_bwd_kernel(const float* dy, const float* y, int act, float* 
   }
 }
 
-__global__ void slab_reduce2_kernel(const float* slabs, int n_slabs, long slab_stride, float* out0, float* out1, long M,
-                                    int N, int o_split) {
+__global__ void slab_reduce2_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out0,
+                                    float* out1, long M, int N, int o_split) {
   const long n = M * N;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long m = i / N;
     int c = (int)(i - m * N);
-    float a = 0.f;
+    float a = bias ? bias[c] : 0.f;
     for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + i];
     if (c < o_split)
       out0[m * o_split + c] = a;
@@ -624,6 +635,13 @@ int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, 
   return check_launch("rac_slice_channels");
 }
 
+int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, void* stream) {
+  RAC_REQUIRE(dst && M > 0 && Ca > 0 && Cb > 0, "rac_cat2_channels: bad args");
+  hipLaunchKernelGGL(cat2_channels_kernel, dim3(grid_for((long)M * (Ca + Cb))), dim3(256), 0, ST(stream), a, Ca, b, Cb,
+                     dst, (long)M);
+  return check_launch("rac_cat2_channels");
+}
+
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(x && out && M > 0 && C > 0, "rac_colsum_acc: bad args");
   int rpb;
@@ -640,12 +658,12 @@ int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, co
   return check_launch("rac_slab_reduce");
 }
 
-int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out0, float* out1, int64_t M,
-                     int32_t N, int32_t o_split, void* stream) {
+int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out0,
+                     float* out1, int64_t M, int32_t N, int32_t o_split, void* stream) {
   RAC_REQUIRE(slabs && out0 && out1 && n_slabs >= 1 && M > 0 && N > 0 && o_split > 0 && o_split < N,
               "rac_slab_reduce2: bad args");
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, ST(stream), slabs, n_slabs,
-                     (long)slab_stride, out0, out1, (long)M, N, o_split);
+                     (long)slab_stride, bias, out0, out1, (long)M, N, o_split);
   return check_launch("rac_slab_reduce2");
 }
 

@@ -215,11 +215,19 @@ class _GaussianConvLSTM(_ConvLSTM):
         super().__init__(config, g)
         self.mu_net = _Conv(g, z, 3)
         self.logvar_net = _Conv(g, z, 3)
+        self._head = None  # (weight, bias) views over both heads, adjacent in the flat buffer (SVGConvModel._flatten)
 
     def forward(self, x, eps_fn, need_z=True):
         h = super().forward(x)
-        mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE)
-        logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE)
+        head = self._head
+        if head is not None and ops.gauss_head_ok(h.shape, head[0]):
+            for t in head:  # the views follow the parameters they alias
+                if t.requires_grad != self.mu_net.weight.requires_grad:
+                    t.requires_grad_(self.mu_net.weight.requires_grad)
+            mu, logvar = ops.GaussHead.apply(h, head[0], head[1], not torch.is_grad_enabled())
+        else:
+            mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE)
+            logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE)
         z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
         return z, mu, logvar
 
@@ -275,19 +283,37 @@ class SVGConvModel(nn.Module):
         if not params:
             return
         dev = params[0].device
-        offs, total = [], 0
-        for p in params:
-            offs.append(total)
+        # buffer order = registration order, except that the mu / logvar heads of a Gaussian LSTM lie weight next to
+        # weight and bias next to bias: stacked along Cout they are ONE conv (ops.GaussHead)
+        heads = [m for m in self.modules() if isinstance(m, _GaussianConvLSTM)]
+        paired = {id(p) for m in heads for c in (m.mu_net, m.logvar_net) for p in (c.weight, c.bias)}
+        order = [p for p in params if id(p) not in paired]
+        for m in heads:
+            order += [m.mu_net.weight, m.logvar_net.weight, m.mu_net.bias, m.logvar_net.bias]
+        total = 0
+        for p in order:
+            p._rac_off = total
             total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         grad = torch.zeros(total, device=dev, dtype=torch.float32)
         with torch.no_grad():
-            for p, o in zip(params, offs):
-                view = torch.as_strided(flat, p.shape, p.stride(), o)
+            for p in params:
+                view = torch.as_strided(flat, p.shape, p.stride(), p._rac_off)
                 view.copy_(p.data)
                 p.data = view
-                p.grad = torch.as_strided(grad, p.shape, p.stride(), o)
+                p.grad = torch.as_strided(grad, p.shape, p.stride(), p._rac_off)
         self._flat, self._flat_grad = flat, grad
+        for m in heads:
+            w0, w1, b0, b1 = m.mu_net.weight, m.logvar_net.weight, m.mu_net.bias, m.logvar_net.bias
+            m._head = None
+            if w0._rac_off + w0.numel() == w1._rac_off and b0._rac_off + b0.numel() == b1._rac_off:
+                z, g, k, _ = w0.shape
+                shape, stride = (2 * z, g, k, k), (k * k * g, 1, k * g, g)
+                wm = torch.as_strided(flat, shape, stride, w0._rac_off).requires_grad_(w0.requires_grad)
+                wm.grad = torch.as_strided(grad, shape, stride, w0._rac_off)
+                bm = torch.as_strided(flat, (2 * z,), (1,), b0._rac_off).requires_grad_(w0.requires_grad)
+                bm.grad = torch.as_strided(grad, (2 * z,), (1,), b0._rac_off)
+                m._head = (wm, bm)
         for m in self.modules():
             if isinstance(m, _VggLayer):
                 m._folded = None
@@ -305,11 +331,10 @@ class SVGConvModel(nn.Module):
         if self._flat_grad is None:
             self._flatten()
         self._flat_grad.zero_()
-        off = 0
         for p in self.parameters():
+            off = p._rac_off
             if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
                 p.grad = torch.as_strided(self._flat_grad, p.shape, p.stride(), off)
-            off += (p.numel() + 3) // 4 * 4
 
     def train(self, mode: bool = True):
         for m in self.modules():

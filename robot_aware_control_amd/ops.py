@@ -232,7 +232,7 @@ def conv_dgrad(dy, weight, C0: int, C1: int = 0, transposed_head: bool = False):
         conv_raw(DGRAD, dy, None, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, split_k=split,
                  slab_stride=M * Cin)
         if C1:
-            call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
+            call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
         else:
             call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
     else:
@@ -453,7 +453,7 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
     dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
     if C1:
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
-        call("rac_slab_reduce2", ptr(slabs), split, M * Cin, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
+        call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
         return dx0, dx1
     call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
     return dx0, None
@@ -669,6 +669,58 @@ class ConvBias(torch.autograd.Function):
         if bias is not None and bias.requires_grad:
             bias_grad_acc(dy, bias)
         return dx0, dx1, None, None, None, None
+
+
+def gauss_head_ok(h_shape, weight: torch.Tensor) -> bool:
+    """The merged mu | logvar head runs split-precision: channel counts in whole 32-chunks, a supported map size."""
+    B, H, W, g = h_shape
+    n2, ci, k, _ = weight.shape
+    return SPLIT_GEMM and ci == g and g % 32 == 0 and n2 % 32 == 0 and split_supported(H, W, k, g, n2, 0)
+
+
+class GaussHead(torch.autograd.Function):
+    """mu, logvar = Conv(h) twice (lstm.py:273-274) as ONE conv with the two weights stacked along Cout (`weight` /
+    `bias` are views over the two adjacent parameters of the flat buffer, their .grad views over the flat gradient):
+    one pass over h forward, one data gradient, one weight gradient, all on the split-precision pipe."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias, frozen=False):
+        B, H, W, g = h.shape
+        n2 = weight.shape[0]
+        z, M = n2 // 2, B * H * W
+        h = h if h.is_contiguous() else h.contiguous()
+        mu = torch.empty((B, H, W, z), device=h.device, dtype=torch.float32)
+        lv = torch.empty_like(mu)
+        k = weight.shape[2]
+        split = plan_split_k(M, n2, k * k * _cdiv(g, 32), tile128_only=True)
+        if split > 1:
+            slabs, split, stride = conv_forward_split(h, None, weight, want_slabs=True)
+            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(bias), ptr(mu), ptr(lv), M, n2, z, stream_ptr())
+        else:
+            y = conv_forward_split(h, None, weight, bias)
+            call("rac_slab_reduce2", ptr(y), 1, M * n2, None, ptr(mu), ptr(lv), M, n2, z, stream_ptr())
+        if not frozen:
+            ctx.save_for_backward(h, weight, bias)
+            ctx.amax = amax_tag(h)
+        return mu, lv
+
+    @staticmethod
+    def backward(ctx, dmu, dlv):
+        h, weight, bias = ctx.saved_tensors
+        retag(h, ctx.amax)
+        B, H, W, g = h.shape
+        z = weight.shape[0] // 2
+        dmu = None if dmu is None else dmu.contiguous()
+        dlv = None if dlv is None else dlv.contiguous()
+        dy = torch.empty((B, H, W, 2 * z), device=h.device, dtype=torch.float32)
+        call("rac_cat2_channels", ptr(dmu), z, ptr(dlv), z, ptr(dy), B * H * W, stream_ptr())
+        dh = None
+        if ctx.needs_input_grad[0]:
+            dh, _ = conv_dgrad_split(dy, weight, g, 0)
+        if weight.requires_grad:
+            conv_wgrad_split_acc(dy, h, None, weight, defer=True)
+            bias_grad_acc(dy, bias)
+        return dh, None, None, None
 
 
 class ConvTHead(torch.autograd.Function):

@@ -38,10 +38,9 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _views(self):
         m, v = self._moments()
-        off = 0
         for p in self.param_groups[0]["params"]:
+            off = p._rac_off  # the parameter's place in the model's flat buffer (SVGConvModel._flatten)
             yield p, torch.as_strided(m, p.shape, p.stride(), off), torch.as_strided(v, p.shape, p.stride(), off)
-            off += (p.numel() + 3) // 4 * 4
 
     def state_dict(self):
         if self._steps:

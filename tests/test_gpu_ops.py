@@ -383,6 +383,47 @@ def test_conv_split_precision_f16x2(dev, case):
     assert relerr(got, xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(16, 8, 8, 128, 32), (300, 8, 8, 64, 64), (3, 16, 16, 64, 16)])
+def test_gauss_head_is_one_conv(dev, case):
+    """mu / logvar heads (lstm.py:273-274) as one conv over the two adjacent parameters: outputs, data gradient,
+    weight and bias gradients (accumulated in place into the flat gradient views) against fp64."""
+    from robot_aware_control_amd import ops
+    B, H, W, g, z = case
+    w = rnd(21, 2 * z, g, 3, 3) * 0.05
+    b = rnd(22, 2 * z, scale=0.1)
+    nw = 2 * z * g * 9
+    flat, grad = torch.zeros(nw + 2 * z, device=dev), torch.zeros(nw + 2 * z, device=dev)
+    shape, stride = (2 * z, g, 3, 3), (9 * g, 1, 3 * g, g)
+    wm = torch.as_strided(flat, shape, stride, 0)
+    wm.copy_(w)
+    wm.requires_grad_(True)
+    wm.grad = torch.as_strided(grad, shape, stride, 0)
+    bm = flat[nw:]
+    bm.copy_(b)
+    bm.requires_grad_(True)
+    bm.grad = grad[nw:]
+    assert ops.gauss_head_ok((B, H, W, g), wm)
+    x = rnd(23, B, g, H, W)
+    gm, gl = rnd(24, B, z, H, W) * 1e-2, rnd(25, B, z, H, W) * 1e-3
+    h = to_map(x, dev).requires_grad_(True)
+    mu, lv = ops.GaussHead.apply(h, wm, bm)
+    ((mu * to_map(gm, dev)).sum() + (lv * to_map(gl, dev)).sum()).backward()
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y = F.conv2d(xr, wr, br, 1, 1)
+    ((y[:, :z] * gm).sum() + (y[:, z:] * gl).sum()).backward()
+    assert relerr(from_map(mu), y[:, :z]) < 2e-6 and relerr(from_map(lv), y[:, z:]) < 2e-6
+    assert relerr(from_map(h.grad), xr.grad) < 2e-6
+    assert relerr(wm.grad.cpu(), wr.grad) < 3e-6 and relerr(bm.grad.cpu(), br.grad) < 3e-6
+    # only one of the two outputs carries gradient (sample_mean / a KL-only path)
+    grad.zero_()
+    h2 = to_map(x, dev).requires_grad_(True)
+    mu, lv = ops.GaussHead.apply(h2, wm, bm)
+    (mu * to_map(gm, dev)).sum().backward()
+    xr.grad = None
+    (F.conv2d(xr, w.double(), b.double(), 1, 1)[:, :z] * gm).sum().backward()
+    assert relerr(from_map(h2.grad), xr.grad) < 2e-6 and float(wm.grad[z:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(64, 96, 3), (128, 64, 5), (32, 64, 3)])
 def test_weight_frag_split(dev, shape):
     """rac_absmax + rac_weight_frag_split == scale by 2^k, split into two fp16 parts, permute into MFMA fragment
