@@ -107,6 +107,28 @@ int rac_absmax(const float* x0, int64_t n0, const float* x1, int64_t n1, uint32_
  * Channel counts % 32 == 0; part_stride in elements. */
 int rac_weight_frag_split(const float* w, const uint32_t* w_amax, uint16_t* parts, int32_t Cout, int32_t Cin,
                           int32_t ksize, int32_t transposed, int64_t part_stride, void* stream);
+/* The two calls above for MANY tensors in one launch each (every conv weight of a model after an optimiser step).
+ * `jobs` is an array in DEVICE memory; job j owns the workgroups [block_begin_j, block_begin_{j+1}) of the launch, with
+ * block_begin the running sum of rac_absmax_blocks(n) / rac_weight_frag_blocks(Cout, Cin, ksize); total_blocks is the
+ * final sum.  Per-job requirements as for the single calls (amax slots zero or an earlier maximum on entry). */
+typedef struct rac_absmax_job {
+  const float* x;
+  int64_t n;
+  uint32_t* amax;
+  int64_t block_begin;
+} rac_absmax_job;
+typedef struct rac_frag_job {
+  const float* w;
+  const uint32_t* w_amax;
+  uint16_t* parts;
+  int64_t part_stride;
+  int32_t Cout, Cin, ksize, transposed;
+  int64_t block_begin;
+} rac_frag_job;
+int64_t rac_absmax_blocks(int64_t n);
+int64_t rac_weight_frag_blocks(int32_t Cout, int32_t Cin, int32_t ksize);
+int rac_absmax_multi(const rac_absmax_job* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
+int rac_weight_frag_split_multi(const rac_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
 /* 1 if rac_conv2d_fwd_split takes this shape: k 3 or 5, Cin % 32 == Cout % 32 == 0 (a_split % 32 == 0), and either
  * H*W <= 128 with a whole number of images per tile that is a multiple of 16 rows (8x8, 6x8 latent maps), or
  * W <= 128 with R | H image rows per tile, R*W <= 128 a multiple of 16, halo included <= 256 staged rows. */
@@ -200,9 +222,15 @@ int rac_unpad_add(const float* src, int32_t Cpad, float* dst, int32_t C, int64_t
 /* dst[m][0:n] = src[m][off:off+n]  (row strides Csrc / n) */
 int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t n, float* dst, int64_t M, void* stream);
 /* dst[m] = [a[m][0:Ca] | b[m][0:Cb]]  (a or b NULL: zeros) -- the gradient of the split above */
-int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, void* stream);
+int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, uint32_t* out_amax,
+                      void* stream);
 /* out[c] += sum_m x[m][c]   (bias gradients) */
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream);
+
+/* out[c] += sum_{t < T} sum_m xs[t][m][c]: the bias gradient of a conv applied at T time steps (T <= RAC_WGRAD_MAX_STEPS,
+ * `xs` a HOST array of T device pointers to [M][C] tensors) in one launch: rac_colsum_acc with every workgroup walking
+ * its rows in all T tensors. */
+int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, int32_t C, void* stream);
 
 /* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
@@ -211,7 +239,8 @@ int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, co
  * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat, and of the merged
  * mu | logvar head conv (lstm.py:273-274; n_slabs = 1 splits a finished [M][N] tensor) */
 int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out0,
-                     float* out1, int64_t M, int32_t N, int32_t o_split, void* stream);
+                     float* out1, int64_t M, int32_t N, int32_t o_split, uint32_t* out0_amax, uint32_t* out1_amax,
+                     void* stream);
 /* stats[c] += sum_m x[m][c]; stats[C+c] += sum_m x[m][c]^2  (fp64; BatchNorm statistics after a split-K combine) */
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, int32_t groups, void* stream);
 /* dx = dy * act'(.) expressed through the activation OUTPUT y (sigmoid: y(1-y); leaky: y>0 ? 1 : 0.2) */

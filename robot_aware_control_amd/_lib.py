@@ -33,6 +33,17 @@ class ConvArgs(C.Structure):
 WGRAD_MAX_STEPS = 16
 
 
+class AbsmaxJob(C.Structure):
+    """struct rac_absmax_job (include/rac_hip.h)."""
+    _fields_ = [("x", vp), ("n", i64), ("amax", vp), ("block_begin", i64)]
+
+
+class FragJob(C.Structure):
+    """struct rac_frag_job (include/rac_hip.h)."""
+    _fields_ = [("w", vp), ("w_amax", vp), ("parts", vp), ("part_stride", i64), ("Cout", i32), ("Cin", i32),
+                ("ksize", i32), ("transposed", i32), ("block_begin", i64)]
+
+
 class WgradArgs(C.Structure):
     """struct rac_wgrad_args (include/rac_hip.h)."""
     _fields_ = [
@@ -49,6 +60,10 @@ _SIGS = {
     "rac_conv2d": [C.POINTER(ConvArgs), vp],
     "rac_absmax": [vp, i64, vp, i64, vp, vp],
     "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
+    "rac_absmax_blocks": [i64],
+    "rac_weight_frag_blocks": [i32, i32, i32],
+    "rac_absmax_multi": [vp, i32, i64, vp],
+    "rac_weight_frag_split_multi": [vp, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
@@ -67,8 +82,9 @@ _SIGS = {
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
     "rac_colsum_acc": [vp, vp, i64, i32, vp],
     "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp, vp],
-    "rac_slab_reduce2": [vp, i32, i64, vp, vp, vp, i64, i32, i32, vp],
-    "rac_cat2_channels": [vp, i32, vp, i32, vp, i64, vp],
+    "rac_slab_reduce2": [vp, i32, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp],
+    "rac_cat2_channels": [vp, i32, vp, i32, vp, i64, vp, vp],
+    "rac_colsum_steps": [C.POINTER(vp), i32, vp, i64, i32, vp],
     "rac_col_stats": [vp, vp, i64, i32, i32, vp],
     "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
@@ -97,7 +113,8 @@ _SIGS = {
     "rac_device_arch": [],
     "rac_last_error": [],
 }
-_RET = {"rac_device_arch": C.c_char_p, "rac_last_error": C.c_char_p}
+_RET = {"rac_device_arch": C.c_char_p, "rac_last_error": C.c_char_p, "rac_absmax_blocks": i64,
+        "rac_weight_frag_blocks": i64}
 EXPORTS = tuple(_SIGS)
 
 _lib = None

@@ -303,14 +303,43 @@ __global__ void slice_channels_kernel(const float* src, int Csrc, int off, int n
 }
 
 // dst[m] = [a[m][0:Ca] | b[m][0:Cb]]; a null source contributes zeros
-__global__ void cat2_channels_kernel(const float* a, int Ca, const float* b, int Cb, float* dst, long M) {
+__global__ void cat2_channels_kernel(const float* a, int Ca, const float* b, int Cb, float* dst, long M,
+                                     unsigned* amax) {
   const int C = Ca + Cb;
   const long n = M * C;
+  unsigned mx = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long m = i / C;
     int c = (int)(i - m * C);
-    dst[i] = c < Ca ? (a ? a[m * Ca + c] : 0.f) : (b ? b[m * Cb + (c - Ca)] : 0.f);
+    const float v = c < Ca ? (a ? a[m * Ca + c] : 0.f) : (b ? b[m * Cb + (c - Ca)] : 0.f);
+    mx = max(mx, absbits(v));
+    dst[i] = v;
   }
+  if (amax) amax_commit_block(mx, amax);
+}
+
+// Bias gradient of a conv applied at T time steps in ONE launch: colsum_acc_kernel below with every workgroup walking
+// its row range in all T tensors (T times fewer atomics than T launches).
+struct ColsumSteps {
+  const float* x[RAC_WGRAD_MAX_STEPS];
+  int T;
+};
+__global__ void colsum_steps_kernel(ColsumSteps p, float* out, long M, int C, int rows_per_block) {
+  __shared__ float s1[256];
+  const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;  // 4 row lanes
+  const long r_begin = (long)blockIdx.x * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, M);
+  float a = 0.f;
+  if (c < C)
+    for (int t = 0; t < p.T; ++t) {
+      const float* x = p.x[t];
+      for (long r = r_begin + rl; r < r_end; r += 4) a += x[r * C + c];
+    }
+  s1[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C) atomicAdd(out + c, (s1[threadIdx.x] + s1[threadIdx.x + 64]) +
+                                                        (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]));
 }
 
 // grid = (row blocks, 64-channel groups): bias gradients of the 4g-wide gate tensors have few rows (B*64) and many
@@ -340,6 +369,44 @@ __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_st
     out[i] = a;
   }
   if (amax) amax_commit_block(mx, amax);
+}
+
+// 16-byte forms of the two combines (N, o_split, slab_stride multiples of 4; 16-byte aligned pointers)
+__global__ void slab_reduce_kernel4(const f32x4* slabs, int n_slabs, long slab_stride4, const f32x4* bias, f32x4* out,
+                                    long n4, int N4, unsigned* amax) {
+  unsigned mx = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    f32x4 a = bias ? bias[i % N4] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride4 + i];
+    mx = max(max(mx, max(absbits(a.x), absbits(a.y))), max(absbits(a.z), absbits(a.w)));
+    out[i] = a;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
+__global__ void slab_reduce2_kernel4(const f32x4* slabs, int n_slabs, long slab_stride4, const f32x4* bias, f32x4* out0,
+                                     f32x4* out1, long M, int N4, int o_split4, unsigned* amax0, unsigned* amax1) {
+  const long n4 = M * N4;
+  unsigned mx0 = 0, mx1 = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    long m = i / N4;
+    int c = (int)(i - m * N4);
+    f32x4 a = bias ? bias[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride4 + i];
+    const unsigned mv = max(max(absbits(a.x), absbits(a.y)), max(absbits(a.z), absbits(a.w)));
+    if (c < o_split4) {
+      out0[m * o_split4 + c] = a;
+      mx0 = max(mx0, mv);
+    } else {
+      out1[m * (N4 - o_split4) + (c - o_split4)] = a;
+      mx1 = max(mx1, mv);
+    }
+  }
+  if (amax0) amax_commit_block(mx0, amax0);
+  if (amax1) {
+    __syncthreads();
+    amax_commit_block(mx1, amax1);
+  }
 }
 
 __global__ void col_stats_kernel(const float* x, double* stats, long Mg, int C, int rows_per_block, int bpg) {
@@ -379,17 +446,26 @@ __global__ void act_bwd_kernel(const float* dy, const float* y, int act, float* 
 }
 
 __global__ void slab_reduce2_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out0,
-                                    float* out1, long M, int N, int o_split) {
+                                    float* out1, long M, int N, int o_split, unsigned* amax0, unsigned* amax1) {
   const long n = M * N;
+  unsigned mx0 = 0, mx1 = 0;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     long m = i / N;
     int c = (int)(i - m * N);
     float a = bias ? bias[c] : 0.f;
     for (int s = 0; s < n_slabs; ++s) a += slabs[s * slab_stride + i];
-    if (c < o_split)
+    if (c < o_split) {
       out0[m * o_split + c] = a;
-    else
+      mx0 = max(mx0, absbits(a));
+    } else {
       out1[m * (N - o_split) + (c - o_split)] = a;
+      mx1 = max(mx1, absbits(a));
+    }
+  }
+  if (amax0) amax_commit_block(mx0, amax0);
+  if (amax1) {
+    __syncthreads();
+    amax_commit_block(mx1, amax1);
   }
 }
 
@@ -635,11 +711,26 @@ int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t nc, 
   return check_launch("rac_slice_channels");
 }
 
-int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, void* stream) {
+int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, uint32_t* out_amax,
+                      void* stream) {
   RAC_REQUIRE(dst && M > 0 && Ca > 0 && Cb > 0, "rac_cat2_channels: bad args");
-  hipLaunchKernelGGL(cat2_channels_kernel, dim3(grid_for((long)M * (Ca + Cb))), dim3(256), 0, ST(stream), a, Ca, b, Cb,
-                     dst, (long)M);
+  hipLaunchKernelGGL(cat2_channels_kernel, dim3(grid_for_amax((long)M * (Ca + Cb), out_amax)), dim3(256), 0, ST(stream),
+                     a, Ca, b, Cb, dst, (long)M, out_amax);
   return check_launch("rac_cat2_channels");
+}
+
+int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, int32_t C, void* stream) {
+  RAC_REQUIRE(xs && out && T >= 1 && T <= RAC_WGRAD_MAX_STEPS && M > 0 && C > 0, "rac_colsum_steps: bad args");
+  ColsumSteps p{};
+  p.T = T;
+  for (int t = 0; t < T; ++t) {
+    RAC_REQUIRE(xs[t], "rac_colsum_steps: null step");
+    p.x[t] = xs[t];
+  }
+  int rpb;
+  dim3 grid = reduce_grid(M, C, &rpb);
+  hipLaunchKernelGGL(colsum_steps_kernel, grid, dim3(256), 0, ST(stream), p, out, (long)M, C, rpb);
+  return check_launch("rac_colsum_steps");
 }
 
 int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
@@ -653,17 +744,32 @@ int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* strea
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
                     int64_t n, int32_t N, uint32_t* out_amax, void* stream) {
   RAC_REQUIRE(slabs && out && n_slabs >= 1 && n > 0 && N > 0, "rac_slab_reduce: bad args");
+  if (n % 4 == 0 && N % 4 == 0 && slab_stride % 4 == 0 && aligned16(slabs) && aligned16(out) && (!bias || aligned16(bias))) {
+    hipLaunchKernelGGL(slab_reduce_kernel4, dim3(grid_for_amax(n / 4, out_amax)), dim3(256), 0, ST(stream),
+                       (const f32x4*)slabs, n_slabs, (long)(slab_stride / 4), (const f32x4*)bias, (f32x4*)out, (long)(n / 4),
+                       N / 4, out_amax);
+    return check_launch("rac_slab_reduce");
+  }
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for_amax(n, out_amax)), dim3(256), 0, ST(stream), slabs, n_slabs,
                      (long)slab_stride, bias, out, (long)n, N, out_amax);
   return check_launch("rac_slab_reduce");
 }
 
 int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out0,
-                     float* out1, int64_t M, int32_t N, int32_t o_split, void* stream) {
+                     float* out1, int64_t M, int32_t N, int32_t o_split, uint32_t* out0_amax, uint32_t* out1_amax,
+                     void* stream) {
   RAC_REQUIRE(slabs && out0 && out1 && n_slabs >= 1 && M > 0 && N > 0 && o_split > 0 && o_split < N,
               "rac_slab_reduce2: bad args");
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(grid_for((long)M * N)), dim3(256), 0, ST(stream), slabs, n_slabs,
-                     (long)slab_stride, bias, out0, out1, (long)M, N, o_split);
+  if (N % 4 == 0 && o_split % 4 == 0 && slab_stride % 4 == 0 && aligned16(slabs) && aligned16(out0) && aligned16(out1) &&
+      (!bias || aligned16(bias))) {
+    hipLaunchKernelGGL(slab_reduce2_kernel4, dim3(grid_for_amax((long)M * N / 4, out0_amax ? out0_amax : out1_amax)),
+                       dim3(256), 0, ST(stream), (const f32x4*)slabs, n_slabs, (long)(slab_stride / 4), (const f32x4*)bias,
+                       (f32x4*)out0, (f32x4*)out1, (long)M, N / 4, o_split / 4, out0_amax, out1_amax);
+    return check_launch("rac_slab_reduce2");
+  }
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(grid_for_amax((long)M * N, out0_amax ? out0_amax : out1_amax)), dim3(256),
+                     0, ST(stream), slabs, n_slabs, (long)slab_stride, bias, out0, out1, (long)M, N, o_split, out0_amax,
+                     out1_amax);
   return check_launch("rac_slab_reduce2");
 }
 

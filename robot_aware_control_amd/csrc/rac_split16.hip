@@ -635,11 +635,11 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float4* x0, long n0v,
 //   k = 32 chunk + 8 q + j
 // forward:    rows r = co, k = ci, value w[r][tap][k]
 // transposed: rows r = ci, k = co, value w[k][taps-1-tap][r]   (the conv that IS the data gradient)
-__global__ void weight_frag16_kernel(const float* w, const unsigned* w_amax, unsigned short* out, int Cout, int Cin,
-                                     int taps, int transposed, long ps) {
+__device__ __forceinline__ void weight_frag16_block(const float* w, const unsigned* w_amax, unsigned short* out, int Cout,
+                                                    int Cin, int taps, int transposed, long ps, long block) {
   const int R = transposed ? Cin : Cout, Kc = transposed ? Cout : Cin;
   const int cch = Kc >> 5;
-  const long cell = (long)blockIdx.x * 2 + (threadIdx.x >> 7);  // ((nt * cch + cc) * taps + tap)
+  const long cell = block * 2 + (threadIdx.x >> 7);  // ((nt * cch + cc) * taps + tap)
   if (cell >= (long)(R >> 5) * cch * taps) return;
   const float s = pow2f(scale_exp(*w_amax));
   const int tap = (int)(cell % taps);
@@ -664,6 +664,52 @@ __global__ void weight_frag16_kernel(const float* w, const unsigned* w_amax, uns
   const long o = (cell * 2 + nb) * 512 + lane * 8;
   *reinterpret_cast<u32x4*>(out + o) = q[0];
   *reinterpret_cast<u32x4*>(out + ps + o) = q[1];
+}
+
+__global__ void weight_frag16_kernel(const float* w, const unsigned* w_amax, unsigned short* out, int Cout, int Cin,
+                                     int taps, int transposed, long ps) {
+  weight_frag16_block(w, w_amax, out, Cout, Cin, taps, transposed, ps, blockIdx.x);
+}
+
+// Many tensors in one launch (every conv weight of a model after an optimiser step): job j owns the workgroups
+// [block_begin_j, block_begin_{j+1}); the job table lives in device memory.
+template <typename Job>
+__device__ __forceinline__ int job_of_block(const Job* jobs, int n_jobs, long block) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_begin <= block) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ void weight_frag16_multi_kernel(const rac_frag_job* jobs, int n_jobs) {
+  const int j = job_of_block(jobs, n_jobs, blockIdx.x);
+  const rac_frag_job q = jobs[j];
+  weight_frag16_block(q.w, q.w_amax, q.parts, q.Cout, q.Cin, q.ksize * q.ksize, q.transposed, q.part_stride,
+                      blockIdx.x - q.block_begin);
+}
+
+__global__ __launch_bounds__(256) void absmax_multi_kernel(const rac_absmax_job* jobs, int n_jobs) {
+  __shared__ unsigned sh[4];
+  const int j = job_of_block(jobs, n_jobs, blockIdx.x);
+  const rac_absmax_job q = jobs[j];
+  const long nb = (j + 1 < n_jobs ? jobs[j + 1].block_begin : (long)gridDim.x) - q.block_begin;
+  const float4* x = reinterpret_cast<const float4*>(q.x);
+  const long nv = q.n >> 2;
+  unsigned m = 0;
+  for (long i = (blockIdx.x - q.block_begin) * 256 + threadIdx.x; i < nv; i += nb * 256) {
+    const float4 v = x[i];
+    m = max(m, max(max(absbits(v.x), absbits(v.y)), max(absbits(v.z), absbits(v.w))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+    if (m > __hip_atomic_load(q.amax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q.amax, m);
+  }
 }
 
 
@@ -925,6 +971,30 @@ extern "C" int rac_weight_frag_split(const float* w, const uint32_t* w_amax, uin
                      reinterpret_cast<hipStream_t>(stream), w, w_amax, parts, Cout, Cin, ksize * ksize, transposed,
                      (long)part_stride);
   return check_launch("rac_weight_frag_split");
+}
+
+extern "C" int64_t rac_absmax_blocks(int64_t n) {
+  long nb = (n / 4 + 1023) / 1024;
+  return nb < 1 ? 1 : (nb > 512 ? 512 : nb);
+}
+
+extern "C" int64_t rac_weight_frag_blocks(int32_t Cout, int32_t Cin, int32_t ksize) {
+  return ((long)Cout * Cin * ksize * ksize / 1024 + 1) / 2;
+}
+
+extern "C" int rac_absmax_multi(const rac_absmax_job* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {
+  RAC_REQUIRE(jobs && n_jobs > 0 && total_blocks >= n_jobs && total_blocks < 0x7FFFFFFFL, "rac_absmax_multi: bad args");
+  hipLaunchKernelGGL(absmax_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), jobs, n_jobs);
+  return check_launch("rac_absmax_multi");
+}
+
+extern "C" int rac_weight_frag_split_multi(const rac_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {
+  RAC_REQUIRE(jobs && n_jobs > 0 && total_blocks >= n_jobs && total_blocks < 0x7FFFFFFFL,
+              "rac_weight_frag_split_multi: bad args");
+  hipLaunchKernelGGL(weight_frag16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), jobs, n_jobs);
+  return check_launch("rac_weight_frag_split_multi");
 }
 
 // image rows per tile of conv16_rows_kernel: R | H, R * W <= 128 and a multiple of 16 (0: none)

@@ -188,18 +188,20 @@ class _ConvLSTM(nn.Module):
         self.batch_size = config.batch_size
         self._hw = (config.image_height // 8, config.image_width // 8)
         self.hidden = None
+        self._zero_state = None
 
     def init_hidden(self, batch_size=None):
         b = self.batch_size if batch_size is None else batch_size
         dev = next(self.parameters()).device
         h, w = self._hw
-        one = ops.amax_one(dev)
-        out = []
-        for _ in self.lstm:
-            h0 = ops.tag_amax(torch.zeros(b, h, w, self.hid_ch, device=dev), one)
-            h0._rac_zero = True  # the first step's gate conv skips the hidden half of K (ops.is_zero)
-            out.append((h0, torch.zeros(b, h, w, self.hid_ch, device=dev)))
-        return out
+        key = (b, h, w, self.hid_ch, dev)
+        if self._zero_state is None or self._zero_state[0] != key:
+            # the initial state is only ever read: one zero map serves every layer, h and c, and every later call
+            z0 = ops.tag_amax(torch.zeros(b, h, w, self.hid_ch, device=dev), ops.amax_one(dev))
+            z0._rac_zero = True  # the first step's gate conv skips the hidden half of K (ops.is_zero)
+            self._zero_state = (key, z0)
+        z0 = self._zero_state[1]
+        return [(z0, z0) for _ in self.lstm]
 
     def forward(self, x):
         for i, cell in enumerate(self.lstm):

@@ -19,13 +19,15 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import functools
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
 
 from . import _lib
-from ._lib import ConvArgs, WgradArgs, call, ptr, stream_ptr
+from ._lib import AbsmaxJob, ConvArgs, FragJob, WgradArgs, call, ptr, stream_ptr
 
 FWD, DGRAD, WGRAD = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
@@ -86,7 +88,12 @@ def padded_weight(weight: torch.Tensor, cp: Optional[int] = None) -> torch.Tenso
     cp = ci + pad4(ci) if cp is None else cp
 
     def build():
-        wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
+        # the copy keeps its buffer (and its identity: the split-precision parts registry keys on the object)
+        wp = getattr(weight, f"_rac_padbuf{cp}", None)
+        if wp is None or wp.device != weight.device:
+            wp = torch.empty((co, k, k, cp), device=weight.device, dtype=torch.float32).permute(0, 3, 1, 2)
+            setattr(weight, f"_rac_padbuf{cp}", wp)
+            wp._rac_pad_source = (weakref.ref(weight), cp)
         call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
         return wp
     return _derived(weight, f"_rac_padded{cp}", build)
@@ -232,7 +239,8 @@ def conv_dgrad(dy, weight, C0: int, C1: int = 0, transposed_head: bool = False):
         conv_raw(DGRAD, dy, None, weight, slabs, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, split_k=split,
                  slab_stride=M * Cin)
         if C1:
-            call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
+            call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, None, None,
+                 stream_ptr())
         else:
             call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
     else:
@@ -252,8 +260,32 @@ def conv_wgrad_acc(dy, x0, x1, weight):
 
 
 def bias_grad_acc(dy, bias):
+    """bias.grad += column sums of dy.  Inside `deferred_wgrad()` the few-row tensors of the recurrent part are only
+    recorded: one launch per bias sums all its time steps when the context exits."""
     M = dy.numel() // dy.shape[-1]
+    if _DEFERRED is not None and M <= _COLSUM_STEPS_MAX_ROWS:
+        _DEFERRED_BIAS.setdefault(id(bias), (bias, []))[1].append(dy)
+        return
     call("rac_colsum_acc", ptr(dy), ptr(grad_buffer(bias)), M, dy.shape[-1], stream_ptr())
+
+
+_COLSUM_STEPS_MAX_ROWS = 16384
+_DEFERRED_BIAS = {}
+
+
+def _flush_bias_grads():
+    pending = dict(_DEFERRED_BIAS)
+    _DEFERRED_BIAS.clear()
+    sp = stream_ptr()
+    for bias, dys in pending.values():
+        g = grad_buffer(bias)
+        Cc = dys[0].shape[-1]
+        M = dys[0].numel() // Cc
+        for lo in range(0, len(dys), _lib.WGRAD_MAX_STEPS):
+            chunk = dys[lo:lo + _lib.WGRAD_MAX_STEPS]
+            assert all(d.shape == dys[0].shape and d.is_contiguous() for d in chunk)
+            xs = (C.c_void_p * len(chunk))(*[ptr(d) for d in chunk])
+            call("rac_colsum_steps", xs, len(chunk), ptr(g), M, Cc, sp)
 
 
 # --------------------------------------------------------------------------- #
@@ -343,25 +375,132 @@ def split_supported(H: int, W: int, k: int, Cin: int, Cout: int, a_split: int = 
     return ok
 
 
-def weight_parts(weight: torch.Tensor, transposed: bool = False):
-    """(fp16 parts of weight * 2^k in MFMA fragment order, amax slot), cached on the parameter until it changes;
-    `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient."""
-    def amax():
-        slot = torch.zeros(1, device=weight.device, dtype=torch.int32)
-        w = weight_mem(weight.detach())
-        call("rac_absmax", ptr(w), w.numel(), None, 0, ptr(slot), stream_ptr())
-        return slot
+# Split-precision weight operands.  Every conv weight that runs on the fp16 pipe is registered here with its amax slot
+# and its fragment-order parts (forward and / or transposed); after an optimiser step ALL of them are stale at once and
+# are refreshed by three launches (zero the slots, rac_absmax_multi, rac_weight_frag_split_multi) instead of three per
+# weight and direction.  A weight that goes stale on its own (a new registration) takes the single-tensor calls.
+class _WeightParts:
+    __slots__ = ("ref", "idx", "slot", "device", "parts", "tag", "__weakref__")
 
-    def build():
+
+_WP_ENTRIES = {}  # id(weight) -> _WeightParts
+_WP_DEV = {}      # device -> {"slots", "free", "sig", "tables"}
+_WP_NSLOTS = 1024
+
+
+def _wp_state(device):
+    st = _WP_DEV.get(device)
+    if st is None:
+        st = _WP_DEV[device] = {"slots": torch.zeros(_WP_NSLOTS, device=device, dtype=torch.int32),
+                                "free": list(range(_WP_NSLOTS - 1, -1, -1)), "sig": None, "tables": None}
+    return st
+
+
+def _wp_drop(key, device, idx, _ref):
+    ent = _WP_ENTRIES.get(key)
+    if ent is not None and ent.idx == idx and ent.device == device:
+        del _WP_ENTRIES[key]
+        st = _WP_DEV.get(device)
+        if st is not None:
+            st["free"].append(idx)
+
+
+def _wp_tag(weight):
+    return (weight._version, PARAM_EPOCH, weight.data_ptr())
+
+
+def _wp_upload(jobs, device):
+    raw = bytes(jobs)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+
+
+def _wp_refresh(device):
+    """Bring every registered weight of `device` whose parameter changed up to date."""
+    st = _wp_state(device)
+    stale, n_live = [], 0
+    for ent in list(_WP_ENTRIES.values()):
+        if ent.device != device:
+            continue
+        w = ent.ref()
+        if w is None:
+            continue
+        src = getattr(w, "_rac_pad_source", None)
+        if src is not None:  # a zero-padded copy of a parameter: rebuild the copy first
+            param = src[0]()
+            if param is None:
+                continue
+            padded_weight(param, src[1])
+        n_live += 1
+        if ent.tag != _wp_tag(w):
+            stale.append((ent, w))
+    if not stale:
+        return
+    sp = stream_ptr()
+    lib = _lib.load()
+    if len(stale) < n_live or len(stale) <= 2:  # new registrations: the single-tensor calls
+        for ent, w in stale:
+            ent.slot.zero_()
+            wm = weight_mem(w.detach())
+            co, ci, k, _ = w.shape
+            call("rac_absmax", ptr(wm), wm.numel(), None, 0, ptr(ent.slot), sp)
+            for transposed, parts in ent.parts.items():
+                call("rac_weight_frag_split", ptr(wm), ptr(ent.slot), ptr(parts), co, ci, k, 1 if transposed else 0,
+                     wm.numel(), sp)
+            ent.tag = _wp_tag(w)
+        return
+    sig = tuple((w.data_ptr(), ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items())))
+                for ent, w in stale)
+    if st["sig"] != sig:  # job tables (device memory) for this set of weights
+        ajobs = (AbsmaxJob * len(stale))()
+        nfrag = sum(len(ent.parts) for ent, _ in stale)
+        fjobs = (FragJob * nfrag)()
+        ab = fb = j = 0
+        for i, (ent, w) in enumerate(stale):
+            wm = weight_mem(w.detach())
+            co, ci, k, _ = w.shape
+            ajobs[i] = AbsmaxJob(x=ptr(wm), n=wm.numel(), amax=ptr(ent.slot), block_begin=ab)
+            ab += lib.rac_absmax_blocks(wm.numel())
+            for transposed, parts in sorted(ent.parts.items()):
+                fjobs[j] = FragJob(w=ptr(wm), w_amax=ptr(ent.slot), parts=ptr(parts), part_stride=wm.numel(), Cout=co,
+                                   Cin=ci, ksize=k, transposed=1 if transposed else 0, block_begin=fb)
+                fb += lib.rac_weight_frag_blocks(co, ci, k)
+                j += 1
+        st["tables"] = (_wp_upload(ajobs, device), len(stale), ab, _wp_upload(fjobs, device), nfrag, fb)
+        st["sig"] = sig
+    ta, na, ab, tf, nf, fb = st["tables"]
+    st["slots"].zero_()  # every live slot is recomputed
+    call("rac_absmax_multi", ptr(ta), na, ab, sp)
+    call("rac_weight_frag_split_multi", ptr(tf), nf, fb, sp)
+    for ent, w in stale:
+        ent.tag = _wp_tag(w)
+
+
+def weight_parts(weight: torch.Tensor, transposed: bool = False):
+    """(fp16 parts of weight * 2^k in MFMA fragment order, amax slot), kept until the parameter changes;
+    `transposed`: of the (Cin, Cout) tap-flipped weight whose forward conv is the data gradient."""
+    key = id(weight)
+    ent = _WP_ENTRIES.get(key)
+    if ent is None or ent.ref() is not weight or ent.device != weight.device:
+        st = _wp_state(weight.device)
+        if not st["free"]:
+            raise _lib.RacError("too many conv weights registered for the split-precision pipe")
         co, ci, k, _ = weight.shape
-        w = weight_mem(weight.detach())
-        slot = _derived(weight, "_rac_amax_w", amax)
-        n = w.numel()
-        parts = torch.empty((2, n), device=w.device, dtype=torch.float16)
-        call("rac_weight_frag_split", ptr(w), ptr(slot), ptr(parts), co, ci, k, 1 if transposed else 0, n, stream_ptr())
+        if co % 32 or ci % 32:
+            raise _lib.RacError(f"split-precision weight {tuple(weight.shape)}: channel counts must be multiples of 32")
+        ent = _WeightParts()
+        ent.idx = st["free"].pop()
+        ent.device, ent.parts, ent.tag = weight.device, {}, None
+        ent.slot = st["slots"][ent.idx:ent.idx + 1]
+        ent.ref = weakref.ref(weight, functools.partial(_wp_drop, key, weight.device, ent.idx))
+        _WP_ENTRIES[key] = ent
+    if transposed not in ent.parts:
+        parts = torch.empty((2, weight.numel()), device=weight.device, dtype=torch.float16)
         parts._rac_transposed = transposed
-        return parts, slot
-    return _derived(weight, "_rac_parts_t" if transposed else "_rac_parts", build)
+        ent.parts[transposed] = parts
+        ent.tag = None
+    if ent.tag != _wp_tag(weight):
+        _wp_refresh(weight.device)
+    return ent.parts[transposed], ent.slot
 
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
@@ -451,12 +590,15 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
     _split_launch(dy, None, amax_for(dy), None, pw, wslot, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout,
                   split_k=split, slab_stride=M * Cin)
     dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
+    s0 = amax_slot(dy.device)  # the combine leaves max |dx| for the conv that consumes the gradient
     if C1:
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
-        call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, stream_ptr())
-        return dx0, dx1
-    call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, None, stream_ptr())
-    return dx0, None
+        s1 = amax_slot(dy.device)
+        call("rac_slab_reduce2", ptr(slabs), split, M * Cin, None, ptr(dx0), ptr(dx1), M, Cin, C0, ptr(s0), ptr(s1),
+             stream_ptr())
+        return tag_amax(dx0, s0), tag_amax(dx1, s1)
+    call("rac_slab_reduce", ptr(slabs), split, M * Cin, None, ptr(dx0), M * Cin, Cin, ptr(s0), stream_ptr())
+    return tag_amax(dx0, s0), None
 
 
 # Deferred, time-batched weight gradients: inside `deferred_wgrad()` the split-precision wgrad of a weight that is
@@ -485,8 +627,10 @@ def deferred_wgrad(on_ready=None):
             _wgrad_split_batch(items, weight)
             if on_ready is not None:
                 on_ready(weight)
+        _flush_bias_grads()
     finally:
         _DEFERRED = None
+        _DEFERRED_BIAS.clear()
 
 
 def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
@@ -541,7 +685,7 @@ def _wgrad_split_batch(items, weight):
     sp = stream_ptr()
     dev = dy.device
     if Cin != ci_real:
-        g = torch.zeros((Cout, k, k, Cin), device=dev, dtype=torch.float32)
+        g = torch.empty((Cout, k, k, Cin), device=dev, dtype=torch.float32)  # the first launch writes (accumulate 0)
     else:
         g = weight_mem(grad_buffer(weight))
     n = Cout * k * k * Cin
@@ -552,7 +696,8 @@ def _wgrad_split_batch(items, weight):
         T = len(chunk)
         ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
-        a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns, accumulate=1,
+        a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
+                      accumulate=0 if (Cin != ci_real and lo == 0) else 1,
                       dw=ptr(g), slabs=ptr(slabs), slab_stride=n)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
             assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
@@ -695,10 +840,11 @@ class GaussHead(torch.autograd.Function):
         split = plan_split_k(M, n2, k * k * _cdiv(g, 32), tile128_only=True)
         if split > 1:
             slabs, split, stride = conv_forward_split(h, None, weight, want_slabs=True)
-            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(bias), ptr(mu), ptr(lv), M, n2, z, stream_ptr())
+            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(bias), ptr(mu), ptr(lv), M, n2, z, None, None,
+                 stream_ptr())
         else:
             y = conv_forward_split(h, None, weight, bias)
-            call("rac_slab_reduce2", ptr(y), 1, M * n2, None, ptr(mu), ptr(lv), M, n2, z, stream_ptr())
+            call("rac_slab_reduce2", ptr(y), 1, M * n2, None, ptr(mu), ptr(lv), M, n2, z, None, None, stream_ptr())
         if not frozen:
             ctx.save_for_backward(h, weight, bias)
             ctx.amax = amax_tag(h)
@@ -713,7 +859,9 @@ class GaussHead(torch.autograd.Function):
         dmu = None if dmu is None else dmu.contiguous()
         dlv = None if dlv is None else dlv.contiguous()
         dy = torch.empty((B, H, W, 2 * z), device=h.device, dtype=torch.float32)
-        call("rac_cat2_channels", ptr(dmu), z, ptr(dlv), z, ptr(dy), B * H * W, stream_ptr())
+        slot = amax_slot(h.device)
+        call("rac_cat2_channels", ptr(dmu), z, ptr(dlv), z, ptr(dy), B * H * W, ptr(slot), stream_ptr())
+        tag_amax(dy, slot)
         dh = None
         if ctx.needs_input_grad[0]:
             dh, _ = conv_dgrad_split(dy, weight, g, 0)

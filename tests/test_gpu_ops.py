@@ -447,6 +447,38 @@ def test_weight_frag_split(dev, shape):
     assert int(s2.cpu()) == int(torch.maximum(a.abs().max(), b.abs().max()).cpu().view(torch.int32))
 
 
+def test_weight_parts_refreshed_in_one_launch(dev):
+    """After an optimiser step (ops.PARAM_EPOCH) every registered weight is refreshed by one rac_absmax_multi + one
+    rac_weight_frag_split_multi launch: same parts and maxima as the single-tensor calls."""
+    from robot_aware_control_amd import ops
+    shapes = [(64, 96, 3, True), (128, 64, 5, False), (32, 64, 3, True), (256, 512, 5, True), (96, 32, 3, False)]
+    ws = [cl_weight(rnd(30 + i, co, ci, k, k) * 0.02).to(dev) for i, (co, ci, k, _) in enumerate(shapes)]
+    for w, (_, _, _, both) in zip(ws, shapes):  # registration: the single-tensor path
+        ops.weight_parts(w)
+        if both:
+            ops.weight_parts(w, transposed=True)
+    for i, w in enumerate(ws):  # "optimiser step": new values behind torch's version counters
+        w.copy_(cl_weight(rnd(40 + i, *w.shape) * (0.5 + i)).to(dev))
+    ops.PARAM_EPOCH += 1
+    calls = []
+    real = ops.call
+    ops.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+    try:
+        got = [(ops.weight_parts(w), ops.weight_parts(w, transposed=True) if both else None)
+               for w, (_, _, _, both) in zip(ws, shapes)]
+    finally:
+        ops.call = real
+    assert calls == ["rac_absmax_multi", "rac_weight_frag_split_multi"], calls
+    for w, ((parts, slot), tr) in zip(ws, got):
+        h1, h2, _ = split_f16x2(w.cpu())
+        assert int(slot.cpu()) == int(w.abs().max().cpu().view(torch.int32))
+        assert torch.equal(parts[0].cpu(), frag_order16(h1).flatten()) and torch.equal(parts[1].cpu(), frag_order16(h2).flatten())
+        if tr is not None:
+            wt = w.detach().permute(1, 0, 2, 3).flip(2, 3).contiguous(memory_format=torch.channels_last)
+            t1, t2, _ = split_f16x2(wt.cpu())
+            assert torch.equal(tr[0][0].cpu(), frag_order16(t1).flatten()) and torch.equal(tr[0][1].cpu(), frag_order16(t2).flatten())
+
+
 @pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 96, 3), (1, 32, 32, 64, 0, 128, 3), (3, 16, 16, 32, 0, 64, 5),
                                   (1, 16, 32, 32, 32, 160, 3), (2, 4, 64, 32, 0, 64, 3), (1, 64, 64, 64, 64, 64, 3),
                                   (2, 12, 16, 64, 0, 96, 3), (1, 24, 32, 32, 32, 64, 3)])

@@ -20,11 +20,14 @@ SKIP = ("aten.empty", "aten.view", "aten.as_strided", "aten.permute", "aten.resh
         "aten.lift_fresh", "aten.set_", "aten.record_stream", "aten._local_scalar", "aten.new_empty", "aten.chunk")
 
 
-def site():
+def site(depth=3):
+    out = []
     for fr in reversed(traceback.extract_stack()[:-2]):
         if fr.filename.startswith(ROOT) and "launch_census" not in fr.filename and not fr.filename.endswith("_lib.py"):
-            return f"{os.path.relpath(fr.filename, ROOT)}:{fr.lineno} {fr.name}"
-    return "autograd engine / other"
+            out.append(f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}")
+            if len(out) == depth:
+                break
+    return " <- ".join(out) if out else "autograd engine / other"
 
 
 class Census(TorchDispatchMode):
@@ -62,6 +65,19 @@ def main():
     with census:
         tr._train_step(data)
     torch.cuda.synchronize()
+    if os.environ.get("CENSUS_MEMCPY"):  # who issues the device-side copies (hipMemcpyAsync blit kernels)?
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            tr._train_step(data)
+            torch.cuda.synchronize()
+        seen = collections.Counter()
+        for ev in prof.events():
+            for k in getattr(ev, "kernels", []) or []:
+                if "copy" in k.name.lower() or "memcpy" in k.name.lower() or "fill" in k.name.lower():
+                    st = [f for f in (ev.stack or []) if "robot_aware_control_amd" in f or "bench" in f][:3]
+                    seen[(k.name[:40], ev.name, " <- ".join(st))] += 1
+        for (kn, en, st), c in seen.most_common(40):
+            print(f"{c:4d}  {kn:40s}  {en:30s}  {st}")
     lines = ["# launch census, one cfg2 train step", "", "## rac_* calls", "", "| calls | entry | site |", "|---|---|---|"]
     by_name = collections.Counter()
     for (n, s), c in rac.items():
