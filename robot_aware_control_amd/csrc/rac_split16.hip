@@ -105,18 +105,92 @@ struct Conv16P {
 // wave-uniform byte offset.
 constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
 
-__device__ __forceinline__ float conv16_epilogue_store(const Conv16P& p, float v, float bias, float sc, float sh,
-                                                       float& s1, float& s2, long idx) {
-  v += bias;
-  s1 += v;
-  s2 += v * v;
-  v = v * sc + sh;
-  if (p.act == RAC_ACT_LEAKY02)
-    v = v > 0.f ? v : 0.2f * v;
-  else if (p.act == RAC_ACT_SIGMOID)
-    v = sigmoid_acc(v);
-  p.out0[idx] = v;
-  return v;
+// Epilogue of both kernels: undo the two operand scales, then as rac_conv2d FWD (bias, fp64 BatchNorm statistics of the
+// biased value, folded eval-BatchNorm scale / shift, activation, max |v|) -- or the raw partial sums of a K split.
+// The accumulator block (mb, nb) holds rows m0 + (mb0 + mb) * 16 + 4 (lane >> 4) + reg, column ncol0 + 16 nb + (lane & 15).
+// Written without per-element branches: a taken branch costs more than the arithmetic it would skip.
+template <int SIG, int MBLK, int NBLK>
+__device__ __forceinline__ unsigned conv16_epilogue_body(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0,
+                                                         int nmb, int ncol0, float ia, float iw,
+                                                         const float (*pre)[3]) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int NS = p.n_store;
+  const float slope = p.act == RAC_ACT_LEAKY02 ? 0.2f : 1.f;
+  unsigned mx = 0;
+#pragma unroll
+  for (int nb = 0; nb < NBLK; ++nb) {
+    const int n = ncol0 + nb * 16 + lr;
+    const bool nok = n < NS;
+    const int nc = nok ? n : 0;
+    // (bias, scale, shift) of the column: fetched here, or by the caller before its main loop -- at this point a
+    // global load is one more exposed round trip
+    const float bias = pre ? pre[nb][0] : (p.bias ? p.bias[nc] : 0.f);
+    const float sc = pre ? pre[nb][1] : (p.scale ? p.scale[nc] : 1.f);
+    const float sh = pre ? pre[nb][2] : (p.scale ? p.shift[nc] : 0.f);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb) {
+      if (mb0 + mb >= nmb) continue;  // wave-uniform: past the tile's rows
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + (mb0 + mb) * 16 + 4 * lq + r;
+        const bool ok = nok & (m < p.M);
+        float v = acc[mb][nb][r] * ia * iw + bias;  // two exact steps: ia * iw alone may underflow
+        const float vs = ok ? v : 0.f;
+        s1 += vs;
+        s2 += vs * vs;
+        v = v * sc + sh;
+        v = v > 0.f ? v : slope * v;
+        if (SIG) v = sigmoid_acc(v);
+        if (ok) {
+          p.out0[(long)m * NS + n] = v;
+          mx = max(mx, absbits(v));
+        }
+      }
+    }
+    if (p.stats) {
+      s1 += __shfl_xor(s1, 16);
+      s2 += __shfl_xor(s2, 16);
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lq == 0 && nok) {
+        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * NS : 0L);
+        atomicAdd(sg + n, (double)s1);
+        atomicAdd(sg + NS + n, (double)s2);
+      }
+    }
+  }
+  return mx;
+}
+
+template <int MBLK, int NBLK>
+__device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0, int nmb,
+                                                int ncol0, int bz, float ia, float iw, const float (*pre)[3] = nullptr) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int NS = p.n_store;
+  if (p.split_k > 1) {  // raw partial sums: the ConvLSTM cell kernel / rac_slab_reduce adds the slabs
+    float* dst = p.out0 + (long)bz * p.slab_stride;
+#pragma unroll
+    for (int nb = 0; nb < NBLK; ++nb) {
+      const int n = ncol0 + nb * 16 + lr;
+#pragma unroll
+      for (int mb = 0; mb < MBLK; ++mb) {
+        if (mb0 + mb >= nmb) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + (mb0 + mb) * 16 + 4 * lq + r;
+          if ((n < NS) & (m < p.M)) dst[(long)m * NS + n] = acc[mb][nb][r] * ia * iw;
+        }
+      }
+    }
+    return;
+  }
+  unsigned mx;
+  if (p.act == RAC_ACT_SIGMOID)
+    mx = conv16_epilogue_body<1>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre);
+  else
+    mx = conv16_epilogue_body<0>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre);
+  if (p.out_amax) amax_commit(mx, p.out_amax);
 }
 
 // WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
@@ -310,51 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
   }
 
-  // ---- epilogue: undo the two scales, then as rac_conv2d FWD; col = l & 15 (+16 nb), rows 4 (l >> 4) + reg ----
-  const float ia = pow2f(-ka), iw = pow2f(-kw);
-  const bool slab = p.split_k > 1;
-  const int NS = p.n_store;
-  unsigned mx = 0;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = n0 + wn * NT * 32 + nb * 16 + lr;
-    const bool nok = n < NS;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (!slab && nok) {
-      if (p.bias) bias = p.bias[n];
-      if (p.scale) {
-        sc = p.scale[n];
-        sh = p.shift[n];
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < RB; ++mb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * RB + mb) * 16 + 4 * lq + r;
-        if (wm * RB + mb >= nmb || m >= p.M || !nok) continue;
-        const float v = acc[mb][nb][r] * ia * iw;
-        if (slab) {
-          p.out0[(long)bz * p.slab_stride + (long)m * NS + n] = v;
-          continue;
-        }
-        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * NS + n)));
-      }
-    }
-    if (p.stats && !slab) {
-      s1 += __shfl_xor(s1, 16);
-      s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lq == 0 && nok) {
-        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * NS : 0L);
-        atomicAdd(sg + n, (double)s1);
-        atomicAdd(sg + NS + n, (double)s2);
-      }
-    }
-  }
-  if (p.out_amax && !slab) amax_commit(mx, p.out_amax);
+  conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -369,7 +399,17 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 // 32-column weight tiles each: (2, 2) 128-column workgroups, waves 64 rows x 64 columns; (2, 1) 64 columns (the
 // 64-channel layers); (4, 1) 32 columns (narrow heads: the 4-channel output head stores only N of them).
 // ---------------------------------------------------------------------------------------------------------
-template <int NV, int WM, int NT>
+// D = weight register sets: a step's B operands are requested D - 1 steps ahead (2 and 4 measure the same on every
+// shape: the weights are L2 hits that arrive within one step).
+// FAST: 3 x 3 taps, full 128-row tiles, whole channel chunks per K range: the 9 taps of a chunk are unrolled over a ring
+// of 3 weight sets (no per-step bookkeeping or branches) and the epilogue's per-column parameters are fetched before the
+// main loop instead of behind it (one exposed memory round trip less): 3-10 % on the 64- and 128-column shapes.
+// What bounds the short-K shapes (64-channel layers on 64x64 maps, 18 steps per tile; SQ counters and in-kernel clocks,
+// round 2): the matrix pipe is busy 27 % of the time; a wave spends 38 % of its life in s_waitcnt (the first chunk's
+// HBM round trip alone is 4-6 us of a 22 us tile) and issues 3.4 other VALU instructions per MFMA (staging with its
+// 2x halo, tap addressing, the epilogue), which share the SIMD's issue port with the MFMAs.  Dropping the fragment
+// reads, the weight loads or the MFMAs themselves from the loop changes the kernel time by 5-10 % each.
+template <int NV, int WM, int NT, int D, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;
   constexpr int MB = 8 / WM;            // 16-row blocks per wave
@@ -486,15 +526,78 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  float pre[NB][3];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const int n = n0 + wn * NT * 32 + nb * 16 + lr;
+      const int nc = n < p.n_store ? n : 0;
+      pre[nb][0] = p.bias ? p.bias[nc] : 0.f;
+      pre[nb][1] = p.scale ? p.scale[nc] : 1.f;
+      pre[nb][2] = p.scale ? p.shift[nc] : 0.f;
+    }
+    static_assert(D == 3, "the 9 taps of a chunk walk a ring of 3 weight register sets");
+    const int c_begin = kc_begin / 9, c_end = kc_end / 9;
+    if (c_begin < c_end) {
+      u32x4 bs[3][4 * NT];
+      issue_a(c_begin);
+      load_b(bs[0], kc_begin);
+      load_b(bs[1], min(kc_begin + 1, kc_end - 1));
+      store_a(0);
+      __syncthreads();
+      int cur = 0;
+      for (int cc = c_begin; cc < c_end; ++cc) {
+        const bool more = cc + 1 < c_end;
+        if (more) issue_a(cc + 1);
+        const int kc0 = cc * 9;
+        const int bufo = cur * abuf;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int ky = tap / 3, kx = tap % 3;
+          load_b(bs[(tap + 2) % 3], min(kc0 + tap + 2, kc_end - 1));
+          const int drow = (ky - 1) * p.W + (kx - 1);
+          const int shift = drow * 16 + bufo + abase;
+          const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
+          f16x8 fb[NB][2];
+#pragma unroll
+          for (int j2 = 0; j2 < NT; ++j2)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int part = 0; part < 2; ++part)
+                fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[tap % 3][(j2 * 2 + part) * 2 + nb]);
+          f16x8 fa[MB][2];
+#pragma unroll
+          for (int t = 0; t < MB; ++t) {
+            // the centre column needs no x test
+            const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+              fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+          }
+#pragma unroll
+          for (int t = 0; t < MB; ++t)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
+        }
+        if (more) {
+          store_a(cur ^ 1);
+          __syncthreads();
+          cur ^= 1;
+        }
+      }
+    }
+  } else
   if (kc_begin < kc_end) {
     int cc = kc_begin / p.taps;
     int tap = kc_begin - cc * p.taps;
     int ky = tap / p.ks, kx = tap - ky * p.ks;
     int cur = 0;
     bool fresh = true;
-    u32x4 b0[4 * NT], b1[4 * NT];
+    u32x4 bs[D][4 * NT];
     issue_a(cc);
-    load_b(b0, kc_begin);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load_b(bs[j], kc_begin + j);
     store_a(0);
     __syncthreads();
 
@@ -548,60 +651,16 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
     };
 
-    for (int kc = kc_begin; kc < kc_end; kc += 2) {
-      load_b(b1, kc + 1);
-      step(b0, kc);
-      if (kc + 1 < kc_end) {
-        load_b(b0, kc + 2);
-        step(b1, kc + 1);
+    for (int kc = kc_begin; kc < kc_end; kc += D) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        if (kc + j >= kc_end) break;
+        load_b(bs[(j + D - 1) % D], min(kc + j + D - 1, kc_end - 1));  // (past the end: a harmless repeat)
+        step(bs[j], kc + j);
       }
     }
   }
-
-  const float ia = pow2f(-ka), iw = pow2f(-kw);
-  const bool slab = p.split_k > 1;
-  const int NS = p.n_store;  // columns stored = row stride of the output (== N except for padded narrow heads)
-  unsigned mx = 0;
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    const int n = n0 + wn * NT * 32 + nb * 16 + lr;
-    const bool nok = n < NS;
-    float bias = 0.f, sc = 1.f, sh = 0.f;
-    if (!slab && nok) {
-      if (p.bias) bias = p.bias[n];
-      if (p.scale) {
-        sc = p.scale[n];
-        sh = p.shift[n];
-      }
-    }
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (wm * MB + mb) * 16 + 4 * lq + r;
-        if (wm * MB + mb >= nmb || m >= p.M || !nok) continue;
-        const float v = acc[mb][nb][r] * ia * iw;
-        if (slab) {
-          p.out0[(long)bz * p.slab_stride + (long)m * NS + n] = v;
-          continue;
-        }
-        mx = max(mx, absbits(conv16_epilogue_store(p, v, bias, sc, sh, s1, s2, (long)m * NS + n)));
-      }
-    }
-    if (p.stats && !slab) {
-      s1 += __shfl_xor(s1, 16);
-      s2 += __shfl_xor(s2, 16);
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lq == 0 && nok) {
-        double* sg = p.stats + (p.stats_rows ? (long)(m0 / p.stats_rows) * 2 * NS : 0L);
-        atomicAdd(sg + n, (double)s1);
-        atomicAdd(sg + NS + n, (double)s2);
-      }
-    }
-  }
-  if (p.out_amax && !slab) amax_commit(mx, p.out_amax);
+  conv16_epilogue(p, acc, m0, wm * MB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), FAST ? pre : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1066,15 +1125,23 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
     RAC_REQUIRE(nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
     typedef void (*rows_fn)(Conv16P);
     static const rows_fn fns[3][3] = {
-        {conv16_rows_kernel<2, 2, 2>, conv16_rows_kernel<3, 2, 2>, conv16_rows_kernel<4, 2, 2>},   // 128 columns
-        {conv16_rows_kernel<2, 2, 1>, conv16_rows_kernel<3, 2, 1>, conv16_rows_kernel<4, 2, 1>},   // 64 columns
-        {conv16_rows_kernel<2, 4, 1>, conv16_rows_kernel<3, 4, 1>, conv16_rows_kernel<4, 4, 1>}};  // 32 columns
-    const size_t lds_rows = (size_t)2 * 2 * 4 * (nrows + 16) * 16;
+        {conv16_rows_kernel<2, 2, 2, 2>, conv16_rows_kernel<3, 2, 2, 2>, conv16_rows_kernel<4, 2, 2, 2>},   // 128 columns
+        {conv16_rows_kernel<2, 2, 1, 2>, conv16_rows_kernel<3, 2, 1, 2>, conv16_rows_kernel<4, 2, 1, 2>},   // 64 columns
+        {conv16_rows_kernel<2, 4, 1, 2>, conv16_rows_kernel<3, 4, 1, 2>, conv16_rows_kernel<4, 4, 1, 2>}};  // 32 columns
+    // 3 x 3, full tiles, chunk-aligned K ranges: the unrolled-tap form
+    static const rows_fn fast_fns[3][3] = {
+        {conv16_rows_kernel<2, 2, 2, 3, true>, conv16_rows_kernel<3, 2, 2, 3, true>, conv16_rows_kernel<4, 2, 2, 3, true>},
+        {conv16_rows_kernel<2, 2, 1, 3, true>, conv16_rows_kernel<3, 2, 1, 3, true>, conv16_rows_kernel<4, 2, 1, 3, true>},
+        {conv16_rows_kernel<2, 4, 1, 3, true>, conv16_rows_kernel<3, 4, 1, 3, true>, conv16_rows_kernel<4, 4, 1, 3, true>}};
+    size_t lds_rows = (size_t)2 * 2 * 4 * (nrows + 16) * 16;
     static bool rows_attr = false;
     if (!rows_attr) {
-      for (int i = 0; i < 9; ++i) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fns[i / 3][i % 3]),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * (256 + 16) * 16);
+      for (int i = 0; i < 18; ++i) {
+        const rows_fn f = i < 9 ? fns[i / 3][i % 3] : fast_fns[(i - 9) / 3][i % 3];
+        if (!f) continue;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * 2 * 4 * (256 + 16) * 16);
         if (e != hipSuccess) {
           set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
           return RAC_ELAUNCH;
@@ -1085,7 +1152,11 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
     const int width = p.N <= 32 ? 2 : (p.N <= 64 ? 1 : 0);
     dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, width == 2 ? 32 : (width == 1 ? 64 : 128)), p.split_k);
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
-    hipLaunchKernelGGL(fns[width][nv - 2], grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
+    static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
+    rows_fn fn = fns[width][nv - 2];
+    if (a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast)))
+      fn = fast_fns[width][nv - 2];
+    hipLaunchKernelGGL(fn, grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(image rows)");
   }
   p.tile_m = (128 / p.HW) * p.HW;  // whole images per workgroup
