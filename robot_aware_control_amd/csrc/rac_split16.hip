@@ -816,7 +816,9 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int addr) {
   return __builtin_bit_cast(f16x8, (h16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int KS>
+// WMW = waves along the output channels: 2 -> workgroup 128 co x 64 ci, waves 64 co x 32 ci; 1 -> 64 co x 64 ci, waves
+// 64 co x 16 ci (64-channel layers: no all-zero half tile; its dy tile is staged by the first two waves only).
+template <int KS, int WMW = 2>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   constexpr int PAD = KS / 2, NR = 2 * PAD + 2;
   constexpr int DYB = 16384, XSLOT = 8192, X_BASE = 2 * DYB;
@@ -824,8 +826,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
-  const int co0 = blockIdx.x * 128, ci0 = blockIdx.y * 64;
+  constexpr int WN = 4 / WMW, NU = 4 / WN;  // waves along ci, 16-ci blocks per wave
+  const int wm = wid / WN, wn = wid % WN;
+  const int co0 = blockIdx.x * (64 * WMW), ci0 = blockIdx.y * 64;
   const int ky = blockIdx.z % KS, split = blockIdx.z / KS;
   const bool first = ci0 < p.C0;
   const int Cs = first ? p.C0 : p.Cin - p.C0;
@@ -849,21 +852,27 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   // ---- staging roles: row kk = tid >> 3 of the 32-row block; dy: 16 channels (segment tid & 7), x: 8 channels ----
   const int skk = tid >> 3, ssub = tid & 7;
   const int ssw = (skk & 3) | (((skk >> 3) & 1) << 2);
-  const int dy_lds = skk * 256 + ((ssub ^ ssw) * 32);                       // + buf * DYB + part * 8192
+  // dy roles of the 64-co form: threads 0..127 (waves 0 and 1), row tid >> 2, 16-channel segment tid & 3
+  const bool dy_role = WMW == 2 || tid < 128;
+  const int dkk = WMW == 2 ? skk : (tid >> 2) & 31, dsub = WMW == 2 ? ssub : tid & 3;
+  const int dsw = (dkk & 3) | (((dkk >> 3) & 1) << 2);
+  const int dy_lds = dkk * 256 + ((dsub ^ dsw) * 32);                       // + buf * DYB + part * 8192
   const int x_lds = X_BASE + skk * 256 + (((ssub >> 1) ^ ssw) * 32) + (ssub & 1) * 16;  // part 1: segment ^ 4 -> ^ 128
-  const bool dy_ch_ok = co0 + ssub * 16 < p.Cout;
+  const bool dy_ch_ok = co0 + dsub * 16 < p.Cout;
   const bool x_ch_ok = cl0 + ssub * 8 < Cs;
   // loader cursors (uniform): dy column e_d, x column e_x, as (group, column) pairs
   int dg = g_begin, dc = 0, xg = g_begin, xc = 0;
   u32x4 rd[4], rx[2];
   auto issue_dy = [&]() {
-    const int t = dg / p.G, gr = dg - t * p.G;
-    const int r = gr * 32 + skk;
-    const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
-    const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + ssub * 16) * 4u;
-    const bool ok = (r < p.R) & dy_ch_ok;
+    if (dy_role) {  // (wave-uniform)
+      const int t = dg / p.G, gr = dg - t * p.G;
+      const int r = gr * 32 + dkk;
+      const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
+      const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
+      const bool ok = (r < p.R) & dy_ch_ok;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+      for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+    }
     if (++dc == p.W) dc = 0, ++dg;
   };
   auto issue_x = [&]() {
@@ -878,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
     if (++xc == p.W) xc = 0, ++xg;
   };
   auto store_dy = [&](int buf) {
+    if (!dy_role) return;
     u32x4 q0[2], q1[2];
     split8h(rd[0], rd[1], sd, q0);
     split8h(rd[2], rd[3], sd, q1);
@@ -899,22 +909,28 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
   const int fsw = fq | ((fg & 1) << 2);
   const int lane_base = (8 * fg + fq) * 256 + fp * 8;
-  int offA[4], offB[2][2];
+  int offA[4], offB[2][NU];
 #pragma unroll
   for (int t = 0; t < 4; ++t) offA[t] = lane_base + (((wm * 4 + t) ^ fsw) * 32);
 #pragma unroll
   for (int part = 0; part < 2; ++part)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) offB[part][u] = X_BASE + lane_base + (((part * 4 + wn * 2 + u) ^ fsw) * 32);
+    for (int u = 0; u < NU; ++u) offB[part][u] = X_BASE + lane_base + (((part * 4 + wn * NU + u) ^ fsw) * 32);
 
-  f32x4 acc[KS][4][2];
+  f32x4 acc[KS][4][NU];
 #pragma unroll
   for (int k = 0; k < KS; ++k)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int u = 0; u < 2; ++u) acc[k][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int u = 0; u < NU; ++u) acc[k][t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if (WMW == 1) {  // the channel segments of the dy tiles that nobody stages (co 64..127 of the 256-byte rows)
+#pragma unroll
+    for (int v = 0; v < 8; ++v)
+      *reinterpret_cast<u32x4*>(lds_raw + (v * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   if (S > 0) {
     // prologue: input columns 0 .. PAD and the dy tile of column 0
     for (int e = 0; e <= PAD && e < S; ++e) {
@@ -941,15 +957,15 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
         int sl = sm + k - PAD;
         sl += sl < 0 ? NR : 0;
         sl -= sl >= NR ? NR : 0;
-        f16x8 fb[2][2];
+        f16x8 fb[NU][2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int u = 0; u < 2; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+          for (int u = 0; u < NU; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
       }
       if (more_dy) store_dy((s + 1) & 1);
       if (more_x) {
@@ -969,8 +985,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   float* dst = split == 0 ? p.dw : p.slabs + (long)(split - 1) * p.slab_stride;
   const bool add = split == 0 && p.accumulate;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int cil = cl0 + wn * 32 + u * 16 + lr;  // channel inside its source
+  for (int u = 0; u < NU; ++u) {
+    const int cil = cl0 + wn * (16 * NU) + u * 16 + lr;  // channel inside its source
     if (cil >= Cs) continue;
     const int ci = (first ? 0 : p.C0) + cil;
 #pragma unroll
@@ -1217,19 +1233,22 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   RAC_REQUIRE(p.nsplit == 1 || (a->slabs && a->slab_stride >= n), "rac_conv2d_wgrad_split: slabs for the K split");
   p.accumulate = a->accumulate;
   p.dw = a->dw, p.slabs = a->slabs, p.slab_stride = a->slab_stride;
-  const int ct = cdiv(a->Cout, 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
+  const bool co64 = a->Cout <= 64;  // 64 co x 64 ci workgroups: no all-zero half of the 128-co tile
+  const int ct = cdiv(a->Cout, co64 ? 64 : 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
   dim3 grid(ct, nt, a->ksize * p.nsplit);
   typedef void (*fn_t)(Wgrad16P);
-  const fn_t fn = a->ksize == 5 ? (fn_t)wgrad16_kernel<5> : (fn_t)wgrad16_kernel<3>;
+  const fn_t fn = a->ksize == 5 ? (co64 ? (fn_t)wgrad16_kernel<5, 1> : (fn_t)wgrad16_kernel<5, 2>)
+                                : (co64 ? (fn_t)wgrad16_kernel<3, 1> : (fn_t)wgrad16_kernel<3, 2>);
   const int lds = 2 * 16384 + (a->ksize + 1) * 8192;
-  static bool attr_done[2] = {false, false};
-  if (!attr_done[a->ksize == 5]) {
+  static bool attr_done[4] = {false, false, false, false};
+  const int fi = (a->ksize == 5) * 2 + co64;
+  if (!attr_done[fi]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {
       set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
       return RAC_ELAUNCH;
     }
-    attr_done[a->ksize == 5] = true;
+    attr_done[fi] = true;
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_wgrad_split");
