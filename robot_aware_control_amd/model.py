@@ -315,6 +315,7 @@ class SVGConvModel(nn.Module):
                 wm.grad = torch.as_strided(grad, shape, stride, w0._rac_off)
                 bm = torch.as_strided(flat, (2 * z,), (1,), b0._rac_off).requires_grad_(w0.requires_grad)
                 bm.grad = torch.as_strided(grad, (2 * z,), (1,), b0._rac_off)
+                wm._rac_sources = (w0, w1)  # ops.weight_parts: the cached operand parts follow both parameters
                 m._head = (wm, bm)
         for m in self.modules():
             if isinstance(m, _VggLayer):

@@ -95,6 +95,9 @@ def padded_weight(weight: torch.Tensor, cp: Optional[int] = None) -> torch.Tenso
             setattr(weight, f"_rac_padbuf{cp}", wp)
             wp._rac_pad_source = (weakref.ref(weight), cp)
         call("rac_pad_rows", ptr(weight_mem(weight)), ci, ptr(wp), cp, co * k * k, stream_ptr())
+        ent = _WP_ENTRIES.get(id(wp))
+        if ent is not None:  # rewritten behind torch's version counter: its cached operand parts are stale
+            ent.tag = None
         return wp
     return _derived(weight, f"_rac_padded{cp}", build)
 
@@ -406,7 +409,11 @@ def _wp_drop(key, device, idx, _ref):
 
 
 def _wp_tag(weight):
-    return (weight._version, PARAM_EPOCH, weight.data_ptr())
+    # a view over several parameters (the merged mu | logvar head) changes when any of them does: in-place updates of
+    # a parameter bump ITS version counter, not the view's
+    src = getattr(weight, "_rac_sources", None)
+    ver = weight._version if src is None else tuple(t._version for t in src)
+    return (ver, PARAM_EPOCH, weight.data_ptr())
 
 
 def _wp_upload(jobs, device):

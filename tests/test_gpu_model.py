@@ -281,6 +281,28 @@ def test_cem_rollouts_full_width_vs_oracle(dev):
     assert err < 1e-5, err
 
 
+def test_cached_weight_operands_follow_load_state_dict(dev):
+    """The fp16 operand parts of every conv weight (and of the merged mu | logvar head, a view over two parameters) are
+    cached; loading other weights into a model that has already run must invalidate them."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=4, sample_mean=True, reward_type="dense",
+                  topk=3, **FLAGSETS["vanilla"])
+    sd_a = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    sd_b = orc.make_weights(cfg, seed=10, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=5, N=4, T=3, with_robot=False, goal_blend=0.15)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    model = build_model(cfg, sd_a, dev)
+    sampler = TrajectorySampler(ns_for(cfg, dev), model)
+    cost_a = sampler.generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+    model.load_state_dict({k: v.clone() for k, v in sd_b.items()})
+    cost_b = sampler.generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+    ref_b = orc.cem_rollouts(sd_b, cfg, prob["actions"], prob["start_img"], prob["goal_imgs"], prob["goal_masks"])["sum_cost"]
+    assert float(np.abs(cost_b - ref_b).max() / np.abs(ref_b).max()) < 1e-5
+    assert float(np.abs(cost_a - cost_b).max()) > 0
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_cem_rollout_options_vs_oracle(dev, sparse):
     """generate_model_rollouts options (trajectory_sampler.py:35-199): ragged last batch (7 candidates, batches of 3),
