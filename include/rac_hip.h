@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 3
+#define RAC_ABI_VERSION 4
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -288,7 +288,14 @@ int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, floa
 /* packed[b][p][:] = [img[b][0..2][p] * (zmask ? 1-zmask[b][p] : 1) | mask[b][0..Cm-1][p]]
  * = zero_robot_region (src/utils/image.py:5-19) + cat([img, mask]) (dynamics.py:578-582), NCHW -> NHWC */
 int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, int32_t pad, float* packed,
-                   int32_t B, int32_t HW, void* stream); /* `pad` trailing zero channels */
+                   int32_t B, int32_t HW, void* stream);
+/* The frozen model's first encoder layer straight from the planes rac_pack_input would pack (no packed tensor):
+ *   out[b][y][x][co] = act(scale[co] * conv3x3([img * (zmask == 0) | mask])[co] + shift[co])     NHWC, Cout = 64
+ * w: the layer's weight, memory [Cout][3][3][3 + Cm]; scale / shift: eval BatchNorm folded (or NULL); act none / leaky;
+ * out_amax as the other `*_amax` outputs.  H, W multiples of 16.  vgg_64.py:8-18 (c1[0]) on dynamics.py:578-582. */
+int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
+                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax, int32_t B,
+                        int32_t H, int32_t W, int32_t Cout, void* stream); /* `pad` trailing zero channels */
 /* dimg[b][c][p] = dpacked[b][p][c] * (zmask ? 1-zmask : 1), c < 3 */
 int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,
                     void* stream);

@@ -30,6 +30,93 @@ __global__ void pack_input_kernel(const float* img, const float* zmask, const fl
   }
 }
 
+// First encoder layer of the frozen model straight from the NCHW planes (vgg_64.py:8-18 on dynamics.py:578-582's input):
+// out[b][y][x][co] = act(scale[co] * sum_{tap, ci} in[b][ci][y + ky - 1][x + kx - 1] * w[co][tap][ci] + shift[co]), with
+// in = [img * (zero_mask == 0) | mask planes].  3..8 input channels are 27..72 multiply-adds per output channel: a
+// matrix-pipe conv would run on 32-channel chunks that are 3/4 padding (and first write the padded NHWC tensor).  Here a
+// workgroup owns a 16 x 16 pixel tile (input halo tile and the [tap][ci][co] weights in LDS); a thread computes 4
+// horizontally adjacent pixels x 16 output channels in fp32 FMAs, so every weight vector it reads feeds 4 pixels and
+// the 4 threads of a pixel quad write 256 contiguous bytes per pixel.  (One pixel x 64 channels per thread is bound by
+// its LDS weight reads: 0.74 ms at 1000 x 3 x 64 x 64 frames; weights through global loads 0.84.)
+// Also leaves max |out| for the next conv's operand scale.
+template <int CIN>
+__global__ __launch_bounds__(256) void first_layer_kernel(const float* img, const float* zmask, const float* mask,
+                                                          const float* w, const float* scale, const float* shift, int act,
+                                                          float* out, unsigned* amax, int H, int W) {
+  constexpr int CO = 64, TP = 18, TPW = 20;  // halo tile 18 x 18, rows padded to 20 floats
+  __shared__ float in_sh[CIN][TP * TPW];
+  __shared__ __attribute__((aligned(16))) float w_sh[9 * CIN][CO];
+  const int tid = threadIdx.x;
+  const int cg = tid & 3, pq = tid >> 2;        // 16-channel group; pixel quad
+  const int ty = pq >> 2, tx = (pq & 3) << 2;   // quad = pixels (ty, tx .. tx + 3) of the tile
+  const int tiles_x = W >> 4;
+  const int b = blockIdx.y, ty0 = (blockIdx.x / tiles_x) << 4, tx0 = (blockIdx.x % tiles_x) << 4;
+  const long HW = (long)H * W;
+  for (int i = tid; i < 9 * CIN * CO; i += 256) {  // w[co][tap][ci] -> w_sh[tap * CIN + ci][co]
+    const int r = i / CO, co = i - r * CO;
+    w_sh[r][co] = w[(long)co * 9 * CIN + r];
+  }
+  for (int i = tid; i < CIN * TP * TP; i += 256) {
+    const int ci = i / (TP * TP), q = i - ci * TP * TP;
+    const int qy = q / TP, qx = q - qy * TP;
+    const int y = ty0 + qy - 1, x = tx0 + qx - 1;
+    float v = 0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+      const long pix = (long)y * W + x;
+      if (ci < 3) {
+        v = img[((long)b * 3 + ci) * HW + pix];
+        if (zmask && zmask[(long)b * HW + pix] != 0.f) v = v * 0.f;
+      } else {
+        v = mask[((long)b * (CIN - 3) + (ci - 3)) * HW + pix];
+      }
+    }
+    in_sh[ci][qy * TPW + qx] = v;
+  }
+  __syncthreads();
+  f32x4 acc[4][4];  // [pixel][4 channels]
+#pragma unroll
+  for (int px = 0; px < 4; ++px)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[px][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1  // (fully unrolled, the compiler hoists every weight vector into registers and spills)
+  for (int tap = 0; tap < 9; ++tap) {
+    const int q = (ty + tap / 3) * TPW + tx + tap % 3;
+#pragma unroll 1
+    for (int ci = 0; ci < CIN; ++ci) {
+      const f32x4* wr = reinterpret_cast<const f32x4*>(&w_sh[tap * CIN + ci][cg * 16]);
+      const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
+#pragma unroll
+      for (int px = 0; px < 4; ++px) {
+        const float v = in_sh[ci][q + px];
+        acc[px][0] += v * w0, acc[px][1] += v * w1, acc[px][2] += v * w2, acc[px][3] += v * w3;
+      }
+    }
+  }
+  const float slope = act == RAC_ACT_LEAKY02 ? 0.2f : 1.f;
+  f32x4 sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sc[j] = scale ? reinterpret_cast<const f32x4*>(scale + cg * 16)[j] : f32x4{1.f, 1.f, 1.f, 1.f};
+    sh[j] = scale ? reinterpret_cast<const f32x4*>(shift + cg * 16)[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  unsigned mx = 0;
+#pragma unroll
+  for (int px = 0; px < 4; ++px) {
+    f32x4* o = reinterpret_cast<f32x4*>(out + (((long)b * H + ty0 + ty) * W + tx0 + tx + px) * CO + cg * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[px][j] * sc[j] + sh[j];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = v[e] > 0.f ? v[e] : slope * v[e];
+        mx = max(mx, absbits(v[e]));
+      }
+      o[j] = v;
+    }
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
 __global__ void unpack_grad_kernel(const float* dpacked, int C, const float* zmask, float* dimg, int B, int HW) {
   const long n = (long)B * HW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -337,6 +424,23 @@ int rac_pack_input(const float* img, const float* zmask, const float* mask, int3
   hipLaunchKernelGGL(pack_input_kernel, dim3(grid_for((long)B * HW)), dim3(256), 0, ST(stream), img, zmask, mask, Cm,
                      pad, packed, B, HW);
   return check_launch("rac_pack_input");
+}
+
+int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
+                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax, int32_t B,
+                        int32_t H, int32_t W, int32_t Cout, void* stream) {
+  RAC_REQUIRE(img && w && out && B > 0 && H > 0 && W > 0 && Cm >= 0 && Cm <= 5 && (Cm == 0 || mask),
+              "rac_first_layer_fwd: bad args (3 image planes + at most 5 mask / heatmap planes)");
+  RAC_REQUIRE(Cout == 64 && H % 16 == 0 && W % 16 == 0 && (scale == nullptr) == (shift == nullptr) && aligned16(out) &&
+                  (!scale || (aligned16(scale) && aligned16(shift))) && (act == RAC_ACT_NONE || act == RAC_ACT_LEAKY02),
+              "rac_first_layer_fwd: Cout 64, H and W multiples of 16, act none / leaky");
+  dim3 grid((H / 16) * (W / 16), B);
+  typedef void (*fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, int, float*,
+                       unsigned*, int, int);
+  static const fn_t fns[6] = {first_layer_kernel<3>, first_layer_kernel<4>, first_layer_kernel<5>,
+                              first_layer_kernel<6>, first_layer_kernel<7>, first_layer_kernel<8>};
+  hipLaunchKernelGGL(fns[Cm], grid, dim3(256), 0, ST(stream), img, zmask, mask, w, scale, shift, act, out, out_amax, H, W);
+  return check_launch("rac_first_layer_fwd");
 }
 
 int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,

@@ -69,6 +69,15 @@ class _VggLayer(nn.Module):
         self.main = nn.ModuleList([_Conv(cin, cout, 3, bias=False), _BatchNorm(cout)])
         self._folded = None
 
+    def folded(self):
+        """eval: BatchNorm folded into the conv epilogue as (scale, shift) per output channel."""
+        if self._folded is None:
+            bn = self.main[1]
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + ops.BN_EPS)
+                self._folded = (scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
+        return self._folded
+
     def forward(self, x0, x1=None, n_updates=1, groups=1):
         """`groups` > 1: the batch holds that many time steps, each normalised with its own batch statistics."""
         conv, bn = self.main[0], self.main[1]
@@ -76,11 +85,7 @@ class _VggLayer(nn.Module):
             bn.pending_updates += n_updates * groups
             folded = None
         else:
-            if self._folded is None:  # eval: BatchNorm folded into the conv epilogue
-                with torch.no_grad():
-                    scale = bn.weight / torch.sqrt(bn.running_var + ops.BN_EPS)
-                    self._folded = (scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous())
-            folded = self._folded
+            folded = self.folded()
         return ops.VggLayer.apply(x0, x1, conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                   self.training, n_updates, folded, groups if self.training else 1)
 
@@ -94,12 +99,15 @@ class _Encoder(nn.Module):
             chans = [nc if (c is None and i == 0) else (dim if c is None else c) for i, c in enumerate(chans)]
             setattr(self, name, nn.ModuleList([_VggLayer(chans[i], chans[i + 1]) for i in range(len(chans) - 1)]))
 
-    def forward(self, x, n_updates=1, groups=1):
+    def forward(self, x, n_updates=1, groups=1, first_done=False):
+        """`first_done`: x is already the output of c1[0] (the frozen model's direct first-layer kernel)."""
         skips = []
         for i, name in enumerate(("c1", "c2", "c3", "c4")):
             if i:
                 x = ops.MaxPool2.apply(x)
-            for layer in getattr(self, name):
+            for j, layer in enumerate(getattr(self, name)):
+                if first_done and i == 0 and j == 0:
+                    continue
                 x = layer(x, None, n_updates, groups)
             skips.append(x)
         return x, skips
@@ -446,6 +454,14 @@ class SVGConvModel(nn.Module):
             mask_planes = mask if mask_planes is None else torch.cat([mask_planes, mask], 1)
         if mask_planes is not None:
             mask_planes = mask_planes.contiguous()
+        zm = None if zero_mask is None else zero_mask.contiguous()
+        first = self.encoder.c1[0]
+        if (not self.training and not torch.is_grad_enabled() and ops.SPLIT_GEMM
+                and ops.first_layer_ok(image, mask_planes, first.main[0].weight)):
+            # frozen model: the first layer reads the planes directly (no packed, 32-channel-padded input tensor)
+            scale, shift = first.folded()
+            x1 = ops.first_layer_frozen(image, zm, mask_planes, first.main[0].weight, scale, shift)
+            return self.encoder(x1, n_updates, groups, first_done=True)
         # one whole 32-channel chunk (zero padded) where the first layer can take the split-precision kernels
         H, W = image.shape[-2], image.shape[-1]
         pad_to = 32 if (ops.SPLIT_GEMM and ops.split_supported(H, W, 3, 32, 64)) else 0

@@ -1266,6 +1266,24 @@ class PackInput(torch.autograd.Function):
         return dimg, None, None, None
 
 
+def first_layer_ok(img, mask, weight) -> bool:
+    """rac_first_layer_fwd takes this first encoder layer (frozen model only: no tape, BatchNorm folded)."""
+    Cm = mask.shape[1] if mask is not None else 0
+    return (img.is_cuda and weight.shape[0] == 64 and weight.shape[1] == 3 + Cm and Cm <= 5 and weight.shape[2] == 3
+            and img.shape[-2] % 16 == 0 and img.shape[-1] % 16 == 0)
+
+
+def first_layer_frozen(img, zero_mask, mask, weight, scale, shift) -> torch.Tensor:
+    """LeakyReLU(BatchNorm_eval(conv3x3([img * (1 - zero_mask) | mask]))) as an NHWC map, straight from the planes."""
+    B, _, H, W = img.shape
+    Cm = mask.shape[1] if mask is not None else 0
+    out = torch.empty((B, H, W, 64), device=img.device, dtype=torch.float32)
+    slot = amax_slot(img.device)
+    call("rac_first_layer_fwd", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(weight_mem(weight.detach())), ptr(scale),
+         ptr(shift), ACT_LEAKY, ptr(out), ptr(slot), B, H, W, 64, stream_ptr())
+    return tag_amax(out, slot)
+
+
 class ZeroRegion(torch.autograd.Function):
     """zero_robot_region (src/utils/image.py:5-19), out of place."""
 

@@ -190,6 +190,28 @@ def test_lstm_cell(dev, g, k, B):
     assert relerr(bd.grad.cpu(), b.grad) < 5e-5
 
 
+@pytest.mark.parametrize("B,H,W,Cm,zero", [(3, 64, 64, 2, True), (2, 48, 64, 1, True), (2, 32, 16, 0, False), (1, 16, 16, 4, True)])
+def test_first_layer_from_planes(dev, B, H, W, Cm, zero):
+    """Frozen model's first encoder layer straight from the NCHW planes: zero_robot_region + mask concat + conv3x3 +
+    folded BatchNorm + LeakyReLU(0.2) in one kernel, and the max |out| it leaves for the next conv."""
+    from robot_aware_control_amd import ops
+    img = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
+    mask = (rnd(2, B, Cm, H, W) > 0.3).float() if Cm else None
+    zm = (rnd(4, B, 1, H, W) > 0.5).float() if zero else None
+    w = rnd(5, 64, 3 + Cm, 3, 3) * 0.2
+    scale, shift = rnd(6, 64).abs() + 0.5, rnd(7, 64, scale=0.3)
+    x = img * (1 - zm) if zero else img
+    x = torch.cat([x, mask], 1) if Cm else x
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double(), None, 1, 1) * scale.double().view(1, -1, 1, 1)
+                       + shift.double().view(1, -1, 1, 1), 0.2)
+    wd = cl_weight(w).to(dev)
+    assert ops.first_layer_ok(img.to(dev), None if mask is None else mask.to(dev), wd)
+    out = ops.first_layer_frozen(img.to(dev), None if zm is None else zm.to(dev), None if mask is None else mask.to(dev),
+                                 wd, scale.to(dev), shift.to(dev))
+    assert relerr(from_map(out), ref) < 2e-6
+    assert int(ops.amax_tag(out).item()) == int(out.abs().max().view(torch.int32).item())
+
+
 def test_pool_upsample_tilecat(dev):
     from robot_aware_control_amd import ops
     x = rnd(1, 2, 12, 16, 16).requires_grad_(True)
