@@ -100,11 +100,12 @@ def test_conv_mfma_layout_asymmetric(dev):
     assert torch.equal(from_map(y), y_ref)
 
 
-def test_convT_head(dev):
+@pytest.mark.parametrize("B,H,W,Ci", [(2, 64, 64, 64), (1, 48, 64, 64), (1, 128, 128, 32), (2, 32, 32, 64)])
+def test_convT_head(dev, B, H, W, Ci):
+    """ConvTranspose2d + bias + Sigmoid head: the narrow 32-column form of the rows kernel (4 real columns)."""
     from robot_aware_control_amd import ops
-    B, H, W = 2, 64, 64
-    x = rnd(1, B, 64, H, W).requires_grad_(True)
-    w = (rnd(2, 64, 4, 3, 3) * 0.05).requires_grad_(True)
+    x = rnd(1, B, Ci, H, W).requires_grad_(True)
+    w = (rnd(2, Ci, 4, 3, 3) * 0.05).requires_grad_(True)
     b = rnd(3, 4, scale=0.1).requires_grad_(True)
     y_ref = torch.sigmoid(F.conv_transpose2d(x, w, b, 1, 1))
     gy = rnd(4, *y_ref.shape)
