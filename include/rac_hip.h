@@ -74,6 +74,11 @@ typedef struct rac_conv_args {
   double* stats;      /* [G][2][N] fp64 sum / sum of squares of the raw conv output (train BatchNorm), or NULL */
   int64_t stats_rows; /* rows (pixels) per statistics group: G = B*H*W / stats_rows groups (time steps batched along
                          the batch axis keep per-step statistics); 0 = one group.  Multiple of 128. */
+  int32_t a0_up;      /* rac_conv2d_fwd_split, maps larger than a 128-pixel tile: a0 is the [B][H/2][W/2][.] tensor whose
+                         nearest-neighbour 2x upsampling is the conv's first source (vgg_64.py:205-216, nn.UpsamplingNearest2d
+                         before upc3 / upc4 / upc5): pixel (y, x) reads a0 at (y / 2, x / 2); the upsampled tensor is never
+                         materialised.  0 elsewhere. */
+  int32_t reserved;
 } rac_conv_args;
 
 /* Replaces aten::conv2d / conv_transpose2d and their backward on the hot path:

@@ -26,7 +26,7 @@ class ConvArgs(C.Structure):
         ("slab_stride", i64),
         ("a0", vp), ("a1", vp), ("w", vp), ("out0", vp), ("out1", vp),
         ("bias", vp), ("scale", vp), ("shift", vp), ("stats", vp),
-        ("stats_rows", i64),
+        ("stats_rows", i64), ("a0_up", i32), ("reserved", i32),
     ]
 
 

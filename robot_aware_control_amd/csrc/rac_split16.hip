@@ -98,6 +98,7 @@ struct Conv16P {
   int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
   int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
+  int a0_up;      // rows kernel: a0 is the half-resolution tensor, read at (y / 2, x / 2) (nearest 2x upsampling)
 };
 
 // LDS image of the tile kernel: CHUNK-major [part 2][8-channel group 4][row 144][16 B]; rows 128..143 are zeros.
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   }
 
   const int y_tile = (m0 % p.HW) / p.W;
-  int s_off[NV], s_row[NV], s_grp[NV];
+  int s_off[NV], s_row[NV], s_grp[NV], s_pix[NV];
   bool s_ok[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -463,6 +464,11 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
     const int y = y_tile - p.pad + row / p.W;
     s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
+    s_pix[i] = m0 - halo + row;
+    if (p.a0_up && s_ok[i]) {  // the pixel of the half-resolution source under this one
+      const int img = s_pix[i] / p.HW, x = row % p.W;
+      s_pix[i] = (img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+    }
   }
   unsigned amask[MB];
 #pragma unroll
@@ -500,10 +506,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     const bool first = c0 < p.a_split;
     const int Cs = first ? p.a_split : p.Cin - p.a_split;
     const int cl = first ? c0 : c0 - p.a_split;
-    const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
+    const bool up = first && p.a0_up;
+    const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1,
+                                    (unsigned)((long)(up ? p.P >> 2 : p.P) * Cs * 4));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const unsigned oa = (unsigned)((m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      const unsigned oa = (unsigned)((up ? s_pix[i] : m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
       ra[2 * i] = load16(a_rsrc, s_ok[i] ? oa : OOB);
       ra[2 * i + 1] = load16(a_rsrc, s_ok[i] ? oa + 16u : OOB);
     }
@@ -1116,6 +1124,9 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.M = p.P, p.N = n_rows, p.n_store = a->Cout;
   p.taps = a->ksize * a->ksize;
   p.a_split = a_split;
+  p.a0_up = a->a0_up ? 1 : 0;
+  RAC_REQUIRE(!p.a0_up || (p.HW > 128 && a->H % 2 == 0 && a->W % 2 == 0),
+              "rac_conv2d_fwd_split: a0_up needs even H, W and a map larger than a 128-pixel tile");
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
   RAC_REQUIRE((long)p.P * (p.a_split > a->Cin - p.a_split ? p.a_split : a->Cin - p.a_split) * 4 < 0xFFFFFF00L,
               "rac_conv2d_fwd_split: operand larger than 4 GiB");

@@ -127,14 +127,20 @@ class _Decoder(nn.Module):
         d = vec
         for layer in self.upc2:
             d = layer(d, None, 1, groups)
+        frozen = not self.training and not torch.is_grad_enabled()
+
+        def up_conv(layer, d, sk):
+            """layer(cat[UpsamplingNearest2d(2)(d), sk]); the frozen model reads d at half resolution instead."""
+            if frozen and ops.vgg_up_frozen_ok(d, sk, layer.main[0].weight):
+                return ops.vgg_up_frozen(d, sk, layer.main[0].weight, *layer.folded())
+            return layer(ops.Upsample2.apply(d), sk, 1, groups)
+
         for name, sk in (("upc3", skip[2]), ("upc4", skip[1])):
-            up = ops.Upsample2.apply(d)
             layers = getattr(self, name)
-            d = layers[0](up, sk, 1, groups)
+            d = up_conv(layers[0], d, sk)
             for layer in list(layers)[1:]:
                 d = layer(d, None, 1, groups)
-        up = ops.Upsample2.apply(d)
-        d = self.upc5[0](up, skip[0], 1, groups)
+        d = up_conv(self.upc5[0], d, skip[0])
         head = self.upc5[1]
         return ops.ConvTHead.apply(d, head.weight, head.bias)
 

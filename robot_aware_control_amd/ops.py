@@ -511,11 +511,11 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
 
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
-                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0):
+                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0, a0_up=0):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
-                    stats_rows=stats_rows)
+                    stats_rows=stats_rows, a0_up=a0_up, reserved=0)
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -538,12 +538,15 @@ def is_zero(t) -> bool:
 
 
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                       want_slabs=False, groups=1):
+                       want_slabs=False, groups=1, x0_up=False):
     """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel.
     An all-zero x1 (`is_zero`) is skipped: the conv runs over the x0 channels of the same weight parts."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
+    if x0_up:  # x0 is the half-resolution tensor; its nearest 2x upsampling is the conv's first source
+        H, W = 2 * H, 2 * W
+        assert x1 is None or tuple(x1.shape[:3]) == (B, H, W)
     Cout, Cin_w, k, _ = weight.shape
     w_cin = 0
     if is_zero(x1) and C0 % 32 == 0:
@@ -558,7 +561,7 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     a0 = amax_for(x0)
     a1 = amax_for(x1) if x1 is not None else None
     pw, wslot = weight_parts(weight)
-    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, w_cin=w_cin)
+    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, w_cin=w_cin, a0_up=1 if x0_up else 0)
     if want_slabs:
         split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
         out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
@@ -1264,6 +1267,19 @@ class PackInput(torch.autograd.Function):
         dimg = torch.empty((B, 3, H, W), device=dout.device, dtype=torch.float32)
         call("rac_unpack_grad", ptr(dout), ctx.C, ptr(zero_mask), ptr(dimg), B, H * W, stream_ptr())
         return dimg, None, None, None
+
+
+def vgg_up_frozen_ok(x_low, skip, weight) -> bool:
+    """The frozen decoder's conv over [upsample2(x_low) | skip] can read x_low directly (a0_up of the rows kernel)."""
+    B, h, w, c0 = x_low.shape
+    return (SPLIT_GEMM and weight.shape[0] >= SPLIT_MIN_COUT and 4 * h * w > 128 and skip is not None
+            and tuple(skip.shape[:3]) == (B, 2 * h, 2 * w) and weight.shape[1] == c0 + skip.shape[3]
+            and split_supported(2 * h, 2 * w, 3, weight.shape[1], weight.shape[0], c0))
+
+
+def vgg_up_frozen(x_low, skip, weight, scale, shift) -> torch.Tensor:
+    """LeakyReLU(BatchNorm_eval(conv3x3([UpsamplingNearest2d(2)(x_low) | skip]))) without the upsampled tensor."""
+    return conv_forward_split(x_low, skip, weight, None, act=ACT_LEAKY, scale=scale, shift=shift, x0_up=True)
 
 
 def first_layer_ok(img, mask, weight) -> bool:

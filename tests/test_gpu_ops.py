@@ -213,6 +213,27 @@ def test_first_layer_from_planes(dev, B, H, W, Cm, zero):
     assert int(ops.amax_tag(out).item()) == int(out.abs().max().view(torch.int32).item())
 
 
+@pytest.mark.parametrize("B,h,w,C0,C1,Cout", [(2, 8, 8, 64, 64, 64), (3, 32, 32, 64, 64, 64), (2, 16, 16, 128, 128, 128),
+                                               (1, 24, 32, 32, 32, 64)])
+def test_conv_reads_half_resolution_source(dev, B, h, w, C0, C1, Cout):
+    """Frozen decoder: conv over [UpsamplingNearest2d(2)(d) | skip] with d read in place at (y / 2, x / 2) -- bit-equal
+    to the conv over the materialised upsampled tensor."""
+    from robot_aware_control_amd import ops
+    d = to_map(rnd(31, B, C0, h, w), dev)
+    sk = to_map(rnd(32, B, C1, 2 * h, 2 * w), dev)
+    wt = cl_weight(rnd(33, Cout, C0 + C1, 3, 3) * 0.05).to(dev)
+    scale, shift = (rnd(34, Cout).abs() + 0.5).to(dev), rnd(35, Cout, scale=0.2).to(dev)
+    assert ops.vgg_up_frozen_ok(d, sk, wt)
+    got = ops.vgg_up_frozen(d, sk, wt, scale, shift)
+    up = ops.Upsample2.apply(d)
+    want = ops.conv_forward_split(up, sk, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift)
+    assert torch.equal(got, want)
+    ref = F.leaky_relu(F.conv2d(torch.cat([F.interpolate(from_map(d).double(), scale_factor=2, mode="nearest"),
+                                           from_map(sk).double()], 1), wt.cpu().double(), None, 1, 1)
+                       * scale.cpu().double().view(1, -1, 1, 1) + shift.cpu().double().view(1, -1, 1, 1), 0.2)
+    assert relerr(from_map(got), ref) < 2e-6
+
+
 def test_pool_upsample_tilecat(dev):
     from robot_aware_control_amd import ops
     x = rnd(1, 2, 12, 16, 16).requires_grad_(True)
