@@ -487,21 +487,29 @@ class SVGConvModel(nn.Module):
                 r = robot.contiguous()
         p = self.prior_input_conv
         frozen = not torch.is_grad_enabled()  # no tape: the input convs may take the split-precision pipe
-        prior_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, None, frozen), None, p.weight, p.bias,
-                                      ACT_NONE, frozen)
+
+        def embed(conv, vs, z):
+            """conv(cat[tile(vs), h, z]); the frozen model's conv reads h in place (no concatenated tensor)."""
+            if frozen and not self.training and ops.embed_frozen_ok(vs, h, z, conv.weight):
+                return ops.embed_frozen(vs, h, z, conv.weight, conv.bias)
+            vs3 = list(vs) + [None] * (3 - len(vs))
+            return ops.ConvBias.apply(ops.TileCat.apply(vs3[0], vs3[1], vs3[2], h, z, frozen), None, conv.weight,
+                                      conv.bias, ACT_NONE, frozen)
+
+        prior_in = embed(p, [v for v in (a, r, r_next) if v is not None], None)
         z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean)
         z = mu_p if sample_mean else z_p
         mu = logvar = None
         if posterior:
             q = self.posterior_input_conv
-            post_x = (ops.TileCat.apply(next_robot.contiguous(), None, None, h, None, frozen)
-                      if cf.model_use_robot_state else h)
-            post_in = ops.ConvBias.apply(post_x, None, q.weight, q.bias, ACT_NONE, frozen)
+            if cf.model_use_robot_state:
+                post_in = embed(q, [next_robot.contiguous()], None)
+            else:
+                post_in = ops.ConvBias.apply(h, None, q.weight, q.bias, ACT_NONE, frozen)
             z_t, mu, logvar = self.posterior(post_in, self._eps)
             if not force_use_prior:
                 z = z_t
         f = self.frame_pred_input_conv
-        frame_in = ops.ConvBias.apply(ops.TileCat.apply(a, r, r_next, h, z, frozen), None, f.weight, f.bias, ACT_NONE,
-                                      frozen)
+        frame_in = embed(f, [v for v in (a, r, r_next) if v is not None], z)
         h_pred = self.frame_predictor(frame_in)
         return h_pred, mu, logvar, mu_p, logvar_p

@@ -1087,6 +1087,43 @@ class TileCat(torch.autograd.Function):
         return None, None, None, dm0, dm1, None
 
 
+def embed_frozen_ok(vs, h, z, weight) -> bool:
+    """The frozen model's input conv over cat[tile(v...), h, z] can read h in place (see embed_frozen)."""
+    B, H, W, g = h.shape
+    nv = sum(v.shape[1] for v in vs if v is not None)
+    cz = z.shape[3] if z is not None else 0
+    cs = nv + cz + (-(nv + cz)) % 32
+    return (SPLIT_GEMM and g % 32 == 0 and weight.shape[1] == nv + g + cz and weight.shape[0] >= 128
+            and split_supported(H, W, weight.shape[2], g + cs, weight.shape[0], g))
+
+
+def embed_frozen(vs, h, z, weight, bias) -> torch.Tensor:
+    """Conv(cat[tile(v0), tile(v1), tile(v2), h, z]) + bias (dynamics.py:591-607,634-640) for the frozen model without
+    the concatenated tensor: the conv's first source is h itself, the second a small [tile(v) | z | 0-pad] map, against a
+    cached copy of the weight whose input channels are reordered to [h | v | z | 0]."""
+    B, H, W, g = h.shape
+    vs = [v for v in vs if v is not None]
+    nv = sum(v.shape[1] for v in vs)
+    cz = z.shape[3] if z is not None else 0
+    pad = (-(nv + cz)) % 32
+    vs3 = vs + [None] * (3 - len(vs))
+    small = torch.empty((B, H, W, nv + cz + pad), device=h.device, dtype=torch.float32)
+    slot = amax_slot(h.device)
+    call("rac_tilecat_fwd", ptr(vs3[0]), vs3[0].shape[1] if vs3[0] is not None else 0, ptr(vs3[1]),
+         vs3[1].shape[1] if vs3[1] is not None else 0, ptr(vs3[2]), vs3[2].shape[1] if vs3[2] is not None else 0,
+         None, 0, ptr(z), cz, pad, ptr(small), B, H * W, ptr(slot), stream_ptr())
+    tag_amax(small, slot)
+
+    def build():
+        w = weight.detach()
+        parts = [w[:, nv:nv + g], w[:, :nv], w[:, nv + g:]]
+        if pad:
+            parts.append(torch.zeros((w.shape[0], pad, w.shape[2], w.shape[3]), device=w.device, dtype=w.dtype))
+        return torch.cat(parts, 1).contiguous(memory_format=torch.channels_last)
+    w2 = _derived(weight, f"_rac_reordered_{nv}_{cz}_{pad}", build)
+    return conv_forward_split(h, small, w2, bias)
+
+
 class LstmCell(torch.autograd.Function):
     """ConvLSTMCell (lstm.py:109-149): gates = Conv_k(cat(x, h_prev)) + b; i,f,o = sigmoid; g = tanh;
     c = f*c_prev + i*g; h = o*tanh(c).  The gate GEMM writes split-K slabs that the cell kernel sums."""
