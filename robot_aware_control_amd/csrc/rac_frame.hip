@@ -85,22 +85,10 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* img, cons
     for (int ci = 0; ci < CIN; ++ci) {
       const f32x4* wr = reinterpret_cast<const f32x4*>(&w_sh[tap * CIN + ci][cg * 16]);
       const f32x4 w0 = wr[0], w1 = wr[1], w2 = wr[2], w3 = wr[3];
-      const f32x4 wv[4] = {w0, w1, w2, w3};
-      // Plain v_fmac_f32, spelled out: left to itself the compiler pairs the channels into v_pk_fma_f32 with the pixel
-      // value broadcast through op_sel, and that form returned wrong sums in lanes 48..63 of a wave in ~10 % of the
-      // launches when several processes shared the GPU (4 ranks of tests/test_gpu_dist.py; never in one process)
-      // -- 10 % faster, not reproducible.
 #pragma unroll
       for (int px = 0; px < 4; ++px) {
         const float v = in_sh[ci][q + px];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a = acc[px][j][e];
-            asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a) : "v"(v), "v"(wv[j][e]));
-            acc[px][j][e] = a;
-          }
+        acc[px][0] += v * w0, acc[px][1] += v * w1, acc[px][2] += v * w2, acc[px][3] += v * w3;
       }
     }
   }

@@ -7,7 +7,8 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 obj=/tmp/rac_variant_$name; mkdir -p "$obj" "$root/robot_aware_control_amd/variants"
 for f in rac_igemm rac_split16 rac_pointwise rac_frame; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$root/include" -Wall -Wno-unused-function "$@" \
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$root/include" -Wall -Wno-unused-function \
+    -Xclang -target-feature -Xclang -packed-fp32-ops "$@" \
     -c "$root/robot_aware_control_amd/csrc/$f.hip" -o "$obj/$f.o" &
 done
 wait
