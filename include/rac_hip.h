@@ -176,6 +176,9 @@ typedef struct rac_wgrad_args {
   float* dw;             /* [Cout][k][k][Cin] */
   float* slabs;          /* workspace for nsplit > 1 */
   int64_t slab_stride;
+  int32_t x1_zero_steps; /* the x1 tensors of steps [0, x1_zero_steps) are all zeros (a ConvLSTM's initial hidden state):
+                            their share of the x1 half of dw is skipped, not computed */
+  int32_t reserved;
 } rac_wgrad_args;
 int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream);
 /* out[i] += sum_s slabs[s*slab_stride + i]  (fixed order) */

@@ -51,7 +51,7 @@ class WgradArgs(C.Structure):
         ("T", i32), ("nsplit", i32), ("accumulate", i32),
         ("dy", vp * WGRAD_MAX_STEPS), ("x0", vp * WGRAD_MAX_STEPS), ("x1", vp * WGRAD_MAX_STEPS),
         ("dy_amax", vp * WGRAD_MAX_STEPS), ("x0_amax", vp * WGRAD_MAX_STEPS), ("x1_amax", vp * WGRAD_MAX_STEPS),
-        ("dw", vp), ("slabs", vp), ("slab_stride", i64),
+        ("dw", vp), ("slabs", vp), ("slab_stride", i64), ("x1_zero_steps", i32), ("reserved", i32),
     ]
 
 

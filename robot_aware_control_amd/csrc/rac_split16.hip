@@ -800,6 +800,7 @@ struct Wgrad16P {
   int Bimg, H, W, Cin, Cout, C0, T;
   int R, G;      // image rows (Bimg * H) and 32-row groups per step
   int nsplit, accumulate;
+  int x1_skip;   // leading steps whose x1 is all zeros: the workgroups of the x1 half start behind them
   const float* dy[RAC_WGRAD_MAX_STEPS];
   const float* x0[RAC_WGRAD_MAX_STEPS];
   const float* x1[RAC_WGRAD_MAX_STEPS];
@@ -851,9 +852,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int kd = scale_exp(amd), kxs = scale_exp(amx);
   const float sd = pow2f(kd), sx = pow2f(kxs);
 
+  const int g_skip = first ? 0 : p.x1_skip * p.G;
   const int NG = p.T * p.G;
-  const int gpb = (NG + p.nsplit - 1) / p.nsplit;
-  const int g_begin = split * gpb;
+  const int gpb = (NG - g_skip + p.nsplit - 1) / p.nsplit;
+  const int g_begin = g_skip + split * gpb;
   const int g_end = min(NG, g_begin + gpb);
   const int S = max(0, g_end - g_begin) * p.W;  // column steps of this workgroup
 
@@ -1244,6 +1246,9 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   RAC_REQUIRE(p.nsplit == 1 || (a->slabs && a->slab_stride >= n), "rac_conv2d_wgrad_split: slabs for the K split");
   p.accumulate = a->accumulate;
   p.dw = a->dw, p.slabs = a->slabs, p.slab_stride = a->slab_stride;
+  RAC_REQUIRE(a->x1_zero_steps >= 0 && a->x1_zero_steps <= a->T && (two || a->x1_zero_steps == 0),
+              "rac_conv2d_wgrad_split: x1_zero_steps");
+  p.x1_skip = a->x1_zero_steps;
   const bool co64 = a->Cout <= 64;  // 64 co x 64 ci workgroups: no all-zero half of the 128-co tile
   const int ct = cdiv(a->Cout, co64 ? 64 : 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
   dim3 grid(ct, nt, a->ksize * p.nsplit);

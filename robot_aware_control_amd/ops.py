@@ -703,12 +703,16 @@ def _wgrad_split_batch(items, weight):
     keep = []
     for lo in range(0, len(items), _lib.WGRAD_MAX_STEPS):
         chunk = items[lo:lo + _lib.WGRAD_MAX_STEPS]
+        # steps whose second source is known to be all zeros (a ConvLSTM's first step) go first: their share of the x1
+        # half of the gradient is skipped (the order of the sum over steps is free)
+        chunk = sorted(chunk, key=lambda it: 0 if is_zero(it[2]) else 1)
+        n_zero = sum(1 for it in chunk if is_zero(it[2]))
         T = len(chunk)
         ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
         a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
                       accumulate=0 if (Cin != ci_real and lo == 0) else 1,
-                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n)
+                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, reserved=0)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
             assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
             a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
@@ -1147,12 +1151,15 @@ class LstmCell(torch.autograd.Function):
         if need_bwd:
             ctx.save_for_backward(x, h_prev, c_prev, weight, bias, act, c)
             ctx.amax = (amax_tag(x), amax_tag(h_prev))
+            ctx.h_zero = is_zero(h_prev)
         return h, c
 
     @staticmethod
     def backward(ctx, dh, dc):
         x, h_prev, c_prev, weight, bias, act, c = ctx.saved_tensors
         retag(x, ctx.amax[0]), retag(h_prev, ctx.amax[1])
+        if ctx.h_zero:  # (saved tensors come back as new objects) the weight gradient skips this step's hidden half
+            h_prev._rac_zero = True
         B, H, W, g = x.shape
         M = B * H * W
         dgates = torch.empty_like(act)

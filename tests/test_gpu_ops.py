@@ -599,3 +599,22 @@ def test_wgrad_split_precision(dev, case, monkeypatch):
         ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd3, defer=True)
         assert wd3.grad is None or float(wd3.grad.abs().max()) == 0.0
     assert relerr(wd3.grad.cpu(), 4 * ref) < 3e-6
+    if C1:
+        # a step whose second source is flagged all-zero (a ConvLSTM's first step) is skipped in the x1 half of dw:
+        # same result as computing with the zeros, whatever position the step has in the batch
+        z1 = torch.zeros_like(x1)
+        z1._rac_zero = True
+        xz = x.clone()
+        xz[:, C0:] = 0
+        wz = w.detach().clone().requires_grad_(True)
+        F.conv2d(xz.double(), wz.double(), None, 1, k // 2).backward(gy.double())
+        ref_z = ref + 2 * wz.grad.double()
+        wd4 = cl_weight(w.detach()).to(dev).requires_grad_(True)
+        with ops.deferred_wgrad():
+            ops.conv_wgrad_split_acc(to_map(gy, dev), x0, z1, wd4, defer=True)
+            ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd4, defer=True)
+            ops.conv_wgrad_split_acc(to_map(gy, dev), x0, z1, wd4, defer=True)
+        assert relerr(wd4.grad.cpu(), ref_z) < 3e-6
+        wd5 = cl_weight(w.detach()).to(dev).requires_grad_(True)
+        ops.conv_wgrad_split_acc(to_map(gy, dev), x0, z1, wd5)  # every step zero: the x1 half stays untouched
+        assert relerr(wd5.grad.cpu(), wz.grad.double()) < 3e-6 and float(wd5.grad[:, C0:].abs().max()) == 0.0
