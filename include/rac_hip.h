@@ -303,7 +303,16 @@ int rac_pack_input(const float* img, const float* zmask, const float* mask, int3
  * out_amax as the other `*_amax` outputs.  H, W multiples of 16.  vgg_64.py:8-18 (c1[0]) on dynamics.py:578-582. */
 int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
                         const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax, int32_t B,
-                        int32_t H, int32_t W, int32_t Cout, void* stream); /* `pad` trailing zero channels */
+                        int32_t H, int32_t W, int32_t Cout, void* stream);
+/* parts[i][w][ky][kx][t] = sum over the pixels of workgroup i's 16 x 16 tiles of wide[p][w] * thin[p + (ky - 1, kx - 1)][t]:
+ * the weight gradient of a 3x3 conv between a 64-channel NHWC tensor and a thin one (Ct <= 8 channels, row stride
+ * thin_stride >= Ct: the packed frame carries pad channels), as n_parts partial sums of 64 * 9 * Ct floats each that
+ * rac_slab_accumulate(parts, n_parts, 576 * Ct, dw, 576 * Ct) adds into the gradient (deterministic).  First encoder
+ * layer: wide = dy, thin = packed frame, dw = the (64, Ct, 3, 3) weight's gradient (vgg_64.py:8-18 backward); output
+ * head: wide = x, thin = d(sigmoid output), dw = the ConvTranspose (64, Ct, 3, 3) parameter's gradient
+ * (vgg_64.py:218-220 backward).  H, W multiples of 16; n_parts <= number of tiles. */
+int rac_thin_wgrad(const float* wide, const float* thin, int32_t thin_stride, int32_t Ct, float* parts, int32_t n_parts,
+                   int32_t B, int32_t H, int32_t W, int32_t Cw, void* stream); /* `pad` trailing zero channels */
 /* dimg[b][c][p] = dpacked[b][p][c] * (zmask ? 1-zmask : 1), c < 3 */
 int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,
                     void* stream);

@@ -117,6 +117,64 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* img, cons
   if (amax) amax_commit_block(mx, amax);
 }
 
+// Weight gradient of a 3x3 conv between a wide (64-channel) and a thin (<= 8-channel) NHWC tensor:
+//   out[w][tap][t] += sum_p wide[p][w] * thin[p + tap - (1, 1)][t]
+// = the first encoder layer's dW (wide = dy, thin = the packed frame: vgg_64.py:8-18 backward) and the output head's
+// (wide = x, thin = d(sigmoid): vgg_64.py:218-220 backward).  2 300 .. 4 600 sums over 327 680 pixels: ~1.5 GFLOP that
+// the GEMM-shaped weight-gradient kernels spend 0.2-0.35 ms on (64 of their 128 rows and all but 4..8 of 32 columns
+// are padding).  Here a workgroup owns a 16 x 16 pixel tile: the thin halo tile sits in LDS, thread (w = tid & 63,
+// q = tid >> 6) walks the tile's pixels with wide[p][w] in a register and accumulates the (tap, t) pairs of its
+// quarter, over all the tiles it is given; the workgroups' partial sums go to a workspace that rac_slab_accumulate adds
+// in a fixed order (deterministic; one float atomic per output and tile instead measured 0.5 ms: 1 280 atomics per
+// address across the XCDs).
+template <int CT>
+__global__ __launch_bounds__(256) void thin_wgrad_kernel(const float* wide, const float* thin, int ldt, float* part, int H,
+                                                         int W, int n_tiles) {
+  constexpr int TP = 18, NO = 9 * CT, NQ = (NO + 3) / 4;  // outputs per w; per thread
+  __shared__ float th[TP * TP][CT];
+  const int tid = threadIdx.x, w = tid & 63, q = tid >> 6;
+  const int tiles_x = W >> 4, tiles_img = (H >> 4) * tiles_x;
+  float acc[NQ];
+  int toff[NQ];  // LDS offset of output j's (tap, t) relative to the pixel
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    acc[j] = 0.f;
+    const int o = min(q * NQ + j, NO - 1), tap = o / CT;
+    toff[j] = ((tap / 3) * TP + tap % 3) * CT + (o - tap * CT);
+  }
+  const float* thf = &th[0][0];
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {  // a workgroup keeps its sums over all its tiles
+    const int b = tile / tiles_img, ti = tile - b * tiles_img;
+    const int ty0 = (ti / tiles_x) << 4, tx0 = (ti % tiles_x) << 4;
+    __syncthreads();
+    for (int i = tid; i < TP * TP * CT; i += 256) {
+      const int pix = i / CT, t = i - pix * CT;
+      const int y = ty0 + pix / TP - 1, x = tx0 + pix % TP - 1;
+      th[pix][t] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                       ? thin[(((long)b * H + y) * W + x) * ldt + t] : 0.f;
+    }
+    __syncthreads();
+    const float* wp = wide + (((long)b * H + ty0) * W + tx0) * 64 + w;
+    for (int py = 0; py < 16; ++py) {
+      float v[16];  // one image row of the tile: 16 independent loads in flight
+#pragma unroll
+      for (int px = 0; px < 16; ++px) v[px] = wp[((long)py * W + px) * 64];
+#pragma unroll
+      for (int px = 0; px < 16; ++px) {
+        const float* tp = thf + (py * TP + px) * CT;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) acc[j] += v[px] * tp[toff[j]];
+      }
+    }
+  }
+  float* dst = part + (long)blockIdx.x * 64 * NO + (long)w * NO;  // this workgroup's partial sums (plain stores)
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const int o = q * NQ + j;
+    if (o < NO) dst[o] = acc[j];
+  }
+}
+
 __global__ void unpack_grad_kernel(const float* dpacked, int C, const float* zmask, float* dimg, int B, int HW) {
   const long n = (long)B * HW;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -441,6 +499,20 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
                               first_layer_kernel<6>, first_layer_kernel<7>, first_layer_kernel<8>};
   hipLaunchKernelGGL(fns[Cm], grid, dim3(256), 0, ST(stream), img, zmask, mask, w, scale, shift, act, out, out_amax, H, W);
   return check_launch("rac_first_layer_fwd");
+}
+
+int rac_thin_wgrad(const float* wide, const float* thin, int32_t thin_stride, int32_t Ct, float* parts, int32_t n_parts,
+                   int32_t B, int32_t H, int32_t W, int32_t Cw, void* stream) {
+  RAC_REQUIRE(wide && thin && parts && B > 0 && H > 0 && W > 0 && Ct >= 1 && Ct <= 8 && thin_stride >= Ct && n_parts >= 1,
+              "rac_thin_wgrad: bad args (1 <= Ct <= 8)");
+  RAC_REQUIRE(Cw == 64 && H % 16 == 0 && W % 16 == 0, "rac_thin_wgrad: Cw 64, H and W multiples of 16");
+  const int n_tiles = B * (H / 16) * (W / 16);
+  RAC_REQUIRE(n_parts <= n_tiles, "rac_thin_wgrad: more parts than 16 x 16 tiles");
+  typedef void (*fn_t)(const float*, const float*, int, float*, int, int, int);
+  static const fn_t fns[8] = {thin_wgrad_kernel<1>, thin_wgrad_kernel<2>, thin_wgrad_kernel<3>, thin_wgrad_kernel<4>,
+                              thin_wgrad_kernel<5>, thin_wgrad_kernel<6>, thin_wgrad_kernel<7>, thin_wgrad_kernel<8>};
+  hipLaunchKernelGGL(fns[Ct - 1], dim3(n_parts), dim3(256), 0, ST(stream), wide, thin, thin_stride, parts, H, W, n_tiles);
+  return check_launch("rac_thin_wgrad");
 }
 
 int rac_unpack_grad(const float* dpacked, int32_t C, const float* zmask, float* dimg, int32_t B, int32_t HW,

@@ -1028,6 +1028,31 @@ __global__ void slab_accumulate_kernel(const float4* slabs, int n_slabs, long st
   }
 }
 
+// the same for MANY small slabs (rac_thin_wgrad's per-workgroup partial sums): 16 lanes share the slabs of a 16-byte
+// column and combine through LDS in a fixed order
+__global__ __launch_bounds__(256) void slab_accumulate_many_kernel(const float4* slabs, int n_slabs, long stride4,
+                                                                   float4* out, long n4) {
+  __shared__ float4 sh[256];
+  const int col = threadIdx.x & 15, lane = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + col;
+  float4 a = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int s = lane; s < n_slabs; s += 16) {
+      const float4 b = slabs[s * stride4 + i];
+      a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (lane == 0 && i < n4) {
+    float4 r = out[i];
+    for (int k = 0; k < 16; ++k) {
+      const float4 b = sh[k * 16 + col];
+      r.x += b.x, r.y += b.y, r.z += b.z, r.w += b.w;
+    }
+    out[i] = r;
+  }
+}
+
 }  // namespace rac
 
 using namespace rac;
@@ -1207,6 +1232,12 @@ extern "C" int rac_slab_accumulate(const float* slabs, int32_t n_slabs, int64_t 
   RAC_REQUIRE(n % 4 == 0 && slab_stride % 4 == 0 && aligned16(slabs) && aligned16(out), "rac_slab_accumulate: alignment");
   long nb = (n / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
+  if (n_slabs >= 64 && n <= (1 << 20)) {
+    hipLaunchKernelGGL(slab_accumulate_many_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), reinterpret_cast<const float4*>(slabs), n_slabs,
+                       (long)(slab_stride / 4), reinterpret_cast<float4*>(out), (long)(n / 4));
+    return check_launch("rac_slab_accumulate");
+  }
   hipLaunchKernelGGL(slab_accumulate_kernel, dim3((int)nb), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      reinterpret_cast<const float4*>(slabs), n_slabs, (long)(slab_stride / 4),
                      reinterpret_cast<float4*>(out), (long)(n / 4));

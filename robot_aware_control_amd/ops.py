@@ -112,6 +112,19 @@ def wgrad_padded_acc(dy, x0, weight):
     call("rac_unpad_add", ptr(gp), cp, ptr(weight_mem(grad_buffer(weight))), ci, co * k * k, stream_ptr())
 
 
+def thin_wgrad_acc(wide, thin, ct: int, weight):
+    """weight.grad ([64][3][3][ct] memory) += the 3x3 conv weight gradient between a 64-channel map and the first `ct`
+    channels of a thin one (rac_thin_wgrad: first encoder layer, output head): partial sums per workgroup, added in a
+    fixed order."""
+    B, H, W, _ = wide.shape
+    n = 64 * 9 * ct
+    n_parts = min(512, B * (H // 16) * (W // 16))
+    parts = torch.empty((n_parts, n), device=wide.device, dtype=torch.float32)
+    sp = stream_ptr()
+    call("rac_thin_wgrad", ptr(wide), ptr(thin), thin.shape[3], ct, ptr(parts), n_parts, B, H, W, 64, sp)
+    call("rac_slab_accumulate", ptr(parts), n_parts, n, ptr(weight_mem(grad_buffer(weight))), n, sp)
+
+
 def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> int:
     """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
     choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
@@ -923,8 +936,11 @@ class ConvTHead(torch.autograd.Function):
         if weight.requires_grad:
             g = grad_buffer(weight)
             # dw[ci][tap][co] += sum_p x[p][ci] * d[p+tap][co]  -> WGRAD with dy:=x, x:=d
-            conv_raw(WGRAD, d, None, x, g, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow, accumulate=1,
-                     split_k=0)
+            if Ciw == 64 and Cow <= 8 and k == 3 and H % 16 == 0 and W % 16 == 0:
+                thin_wgrad_acc(x, d, Cow, weight)
+            else:
+                conv_raw(WGRAD, d, None, x, g, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow, accumulate=1,
+                         split_k=0)
         if bias.requires_grad:
             bias_grad_acc(d, bias)
         return dx, None, None
@@ -1006,7 +1022,12 @@ class VggLayer(torch.autograd.Function):
             else:
                 dx0, dx1 = conv_dgrad(draw, wuse, C0, C1)
         if weight.requires_grad:
-            if ctx.split:
+            Bq, Hq, Wq, _ = draw.shape
+            if (ctx.padded and x1 is None and weight.shape[1] <= 8 and Cout == 64 and weight.shape[2] == 3
+                    and Hq % 16 == 0 and Wq % 16 == 0):
+                # first encoder layer: 64 x 9 x (3..8) sums over all pixels, straight into the unpadded gradient
+                thin_wgrad_acc(draw, x0, weight.shape[1], weight)
+            elif ctx.split:
                 conv_wgrad_split_acc(draw, x0, x1, weight)  # un-pads into weight.grad where x0 carries pad channels
             elif ctx.padded:
                 wgrad_padded_acc(draw, x0, weight)
