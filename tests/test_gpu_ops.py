@@ -234,6 +234,28 @@ def test_conv_reads_half_resolution_source(dev, B, h, w, C0, C1, Cout):
     assert relerr(from_map(got), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,ct,stride", [(2, 32, 48, 4, 4), (3, 64, 64, 5, 32), (1, 16, 16, 7, 8), (600, 16, 16, 3, 4)])
+def test_thin_weight_gradient(dev, B, H, W, ct, stride):
+    """dW of a 3x3 conv between a 64-channel map and a thin one (first encoder layer, output head) against fp64;
+    accumulates into .grad; bit-reproducible (per-workgroup partials, fixed-order sum)."""
+    from robot_aware_control_amd import ops
+    wide = rnd(41, B, 64, H, W) * 1e-3
+    thin = rnd(42, B, ct, H, W)
+    wr = torch.zeros(64, ct, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(thin.double(), wr, None, 1, 1).backward(wide.double())
+    thin_map = torch.zeros(B, H, W, stride)
+    thin_map[..., :ct] = thin.permute(0, 2, 3, 1)
+    wd = cl_weight(torch.zeros(64, ct, 3, 3)).to(dev).requires_grad_(True)
+    ops.thin_wgrad_acc(to_map(wide, dev), thin_map.to(dev), ct, wd)
+    first = wd.grad.clone()
+    assert relerr(first.cpu(), wr.grad) < 3e-6
+    ops.thin_wgrad_acc(to_map(wide, dev), thin_map.to(dev), ct, wd)
+    assert relerr(wd.grad.cpu(), 2 * wr.grad) < 3e-6
+    wd2 = cl_weight(torch.zeros(64, ct, 3, 3)).to(dev).requires_grad_(True)
+    ops.thin_wgrad_acc(to_map(wide, dev), thin_map.to(dev), ct, wd2)
+    assert torch.equal(wd2.grad, first)
+
+
 def test_pool_upsample_tilecat(dev):
     from robot_aware_control_amd import ops
     x = rnd(1, 2, 12, 16, 16).requires_grad_(True)
