@@ -178,9 +178,16 @@ typedef struct rac_wgrad_args {
   int64_t slab_stride;
   int32_t x1_zero_steps; /* the x1 tensors of steps [0, x1_zero_steps) are all zeros (a ConvLSTM's initial hidden state):
                             their share of the x1 half of dw is skipped, not computed */
-  int32_t reserved;
+  int32_t presplit;      /* 1: dy / x0 / x1 point to the fp16 part pairs rac_split_steps wrote ([2][elements], split under
+                            the SAME slot lists: every dy_amax for dy, every x0_amax and x1_amax for x0 and x1) */
 } rac_wgrad_args;
 int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream);
+/* parts[t] ([2][n] halves) = the two fp16 parts of xs[t] (n floats, n % 8 == 0) under ONE power-of-two scale taken from the
+ * maximum over the n_amax slots: the operands of rac_conv2d_wgrad_split split once instead of in every workgroup that
+ * stages them (a tile of dy is read by one workgroup per input-channel tile and kernel row).  xs / parts / amax are
+ * HOST arrays of device pointers. */
+int rac_split_steps(const float* const* xs, uint16_t* const* parts, int32_t T, int64_t n, const uint32_t* const* amax,
+                    int32_t n_amax, void* stream);
 /* out[i] += sum_s slabs[s*slab_stride + i]  (fixed order) */
 int rac_slab_accumulate(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, int64_t n, void* stream);
 

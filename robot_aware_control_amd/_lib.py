@@ -51,7 +51,7 @@ class WgradArgs(C.Structure):
         ("T", i32), ("nsplit", i32), ("accumulate", i32),
         ("dy", vp * WGRAD_MAX_STEPS), ("x0", vp * WGRAD_MAX_STEPS), ("x1", vp * WGRAD_MAX_STEPS),
         ("dy_amax", vp * WGRAD_MAX_STEPS), ("x0_amax", vp * WGRAD_MAX_STEPS), ("x1_amax", vp * WGRAD_MAX_STEPS),
-        ("dw", vp), ("slabs", vp), ("slab_stride", i64), ("x1_zero_steps", i32), ("reserved", i32),
+        ("dw", vp), ("slabs", vp), ("slab_stride", i64), ("x1_zero_steps", i32), ("presplit", i32),
     ]
 
 
@@ -67,6 +67,7 @@ _SIGS = {
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
+    "rac_split_steps": [C.POINTER(vp), C.POINTER(vp), i32, i64, C.POINTER(vp), i32, vp],
     "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
     "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp, vp],

@@ -801,6 +801,7 @@ struct Wgrad16P {
   int R, G;      // image rows (Bimg * H) and 32-row groups per step
   int nsplit, accumulate;
   int x1_skip;   // leading steps whose x1 is all zeros: the workgroups of the x1 half start behind them
+  int presplit;  // the operand pointers are fp16 part pairs [2][elements] (rac_split_steps), already scaled
   const float* dy[RAC_WGRAD_MAX_STEPS];
   const float* x0[RAC_WGRAD_MAX_STEPS];
   const float* x1[RAC_WGRAD_MAX_STEPS];
@@ -877,11 +878,21 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
     if (dy_role) {  // (wave-uniform)
       const int t = dg / p.G, gr = dg - t * p.G;
       const int r = gr * 32 + dkk;
-      const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
-      const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
       const bool ok = (r < p.R) & dy_ch_ok;
+      if (p.presplit) {  // 16 channels = 32 bytes per part: rd[0..1] part 0, rd[2..3] part 1
+        const unsigned pbytes = (unsigned)((long)p.R * p.W * p.Cout * 2);
+        const rsrc_t rs = make_rsrc(p.dy[t], 2u * pbytes);
+        const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 2u;
+        rd[0] = load16(rs, ok ? off : OOB);
+        rd[1] = load16(rs, ok ? off + 16u : OOB);
+        rd[2] = load16(rs, ok ? off + pbytes : OOB);
+        rd[3] = load16(rs, ok ? off + pbytes + 16u : OOB);
+      } else {
+        const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
+        const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+        for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+      }
     }
     if (++dc == p.W) dc = 0, ++dg;
   };
@@ -889,18 +900,30 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
     const int t = xg / p.G, gr = xg - t * p.G;
     const int r = gr * 32 + skk;
     const int y = r % p.H + ky - PAD;
-    const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
-    const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
     const bool ok = (r < p.R) & ((unsigned)y < (unsigned)p.H) & x_ch_ok;
-    rx[0] = load16(rs, ok ? off : OOB);
-    rx[1] = load16(rs, ok ? off + 16u : OOB);
+    if (p.presplit) {  // 8 channels = 16 bytes per part: rx[0] part 0, rx[1] part 1
+      const unsigned pbytes = (unsigned)((long)p.R * p.W * Cs * 2);
+      const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], 2u * pbytes);
+      const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 2u;
+      rx[0] = load16(rs, ok ? off : OOB);
+      rx[1] = load16(rs, ok ? off + pbytes : OOB);
+    } else {
+      const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
+      const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+      rx[0] = load16(rs, ok ? off : OOB);
+      rx[1] = load16(rs, ok ? off + 16u : OOB);
+    }
     if (++xc == p.W) xc = 0, ++xg;
   };
   auto store_dy = [&](int buf) {
     if (!dy_role) return;
     u32x4 q0[2], q1[2];
-    split8h(rd[0], rd[1], sd, q0);
-    split8h(rd[2], rd[3], sd, q1);
+    if (p.presplit) {
+      q0[0] = rd[0], q1[0] = rd[1], q0[1] = rd[2], q1[1] = rd[3];
+    } else {
+      split8h(rd[0], rd[1], sd, q0);
+      split8h(rd[2], rd[3], sd, q1);
+    }
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
@@ -910,7 +933,10 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   };
   auto store_x = [&](int slot) {
     u32x4 q[2];
-    split8h(rx[0], rx[1], sx, q);
+    if (p.presplit)
+      q[0] = rx[0], q[1] = rx[1];
+    else
+      split8h(rx[0], rx[1], sx, q);
     *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + x_lds) = q[0];
     *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + (x_lds ^ 128)) = q[1];
   };
@@ -1025,6 +1051,33 @@ __global__ void slab_accumulate_kernel(const float4* slabs, int n_slabs, long st
       a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
     }
     out[i] = a;
+  }
+}
+
+// fp32 tensors of up to 16 time steps -> their two fp16 parts under ONE power-of-two scale (from the maximum over the
+// given amax slots): parts[t] = [2][n] halves, h1 = fp16(x s), h2 = fp16(x s - h1).  The weight-gradient kernel reads
+// every operand tile in dozens of workgroups (one per input-channel tile and kernel row); splitting once here takes
+// the conversion out of all of them.
+struct SplitSteps {
+  const float* x[RAC_WGRAD_MAX_STEPS];
+  unsigned short* parts[RAC_WGRAD_MAX_STEPS];
+  const unsigned* amax[2 * RAC_WGRAD_MAX_STEPS];
+  int n_amax;
+  long n8;  // elements / 8 per step
+};
+__global__ __launch_bounds__(256) void split_steps_kernel(SplitSteps p) {
+  unsigned am = 0;
+  for (int i = 0; i < p.n_amax; ++i) am = max(am, *p.amax[i]);
+  const float s = pow2f(scale_exp(am));
+  const int t = blockIdx.y;
+  const u32x4* src = reinterpret_cast<const u32x4*>(p.x[t]);
+  u32x4* d0 = reinterpret_cast<u32x4*>(p.parts[t]);
+  u32x4* d1 = d0 + p.n8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < p.n8; i += (long)gridDim.x * 256) {
+    u32x4 q[2];
+    split8h(src[2 * i], src[2 * i + 1], s, q);
+    d0[i] = q[0];
+    d1[i] = q[1];
   }
 }
 
@@ -1226,6 +1279,27 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   return check_launch("rac_conv2d_fwd_split(whole images)");
 }
 
+extern "C" int rac_split_steps(const float* const* xs, uint16_t* const* parts, int32_t T, int64_t n,
+                               const uint32_t* const* amax, int32_t n_amax, void* stream) {
+  RAC_REQUIRE(xs && parts && amax && T >= 1 && T <= RAC_WGRAD_MAX_STEPS && n > 0 && n % 8 == 0 && n_amax >= 1 &&
+                  n_amax <= 2 * RAC_WGRAD_MAX_STEPS,
+              "rac_split_steps: bad args (n %% 8 == 0, 1 <= T <= 16, 1 <= n_amax <= 32)");
+  SplitSteps p{};
+  for (int t = 0; t < T; ++t) {
+    RAC_REQUIRE(xs[t] && parts[t] && aligned16(xs[t]) && aligned16(parts[t]), "rac_split_steps: null / unaligned step");
+    p.x[t] = xs[t], p.parts[t] = parts[t];
+  }
+  for (int i = 0; i < n_amax; ++i) {
+    RAC_REQUIRE(amax[i], "rac_split_steps: null amax slot");
+    p.amax[i] = amax[i];
+  }
+  p.n_amax = n_amax, p.n8 = n / 8;
+  long nb = (p.n8 + 255) / 256;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(split_steps_kernel, dim3((unsigned)nb, T), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p);
+  return check_launch("rac_split_steps");
+}
+
 extern "C" int rac_slab_accumulate(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, int64_t n,
                                    void* stream) {
   RAC_REQUIRE(slabs && out && n_slabs >= 1 && n > 0 && slab_stride >= n, "rac_slab_accumulate: bad args");
@@ -1280,6 +1354,8 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   RAC_REQUIRE(a->x1_zero_steps >= 0 && a->x1_zero_steps <= a->T && (two || a->x1_zero_steps == 0),
               "rac_conv2d_wgrad_split: x1_zero_steps");
   p.x1_skip = a->x1_zero_steps;
+  p.presplit = a->presplit ? 1 : 0;
+  RAC_REQUIRE(!p.presplit || (a->Cout % 16 == 0 && p.C0 % 8 == 0), "rac_conv2d_wgrad_split: presplit operand alignment");
   const bool co64 = a->Cout <= 64;  // 64 co x 64 ci workgroups: no all-zero half of the 128-co tile
   const int ct = cdiv(a->Cout, co64 ? 64 : 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
   dim3 grid(ct, nt, a->ksize * p.nsplit);

@@ -630,6 +630,9 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
 # gradient instead of T, longer K loops).  Same sum, different association across steps.
 _DEFERRED = None
 DEFER_WGRAD = os.environ.get("RAC_DEFER_WGRAD", "1") == "1"
+WGRAD_PRESPLIT = os.environ.get("RAC_WGRAD_PRESPLIT", "1") == "1"
+# workgroups that stage one operand tile before splitting it once pays
+WGRAD_PRESPLIT_MIN_READERS = int(os.environ.get("RAC_WGRAD_PRESPLIT_MIN", "32"))
 
 
 @contextlib.contextmanager
@@ -725,12 +728,36 @@ def _wgrad_split_batch(items, weight):
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
         a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
                       accumulate=0 if (Cin != ci_real and lo == 0) else 1,
-                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, reserved=0)
+                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, presplit=0)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
             assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
             a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
             a.dy_amax[t], a.x0_amax[t] = ptr(amax_for(dy_t)), ptr(amax_for(x0_t))
             a.x1_amax[t] = ptr(amax_for(x1_t)) if x1_t is not None else None
+        # every operand tile is staged by one workgroup per input-channel tile and kernel row: where that is many (the
+        # ConvLSTM gate weights: 48 .. 160), split the operands into their fp16 parts ONCE instead of in each of them
+        readers = (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
+        if WGRAD_PRESPLIT and readers >= WGRAD_PRESPLIT_MIN_READERS and Cin == ci_real:
+            two = chunk[0][2] is not None
+
+            def split(tensors, slots):
+                n_el = tensors[0].numel()
+                parts = torch.empty((len(tensors), 2, n_el), device=dev, dtype=torch.float16)
+                xs = (C.c_void_p * len(tensors))(*[ptr(t_) for t_ in tensors])
+                ps = (C.c_void_p * len(tensors))(*[ptr(parts[i]) for i in range(len(tensors))])
+                am = (C.c_void_p * len(slots))(*[ptr(s_) for s_ in slots])
+                call("rac_split_steps", xs, ps, len(tensors), n_el, am, len(slots), sp)
+                return parts
+            x_slots = [amax_for(it[1]) for it in chunk] + ([amax_for(it[2]) for it in chunk] if two else [])
+            dy_p = split([it[0] for it in chunk], [amax_for(it[0]) for it in chunk])
+            x0_p = split([it[1] for it in chunk], x_slots)
+            x1_p = split([it[2] for it in chunk[n_zero:]], x_slots) if two and n_zero < T else None
+            for t in range(T):
+                a.dy[t], a.x0[t] = ptr(dy_p[t]), ptr(x0_p[t])
+                if two:  # (the all-zero steps' x1 is never read: any valid pointer)
+                    a.x1[t] = ptr(x1_p[t - n_zero]) if t >= n_zero else ptr(x0_p[t])
+            a.presplit = 1
+            keep.extend([dy_p, x0_p, x1_p])
         if SHAPE_LOG is not None:
             _log_shape("wgrad16", WGRAD, k, Cout, Cin * k * k, T * B * H * W, 2500.0 / 3)
         call("rac_conv2d_wgrad_split", C.byref(a), sp)

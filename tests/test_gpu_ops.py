@@ -581,10 +581,13 @@ def test_conv_split_rows_kernel(dev, case):
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3),
                                   (2, 32, 32, 64, 64, 64, 3), (3, 16, 16, 128, 0, 64, 5), (2, 8, 8, 64, 0, 48, 3)])
-def test_wgrad_split_precision(dev, case, monkeypatch):
+@pytest.mark.parametrize("presplit", [False, True])
+def test_wgrad_split_precision(dev, case, presplit, monkeypatch):
     """Weight gradient on the split-precision pipe against fp64, next to the exact-fp32 MFMA kernel; accumulation into
-    .grad; the deferred (time-batched) form."""
+    .grad; the deferred (time-batched) form.  `presplit`: the operands are split into their fp16 parts once by
+    rac_split_steps (what the ConvLSTM gate weights get) instead of inside the kernel."""
     from robot_aware_control_amd import ops
+    monkeypatch.setattr(ops, "WGRAD_PRESPLIT_MIN_READERS", 1 if presplit else 10 ** 9)
     B, H, W, C0, C1, Cout, k = case
     Cin = C0 + C1
     x = rnd(1, B, Cin, H, W)
