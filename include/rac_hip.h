@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 4
+#define RAC_ABI_VERSION 5
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -78,7 +78,10 @@ typedef struct rac_conv_args {
                          nearest-neighbour 2x upsampling is the conv's first source (vgg_64.py:205-216, nn.UpsamplingNearest2d
                          before upc3 / upc4 / upc5): pixel (y, x) reads a0 at (y / 2, x / 2); the upsampled tensor is never
                          materialised.  0 elsewhere. */
-  int32_t reserved;
+  int32_t amax_per_image; /* rac_conv2d_fwd_split: a_amax0 / a_amax1 / out_amax are arrays of B slots, one per image, and
+                         every image is scaled by its OWN maximum: an image's result then cannot depend on what else is in
+                         the batch (the frozen model's rollouts: candidates_batch_size and the shard a candidate lands in
+                         must not change its cost, trajectory_sampler.py:123-174).  Needs split_k 1 and H*W % 16 == 0. */
 } rac_conv_args;
 
 /* Replaces aten::conv2d / conv_transpose2d and their backward on the hot path:
@@ -104,6 +107,9 @@ int rac_conv2d(const rac_conv_args* a, void* stream);
 /* *amax = max(*amax, bits(max |x|)) over x0[0..n0) and x1[0..n1) (x1 may be NULL, n1 = 0).  The slot must hold 0 or
  * an earlier maximum on entry; several calls may accumulate into one slot.  n % 4 == 0, 16-byte aligned. */
 int rac_absmax(const float* x0, int64_t n0, const float* x1, int64_t n1, uint32_t* amax, void* stream);
+/* amax[r] = bits(max |x[r][0..row_len)|) for every row r < rows (one slot per image: `amax_per_image` operands of
+ * rac_conv2d_fwd_split).  Plain stores: the slots need no initialisation.  row_len % 4 == 0, 16-byte aligned. */
+int rac_absmax_rows(const float* x, int64_t rows, int64_t row_len, uint32_t* amax, void* stream);
 /* Conv weight (fp32, [Cout][k][k][Cin] memory) -> the two fp16 parts of w * s_W in MFMA fragment order
  *   parts[part][R/32][K/32][k*k][nb 2][lane 64][8],  lane = 16 q + (r mod 16), row r = 32 tile + 16 nb + lane mod 16,
  *   k = 32 chunk + 8 q + j   (the B operand of v_mfma_f32_16x16x32_f16: one coalesced 1 KB load per MFMA operand).
@@ -228,7 +234,8 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
  * action / robot-state tiling + channel concat in front of the three input convs) */
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
                     const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
-                    int32_t HW, uint32_t* out_amax, void* stream); /* `pad` trailing zero channels */
+                    int32_t HW, uint32_t* out_amax, int32_t amax_per_image, void* stream);
+/* `pad` trailing zero channels; amax_per_image: out_amax is an array of B slots (plain stores), one per image */
 /* dst[r][0:C] = src[r][0:C], dst[r][C:Cpad] = 0  -- 16-byte aligned rows for the vector-load conv path
  * (weights of the convs whose channel count is not a multiple of 4: first encoder layer, the three input convs) */
 int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t R, void* stream);
@@ -309,8 +316,9 @@ int rac_pack_input(const float* img, const float* zmask, const float* mask, int3
  * w: the layer's weight, memory [Cout][3][3][3 + Cm]; scale / shift: eval BatchNorm folded (or NULL); act none / leaky;
  * out_amax as the other `*_amax` outputs.  H, W multiples of 16.  vgg_64.py:8-18 (c1[0]) on dynamics.py:578-582. */
 int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
-                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax, int32_t B,
-                        int32_t H, int32_t W, int32_t Cout, void* stream);
+                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax,
+                        int32_t amax_per_image, int32_t B, int32_t H, int32_t W, int32_t Cout, void* stream);
+/* amax_per_image: out_amax is an array of B zeroed slots, one per image */
 /* parts[i][w][ky][kx][t] = sum over the pixels of workgroup i's 16 x 16 tiles of wide[p][w] * thin[p + (ky - 1, kx - 1)][t]:
  * the weight gradient of a 3x3 conv between a 64-channel NHWC tensor and a thin one (Ct <= 8 channels, row stride
  * thin_stride >= Ct: the packed frame carries pad channels), as n_parts partial sums of 64 * 9 * Ct floats each that

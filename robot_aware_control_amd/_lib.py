@@ -26,11 +26,12 @@ class ConvArgs(C.Structure):
         ("slab_stride", i64),
         ("a0", vp), ("a1", vp), ("w", vp), ("out0", vp), ("out1", vp),
         ("bias", vp), ("scale", vp), ("shift", vp), ("stats", vp),
-        ("stats_rows", i64), ("a0_up", i32), ("reserved", i32),
+        ("stats_rows", i64), ("a0_up", i32), ("amax_per_image", i32),
     ]
 
 
 WGRAD_MAX_STEPS = 16
+ABI_VERSION = 5  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -59,6 +60,7 @@ class WgradArgs(C.Structure):
 _SIGS = {
     "rac_conv2d": [C.POINTER(ConvArgs), vp],
     "rac_absmax": [vp, i64, vp, i64, vp, vp],
+    "rac_absmax_rows": [vp, i64, i64, vp, vp],
     "rac_weight_frag_split": [vp, vp, vp, i32, i32, i32, i32, i64, vp],
     "rac_absmax_blocks": [i64],
     "rac_weight_frag_blocks": [i32, i32, i32],
@@ -77,7 +79,7 @@ _SIGS = {
     "rac_maxpool2_bwd": [vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_fwd": [vp, vp, i32, i32, i32, i32, vp],
     "rac_upsample2_bwd": [vp, vp, i32, i32, i32, i32, vp],
-    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp],
+    "rac_tilecat_fwd": [vp, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp, i32, vp],
     "rac_pad_rows": [vp, i32, vp, i32, i64, vp],
     "rac_unpad_add": [vp, i32, vp, i32, i64, vp],
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
@@ -98,7 +100,7 @@ _SIGS = {
     "rac_reparam_fwd": [vp, vp, vp, vp, i64, vp],
     "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
     "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],
-    "rac_first_layer_fwd": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp],
+    "rac_first_layer_fwd": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_thin_wgrad": [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp],
     "rac_unpack_grad": [vp, i32, vp, vp, i32, i32, vp],
     "rac_zero_region": [vp, vp, vp, i32, i32, vp],
@@ -140,6 +142,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = _RET.get(name, C.c_int)
+    if lib.rac_version() != ABI_VERSION:
+        raise RacError(f"{LIB_PATH} is ABI version {lib.rac_version()}, this binding needs {ABI_VERSION}: rebuild it")
     _lib = lib
     return lib
 

@@ -42,7 +42,7 @@ __global__ void pack_input_kernel(const float* img, const float* zmask, const fl
 template <int CIN>
 __global__ __launch_bounds__(256) void first_layer_kernel(const float* img, const float* zmask, const float* mask,
                                                           const float* w, const float* scale, const float* shift, int act,
-                                                          float* out, unsigned* amax, int H, int W) {
+                                                          float* out, unsigned* amax, int per_image, int H, int W) {
   constexpr int CO = 64, TP = 18, TPW = 20;  // halo tile 18 x 18, rows padded to 20 floats
   __shared__ float in_sh[CIN][TP * TPW];
   __shared__ __attribute__((aligned(16))) float w_sh[9 * CIN][CO];
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* img, cons
       o[j] = v;
     }
   }
-  if (amax) amax_commit_block(mx, amax);
+  if (amax) amax_commit_block(mx, per_image ? amax + b : amax);
 }
 
 // Weight gradient of a 3x3 conv between a wide (64-channel) and a thin (<= 8-channel) NHWC tensor:
@@ -485,8 +485,8 @@ int rac_pack_input(const float* img, const float* zmask, const float* mask, int3
 }
 
 int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
-                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax, int32_t B,
-                        int32_t H, int32_t W, int32_t Cout, void* stream) {
+                        const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax,
+                        int32_t amax_per_image, int32_t B, int32_t H, int32_t W, int32_t Cout, void* stream) {
   RAC_REQUIRE(img && w && out && B > 0 && H > 0 && W > 0 && Cm >= 0 && Cm <= 5 && (Cm == 0 || mask),
               "rac_first_layer_fwd: bad args (3 image planes + at most 5 mask / heatmap planes)");
   RAC_REQUIRE(Cout == 64 && H % 16 == 0 && W % 16 == 0 && (scale == nullptr) == (shift == nullptr) && aligned16(out) &&
@@ -494,10 +494,11 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
               "rac_first_layer_fwd: Cout 64, H and W multiples of 16, act none / leaky");
   dim3 grid((H / 16) * (W / 16), B);
   typedef void (*fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, int, float*,
-                       unsigned*, int, int);
+                       unsigned*, int, int, int);
   static const fn_t fns[6] = {first_layer_kernel<3>, first_layer_kernel<4>, first_layer_kernel<5>,
                               first_layer_kernel<6>, first_layer_kernel<7>, first_layer_kernel<8>};
-  hipLaunchKernelGGL(fns[Cm], grid, dim3(256), 0, ST(stream), img, zmask, mask, w, scale, shift, act, out, out_amax, H, W);
+  hipLaunchKernelGGL(fns[Cm], grid, dim3(256), 0, ST(stream), img, zmask, mask, w, scale, shift, act, out, out_amax,
+                     amax_per_image ? 1 : 0, H, W);
   return check_launch("rac_first_layer_fwd");
 }
 

@@ -276,6 +276,58 @@ __global__ void tilecat_kernel(const float* v0, int n0, const float* v1, int n1,
   if (amax) amax_commit_block(mx, amax);
 }
 
+// per-image maxima: workgroup b writes image b (the same values as tilecat_kernel) and leaves max |v| in amax[b]
+__global__ __launch_bounds__(256) void tilecat_image_kernel(const float* v0, int n0, const float* v1, int n1, const float* v2,
+                                                            int n2, const float* m0, int c0, const float* m1, int c1,
+                                                            int pad, float* out, int HW, unsigned* amax) {
+  const int Cv = n0 + n1 + n2 + c0 + c1;
+  const int Ct = Cv + pad;
+  const int b = blockIdx.x;
+  const int n = HW * Ct;
+  unsigned mx = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int c = i % Ct;
+    const long q = (long)b * HW + i / Ct;
+    float v;
+    if (c < n0)
+      v = v0[b * n0 + c];
+    else if (c < n0 + n1)
+      v = v1[b * n1 + (c - n0)];
+    else if (c < n0 + n1 + n2)
+      v = v2[b * n2 + (c - n0 - n1)];
+    else if (c < n0 + n1 + n2 + c0)
+      v = m0[q * c0 + (c - n0 - n1 - n2)];
+    else if (c < Cv)
+      v = m1[q * c1 + (c - n0 - n1 - n2 - c0)];
+    else
+      v = 0.f;
+    mx = max(mx, absbits(v));
+    out[(long)b * n + i] = v;
+  }
+  __shared__ unsigned sh[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) amax[b] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+}
+
+// amax[r] = bits(max |x[r][:]|): one workgroup per row (image)
+__global__ __launch_bounds__(256) void absmax_rows_kernel(const f32x4* x, long len4, unsigned* amax) {
+  const f32x4* row = x + (long)blockIdx.x * len4;
+  unsigned mx = 0;
+  for (long i = threadIdx.x; i < len4; i += 256) {
+    const f32x4 v = row[i];
+    mx = max(mx, max(max(absbits(v.x), absbits(v.y)), max(absbits(v.z), absbits(v.w))));
+  }
+  __shared__ unsigned sh[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) amax[blockIdx.x] = max(max(sh[0], sh[1]), max(sh[2], sh[3]));
+}
+
 __global__ void pad_rows_kernel(const float* src, int C, float* dst, int Cpad, long R) {
   const long n = R * Cpad;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -679,15 +731,29 @@ int rac_upsample2_bwd(const float* dy, float* dx, int32_t B, int32_t h, int32_t 
 
 int rac_tilecat_fwd(const float* v0, int32_t n0, const float* v1, int32_t n1, const float* v2, int32_t n2,
                     const float* m0, int32_t c0, const float* m1, int32_t c1, int32_t pad, float* out, int32_t B,
-                    int32_t HW, uint32_t* out_amax, void* stream) {
+                    int32_t HW, uint32_t* out_amax, int32_t amax_per_image, void* stream) {
   RAC_REQUIRE(out && B > 0 && HW > 0 && pad >= 0, "rac_tilecat_fwd: bad args");
   RAC_REQUIRE((n0 == 0 || v0) && (n1 == 0 || v1) && (n2 == 0 || v2) && (c0 == 0 || m0) && (c1 == 0 || m1),
               "rac_tilecat_fwd: null source with non-zero width");
   long n = (long)B * HW * (n0 + n1 + n2 + c0 + c1 + pad);
   RAC_REQUIRE(n > 0, "rac_tilecat_fwd: empty");
+  if (amax_per_image && out_amax) {
+    RAC_REQUIRE(n / B < 0x7FFFFFFFL, "rac_tilecat_fwd: image too large");
+    hipLaunchKernelGGL(tilecat_image_kernel, dim3(B), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1, c1, pad,
+                       out, HW, out_amax);
+    return check_launch("rac_tilecat_fwd");
+  }
   hipLaunchKernelGGL(tilecat_kernel, dim3(grid_for_amax(n, out_amax)), dim3(256), 0, ST(stream), v0, n0, v1, n1, v2, n2, m0, c0, m1,
                      c1, pad, out, B, HW, out_amax);
   return check_launch("rac_tilecat_fwd");
+}
+
+int rac_absmax_rows(const float* x, int64_t rows, int64_t row_len, uint32_t* amax, void* stream) {
+  RAC_REQUIRE(x && amax && rows > 0 && rows < 0x7FFFFFFFL && row_len > 0, "rac_absmax_rows: bad args");
+  RAC_REQUIRE(row_len % 4 == 0 && aligned16(x), "rac_absmax_rows: row_len % 4 == 0, 16-byte aligned rows");
+  hipLaunchKernelGGL(absmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, ST(stream), (const f32x4*)x,
+                     (long)(row_len / 4), amax);
+  return check_launch("rac_absmax_rows");
 }
 
 int rac_pad_rows(const float* src, int32_t C, float* dst, int32_t Cpad, int64_t R, void* stream) {

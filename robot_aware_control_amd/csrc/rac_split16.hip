@@ -99,6 +99,8 @@ struct Conv16P {
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
   int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
   int a0_up;      // rows kernel: a0 is the half-resolution tensor, read at (y / 2, x / 2) (nearest 2x upsampling)
+  int per_image;  // a_amax0 / a_amax1 / out_amax are arrays of B slots, one per image: every image is scaled by its OWN
+                  // maximum, so its result cannot depend on what else is in the batch (the frozen model's rollouts)
 };
 
 // LDS image of the tile kernel: CHUNK-major [part 2][8-channel group 4][row 144][16 B]; rows 128..143 are zeros.
@@ -110,14 +112,22 @@ constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
 // biased value, folded eval-BatchNorm scale / shift, activation, max |v|) -- or the raw partial sums of a K split.
 // The accumulator block (mb, nb) holds rows m0 + (mb0 + mb) * 16 + 4 (lane >> 4) + reg, column ncol0 + 16 nb + (lane & 15).
 // Written without per-element branches: a taken branch costs more than the arithmetic it would skip.
+// `ia_rows` (LDS, per-image scales): 1 / scale of every tile row instead of the one `ia`.  mxb[mb] = max |v| of the
+// lane's values in 16-row block mb (the caller folds them into one slot, or into one slot per image).
 template <int SIG, int MBLK, int NBLK>
-__device__ __forceinline__ unsigned conv16_epilogue_body(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0,
-                                                         int nmb, int ncol0, float ia, float iw,
-                                                         const float (*pre)[3]) {
+__device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0,
+                                                     int nmb, int ncol0, float ia, float iw, const float (*pre)[3],
+                                                     const float* ia_rows, unsigned (&mxb)[MBLK]) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int NS = p.n_store;
   const float slope = p.act == RAC_ACT_LEAKY02 ? 0.2f : 1.f;
-  unsigned mx = 0;
+  float iav[MBLK][4];
+#pragma unroll
+  for (int mb = 0; mb < MBLK; ++mb) {
+    mxb[mb] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) iav[mb][r] = ia_rows ? ia_rows[min((mb0 + mb) * 16 + 4 * lq + r, 127)] : ia;
+  }
 #pragma unroll
   for (int nb = 0; nb < NBLK; ++nb) {
     const int n = ncol0 + nb * 16 + lr;
@@ -136,7 +146,7 @@ __device__ __forceinline__ unsigned conv16_epilogue_body(const Conv16P& p, const
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + (mb0 + mb) * 16 + 4 * lq + r;
         const bool ok = nok & (m < p.M);
-        float v = acc[mb][nb][r] * ia * iw + bias;  // two exact steps: ia * iw alone may underflow
+        float v = acc[mb][nb][r] * iav[mb][r] * iw + bias;  // two exact steps: ia * iw alone may underflow
         const float vs = ok ? v : 0.f;
         s1 += vs;
         s2 += vs * vs;
@@ -145,7 +155,7 @@ __device__ __forceinline__ unsigned conv16_epilogue_body(const Conv16P& p, const
         if (SIG) v = sigmoid_acc(v);
         if (ok) {
           p.out0[(long)m * NS + n] = v;
-          mx = max(mx, absbits(v));
+          mxb[mb] = max(mxb[mb], absbits(v));
         }
       }
     }
@@ -161,12 +171,15 @@ __device__ __forceinline__ unsigned conv16_epilogue_body(const Conv16P& p, const
       }
     }
   }
-  return mx;
 }
 
+// `out_amax`: the slot of the tile's output maximum -- p.out_amax, or with per-image scales the slot of the tile's first
+// image (ia_rows == nullptr: the whole tile lies in ONE image, the rows kernel) / of image 0 (ia_rows given: the tile
+// holds whole images of HW rows, HW % 16 == 0, the tile kernel; each image's blocks go to that image's slot).
 template <int MBLK, int NBLK>
 __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0, int nmb,
-                                                int ncol0, int bz, float ia, float iw, const float (*pre)[3] = nullptr) {
+                                                int ncol0, int bz, float ia, float iw, const float (*pre)[3] = nullptr,
+                                                const float* ia_rows = nullptr, unsigned* out_amax = nullptr) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int NS = p.n_store;
   if (p.split_k > 1) {  // raw partial sums: the ConvLSTM cell kernel / rac_slab_reduce adds the slabs
@@ -186,12 +199,33 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
     }
     return;
   }
-  unsigned mx;
+  unsigned mxb[MBLK];
   if (p.act == RAC_ACT_SIGMOID)
-    mx = conv16_epilogue_body<1>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre);
+    conv16_epilogue_body<1>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb);
   else
-    mx = conv16_epilogue_body<0>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre);
-  if (p.out_amax) amax_commit(mx, p.out_amax);
+    conv16_epilogue_body<0>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb);
+  if (!out_amax) return;
+  if (!ia_rows) {  // one slot for everything this wave wrote
+    unsigned mx = 0;
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb) mx = max(mx, mxb[mb]);
+    amax_commit(mx, out_amax);
+    return;
+  }
+  int cur = -1;  // (wave-uniform) image of the blocks folded into mx so far
+  unsigned mx = 0;
+#pragma unroll
+  for (int mb = 0; mb < MBLK; ++mb) {
+    const int row = m0 + (mb0 + mb) * 16;
+    if (mb0 + mb >= nmb || row >= p.M) continue;
+    const int img = row / p.HW;
+    if (img != cur) {
+      if (cur >= 0) amax_commit(mx, out_amax + cur);
+      cur = img, mx = 0;
+    }
+    mx = max(mx, mxb[mb]);
+  }
+  if (cur >= 0) amax_commit(mx, out_amax + cur);
 }
 
 // WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
@@ -224,8 +258,18 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const int m0 = bx * TM, n0 = by * SBN;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
-  unsigned am = *p.a_amax0;
-  if (p.a_amax1) am = max(am, *p.a_amax1);
+  const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
+  __shared__ float ia_sh[128];  // per-image scales: 1 / scale of every tile row's image
+  unsigned am;
+  if (p.per_image) {  // the scale of the image this thread's staged row belongs to
+    const int img = min((m0 + srow) / p.HW, p.B - 1);
+    am = p.a_amax0[img];
+    if (p.a_amax1) am = max(am, p.a_amax1[img]);
+    ia_sh[srow] = pow2f(-scale_exp(am));
+  } else {
+    am = *p.a_amax0;
+    if (p.a_amax1) am = max(am, *p.a_amax1);
+  }
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
   const float sa = pow2f(ka);
   // zero rows 128..143 of every chunk plane of both buffers: 2 * 2 * 4 * 16 = 256 vectors
@@ -235,7 +279,6 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
                               (128 + r) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
   const bool a_ok = (srow < TM) & (m0 + srow < p.M);
   unsigned amask[RB];  // per 16-row block: one bit per tap for the shifted pixel's validity
 #pragma unroll
@@ -385,7 +428,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
   }
 
-  conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw));
+  if (p.per_image) __syncthreads();  // ia_sh (a workgroup with an empty K range has not passed a barrier yet)
+  conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), nullptr,
+                  p.per_image ? ia_sh : nullptr, p.out_amax);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -437,8 +482,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int m0 = bx * TM, n0 = by * BNW;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
-  unsigned am = *p.a_amax0;
-  if (p.a_amax1) am = max(am, *p.a_amax1);
+  const int img = p.per_image ? m0 / p.HW : 0;  // a tile is R rows of ONE image: one scale, one output slot
+  unsigned am = p.a_amax0[img];
+  if (p.a_amax1) am = max(am, p.a_amax1[img]);
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
   const float sa = pow2f(ka);
   const int halo = p.pad * p.W;
@@ -668,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       }
     }
   }
-  conv16_epilogue(p, acc, m0, wm * MB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), FAST ? pre : nullptr);
+  conv16_epilogue(p, acc, m0, wm * MB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), FAST ? pre : nullptr, nullptr,
+                  p.out_amax ? p.out_amax + img : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1205,6 +1252,9 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.taps = a->ksize * a->ksize;
   p.a_split = a_split;
   p.a0_up = a->a0_up ? 1 : 0;
+  p.per_image = a->amax_per_image ? 1 : 0;
+  RAC_REQUIRE(!p.per_image || (p.split_k == 1 && (p.HW > 128 || p.HW % 16 == 0)),
+              "rac_conv2d_fwd_split: amax_per_image needs split_k 1 and H*W a multiple of 16");
   RAC_REQUIRE(!p.a0_up || (p.HW > 128 && a->H % 2 == 0 && a->W % 2 == 0),
               "rac_conv2d_fwd_split: a0_up needs even H, W and a map larger than a 128-pixel tile");
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");

@@ -142,7 +142,7 @@ class _Decoder(nn.Module):
                 d = layer(d, None, 1, groups)
         d = up_conv(self.upc5[0], d, skip[0])
         head = self.upc5[1]
-        return ops.ConvTHead.apply(d, head.weight, head.bias)
+        return ops.ConvTHead.apply(d, head.weight, head.bias, frozen)
 
 
 class _LstmCell(nn.Module):
@@ -183,8 +183,9 @@ class _NormLstmCell(nn.Module):
     def forward(self, x, state):
         h_prev, c_prev = state
         ci, ch = self.ih_gates[0], self.hh_gates[0]
-        g_ih = self.ih_gates[1](ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE))
-        g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE))
+        frozen = not torch.is_grad_enabled()
+        g_ih = self.ih_gates[1](ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, frozen))
+        g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, frozen))
         c_raw, act = ops.NormCellCore.apply(g_ih, g_hh, c_prev)
         c = self.c_norm(c_raw)
         h = ops.LstmOut.apply(act, c)
@@ -242,8 +243,9 @@ class _GaussianConvLSTM(_ConvLSTM):
                     t.requires_grad_(self.mu_net.weight.requires_grad)
             mu, logvar = ops.GaussHead.apply(h, head[0], head[1], not torch.is_grad_enabled())
         else:
-            mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE)
-            logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE)
+            frozen = not torch.is_grad_enabled()
+            mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE, frozen)
+            logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE, frozen)
         z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
         return z, mu, logvar
 

@@ -203,10 +203,11 @@ def _conv_launch(mode, a0, a1, w, out0, out1, B, H, W, ksize, Cin, Cout, act, sp
 
 
 def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                 allow_split=True, want_slabs=False, groups=1):
+                 allow_split=True, want_slabs=False, groups=1, frozen=False):
     """FWD conv over the virtual concat [x0 | x1].  Returns the (B,H,W,Cout) map, or
     (slabs, n_slabs, slab_stride) when `want_slabs` (raw partial sums, no bias/epilogue).
-    `groups`: `stats` is [groups][2][Cout], one statistics group per B/groups images."""
+    `groups`: `stats` is [groups][2][Cout], one statistics group per B/groups images.
+    `frozen`: K is never split (the split count follows the batch size, and with it the order of the fp32 sums)."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
     C1 = x1.shape[3] if x1 is not None else 0
@@ -216,7 +217,7 @@ def conv_forward(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=N
     M = B * H * W
     nchunks = k * k * _cdiv(Cin, 32)
     fused = act != ACT_NONE or scale is not None
-    split = plan_split_k(M, Cout, nchunks) if (allow_split and not fused) else 1
+    split = plan_split_k(M, Cout, nchunks) if (allow_split and not fused and not frozen) else 1
     if want_slabs:
         slabs = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
         if split == 1:
@@ -317,41 +318,48 @@ SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "64"))
 
 _AMAX = {"buf": None, "used": 0, "one": None}
-_AMAX_SLOTS = 1 << 14
+_AMAX_SLOTS = 1 << 20
 
 
-def _amax_arena(device):
+def _amax_take(device, n: int) -> torch.Tensor:
+    """`n` zeroed slots (an int32 view) of the arena; a full arena is replaced by a fresh zeroed one (tensors that still
+    carry slots of the old one keep it alive)."""
     buf = _AMAX["buf"]
-    if buf is None or buf.device != torch.device(device) or _AMAX["used"] >= _AMAX_SLOTS:
-        buf = _AMAX["buf"] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.int32)
+    if buf is None or buf.device != torch.device(device) or _AMAX["used"] + n > _AMAX_SLOTS:
+        buf = _AMAX["buf"] = torch.zeros(max(_AMAX_SLOTS, n), device=device, dtype=torch.int32)
         _AMAX["used"] = 0
-    return buf
-
-
-def amax_of(x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Device slot (1-element int32 view) holding the bit pattern of max |x| over x0 (and x1)."""
-    buf = _amax_arena(x0.device)
     k = _AMAX["used"]
-    _AMAX["used"] = k + 1
-    slot = buf[k:k + 1]
+    _AMAX["used"] = k + n
+    return buf[k:k + n]
+
+
+def amax_of(x0: torch.Tensor, x1: Optional[torch.Tensor] = None, per_image: bool = False) -> torch.Tensor:
+    """Device slot (1-element int32 view) holding the bit pattern of max |x| over x0 (and x1); `per_image`: one slot
+    per leading index of x0 (B slots: the frozen model scales every image by its own maximum)."""
+    if per_image:
+        assert x1 is None
+        slot = _amax_take(x0.device, x0.shape[0])
+        call("rac_absmax_rows", ptr(x0), x0.shape[0], x0.numel() // x0.shape[0], ptr(slot), stream_ptr())
+        return slot
+    slot = _amax_take(x0.device, 1)
     call("rac_absmax", ptr(x0), x0.numel(), ptr(x1), x1.numel() if x1 is not None else 0, ptr(slot), stream_ptr())
     return slot
 
 
-def amax_slot(device) -> torch.Tensor:
-    """A zeroed slot for a kernel that folds the max |v| of its output in (`*_amax` output arguments of the C ABI)."""
-    buf = _amax_arena(device)
-    k = _AMAX["used"]
-    _AMAX["used"] = k + 1
-    return buf[k:k + 1]
+def amax_slot(device, n: int = 1) -> torch.Tensor:
+    """Zeroed slot(s) for a kernel that folds the max |v| of its output in (`*_amax` output arguments of the C ABI);
+    n = B: one per image."""
+    return _amax_take(device, n)
 
 
-def amax_one(device) -> torch.Tensor:
-    """Slot for tensors bounded by 1 in magnitude (ConvLSTM hidden states h = o * tanh(c); frames and masks)."""
+def amax_one(device, n: int = 1) -> torch.Tensor:
+    """Slot(s) for tensors bounded by 1 in magnitude (ConvLSTM hidden states h = o * tanh(c); frames and masks)."""
     one = _AMAX["one"]
-    if one is None or one.device != torch.device(device):
-        one = _AMAX["one"] = torch.tensor([0x3F800000], device=device, dtype=torch.int32)
-    return one
+    if one is None or one.device != torch.device(device) or one.numel() < n:
+        one = _AMAX["one"] = torch.full((max(n, 1024),), 0x3F800000, device=device, dtype=torch.int32)
+    view = one[:n]
+    view._rac_bound1 = True  # amax_for hands out as many of these as the consumer's granularity needs
+    return view
 
 
 def tag_amax(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
@@ -372,10 +380,14 @@ def retag(t, slot):
     return t
 
 
-def amax_for(t: torch.Tensor) -> torch.Tensor:
+def amax_for(t: torch.Tensor, per_image: bool = False) -> torch.Tensor:
+    """The tensor's slot (per_image: its B slots), measured now unless a producer left a tag of that kind."""
     slot = getattr(t, "_rac_amax", None)
-    if slot is None:
-        slot = amax_of(t)
+    want = t.shape[0] if per_image else 1
+    if slot is not None and getattr(slot, "_rac_bound1", False):
+        return amax_one(t.device, want)  # |t| <= 1 whatever the granularity
+    if slot is None or slot.numel() != want:
+        slot = amax_of(t, per_image=per_image)
         t._rac_amax = slot
     return slot
 
@@ -524,11 +536,12 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
 
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
-                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0, a0_up=0):
+                  shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0, a0_up=0,
+                  per_image=False):
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
                     out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
-                    stats_rows=stats_rows, a0_up=a0_up, reserved=0)
+                    stats_rows=stats_rows, a0_up=a0_up, amax_per_image=1 if per_image else 0)
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -550,11 +563,18 @@ def is_zero(t) -> bool:
     return t is not None and getattr(t, "_rac_zero", False)
 
 
+def per_image_ok(H: int, W: int) -> bool:
+    """Map sizes whose per-image scales the split kernels take (whole 16-row blocks per image)."""
+    return H * W > 128 or (H * W) % 16 == 0
+
+
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                       want_slabs=False, groups=1, x0_up=False):
+                       want_slabs=False, groups=1, x0_up=False, per_image=False):
     """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel.
-    An all-zero x1 (`is_zero`) is skipped: the conv runs over the x0 channels of the same weight parts."""
+    An all-zero x1 (`is_zero`) is skipped: the conv runs over the x0 channels of the same weight parts.
+    `per_image` (the frozen model): every image is scaled by its own max |x| and K is never split, so an image's
+    result is the same bits whatever else is in the batch and however large the batch is."""
     _require_cuda(x0)
     B, H, W, C0 = x0.shape
     if x0_up:  # x0 is the half-resolution tensor; its nearest 2x upsampling is the conv's first source
@@ -571,19 +591,21 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     x0 = x0 if x0.is_contiguous() else x0.contiguous()
     if x1 is not None and not x1.is_contiguous():
         x1 = x1.contiguous()
-    a0 = amax_for(x0)
-    a1 = amax_for(x1) if x1 is not None else None
+    a0 = amax_for(x0, per_image)
+    a1 = amax_for(x1, per_image) if x1 is not None else None
     pw, wslot = weight_parts(weight)
-    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, w_cin=w_cin, a0_up=1 if x0_up else 0)
+    kw = dict(B=B, H=H, W=W, k=k, Cin=Cin, Cout=Cout, C0=C0, w_cin=w_cin, a0_up=1 if x0_up else 0,
+              per_image=per_image)
     if want_slabs:
-        split = plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
+        split = 1 if per_image else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
         out = torch.empty((split, B, H, W, Cout), device=x0.device, dtype=torch.float32)
         _split_launch(x0, x1, a0, a1, pw, wslot, out, split_k=split, slab_stride=M * Cout, **kw)
         return out, split, M * Cout
     out = torch.empty((B, H, W, Cout), device=x0.device, dtype=torch.float32)
     fused = act != ACT_NONE or scale is not None
-    split = 1 if fused else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
-    slot = amax_slot(x0.device)  # the kernel that writes `out` also leaves its max |v| for the next conv
+    split = 1 if (fused or per_image) else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
+    # the kernel that writes `out` also leaves its max |v| (per image: maxima) for the next conv
+    slot = amax_slot(x0.device, B if per_image else 1)
     if split == 1:
         _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, stats=stats,
                       stats_rows=(M // groups if (groups > 1 and stats is not None) else 0), out_amax=slot, **kw)
@@ -812,7 +834,8 @@ class ConvBias(torch.autograd.Function):
         ctx.pad32 = (x1 is None and x0.shape[3] == ci + (-ci) % 32 and x0.shape[3] != ci + pad4(ci) and act == ACT_NONE)
         if ctx.pad32:
             # TileCat padded the input to whole 32-channel chunks so that the conv runs split-precision
-            y = conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias)
+            y = conv_forward_split(x0, None, padded_weight(weight, x0.shape[3]), bias,
+                                   per_image=frozen and per_image_ok(x0.shape[1], x0.shape[2]))
             if not frozen:
                 ctx.save_for_backward(x0, None, weight, bias, None)
                 ctx.act, ctx.padded, ctx.split = act, False, False
@@ -824,10 +847,12 @@ class ConvBias(torch.autograd.Function):
         # the split-precision kernels where the shape allows (the NormConvLSTM gate convs)
         ctx.split = (SPLIT_GEMM and act == ACT_NONE and not padded and x0.shape[3] % 32 == 0 and weight.shape[0] >= 128
                      and split_supported(H, W, weight.shape[2], ci, weight.shape[0], x0.shape[3] if x1 is not None else 0))
+        if ctx.split and frozen and not per_image_ok(H, W):
+            ctx.split = False
         if ctx.split:
-            y = conv_forward_split(x0, x1, w, bias)
+            y = conv_forward_split(x0, x1, w, bias, per_image=frozen)
         else:
-            y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE))
+            y = conv_forward(x0, x1, w, bias, act=act, allow_split=(act == ACT_NONE), frozen=frozen)
         ctx.save_for_backward(x0, x1, weight, bias, y if act != ACT_NONE else None)
         ctx.act, ctx.padded = act, padded
         ctx.amax = (amax_tag(x0), amax_tag(x1))
@@ -874,7 +899,8 @@ def gauss_head_ok(h_shape, weight: torch.Tensor) -> bool:
     """The merged mu | logvar head runs split-precision: channel counts in whole 32-chunks, a supported map size."""
     B, H, W, g = h_shape
     n2, ci, k, _ = weight.shape
-    return SPLIT_GEMM and ci == g and g % 32 == 0 and n2 % 32 == 0 and split_supported(H, W, k, g, n2, 0)
+    return (SPLIT_GEMM and ci == g and g % 32 == 0 and n2 % 32 == 0 and split_supported(H, W, k, g, n2, 0)
+            and per_image_ok(H, W))
 
 
 class GaussHead(torch.autograd.Function):
@@ -891,13 +917,13 @@ class GaussHead(torch.autograd.Function):
         mu = torch.empty((B, H, W, z), device=h.device, dtype=torch.float32)
         lv = torch.empty_like(mu)
         k = weight.shape[2]
-        split = plan_split_k(M, n2, k * k * _cdiv(g, 32), tile128_only=True)
+        split = 1 if frozen else plan_split_k(M, n2, k * k * _cdiv(g, 32), tile128_only=True)
         if split > 1:
             slabs, split, stride = conv_forward_split(h, None, weight, want_slabs=True)
             call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(bias), ptr(mu), ptr(lv), M, n2, z, None, None,
                  stream_ptr())
         else:
-            y = conv_forward_split(h, None, weight, bias)
+            y = conv_forward_split(h, None, weight, bias, per_image=frozen)
             call("rac_slab_reduce2", ptr(y), 1, M * n2, None, ptr(mu), ptr(lv), M, n2, z, None, None, stream_ptr())
         if not frozen:
             ctx.save_for_backward(h, weight, bias)
@@ -930,7 +956,7 @@ class ConvTHead(torch.autograd.Function):
     weight is the ConvTranspose parameter (Cin_w, Cout_w, 3, 3); its forward is the DGRAD form."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, frozen=False):
         B, H, W, Ci = x.shape
         Ciw, Cow, k, _ = weight.shape
         assert Ci == Ciw
@@ -941,8 +967,9 @@ class ConvTHead(torch.autograd.Function):
             # Cow rows zero-padded to one 32-column tile; only the Cow real columns are computed into y
             pw, wslot = weight_parts(padded_weight(weight, 32), transposed=True)
             x = x if x.is_contiguous() else x.contiguous()
-            _split_launch(x, None, amax_for(x), None, pw, wslot, y, B=B, H=H, W=W, k=k, Cin=Ciw, Cout=Cow, C0=Ciw,
-                          act=ACT_SIGMOID, bias=bias)
+            per_image = frozen and per_image_ok(H, W)
+            _split_launch(x, None, amax_for(x, per_image), None, pw, wslot, y, B=B, H=H, W=W, k=k, Cin=Ciw, Cout=Cow,
+                          C0=Ciw, act=ACT_SIGMOID, bias=bias, per_image=per_image)
         else:
             conv_raw(DGRAD, x, None, weight, y, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, act=ACT_SIGMOID, bias=bias)
         ctx.save_for_backward(x, weight, bias, y)
@@ -970,7 +997,7 @@ class ConvTHead(torch.autograd.Function):
                          split_k=0)
         if bias.requires_grad:
             bias_grad_acc(d, bias)
-        return dx, None, None
+        return dx, None, None, None
 
 
 class VggLayer(torch.autograd.Function):
@@ -994,7 +1021,9 @@ class VggLayer(torch.autograd.Function):
             c0 = x0.shape[3]
             if (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT
                     and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, c0 if x1 is not None else 0)):
-                y = conv_forward_split(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
+                # (no tape through the folded BatchNorm: this is the frozen model, scaled image by image)
+                y = conv_forward_split(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift,
+                                       per_image=per_image_ok(x0.shape[1], x0.shape[2]))
             else:
                 y = conv_forward(x0, x1, weight, None, act=ACT_LEAKY, scale=scale, shift=shift)
             ctx.mark_non_differentiable(y)  # frozen-model path (CEM / eval): no backward through folded BatchNorm
@@ -1116,9 +1145,9 @@ class TileCat(torch.autograd.Function):
         if SPLIT_GEMM and ct >= 128 and whole and c0 % 32 == 0:
             pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
-        slot = amax_slot(m0.device)
+        slot = amax_slot(m0.device, B if frozen else 1)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
-             ptr(out), B, H * W, ptr(slot), stream_ptr())
+             ptr(out), B, H * W, ptr(slot), 1 if frozen else 0, stream_ptr())
         tag_amax(out, slot)
         ctx.meta = (sum(ns), c0, c1)
         return out
@@ -1146,7 +1175,7 @@ def embed_frozen_ok(vs, h, z, weight) -> bool:
     cz = z.shape[3] if z is not None else 0
     cs = nv + cz + (-(nv + cz)) % 32
     return (SPLIT_GEMM and g % 32 == 0 and weight.shape[1] == nv + g + cz and weight.shape[0] >= 128
-            and split_supported(H, W, weight.shape[2], g + cs, weight.shape[0], g))
+            and split_supported(H, W, weight.shape[2], g + cs, weight.shape[0], g) and per_image_ok(H, W))
 
 
 def embed_frozen(vs, h, z, weight, bias) -> torch.Tensor:
@@ -1160,10 +1189,10 @@ def embed_frozen(vs, h, z, weight, bias) -> torch.Tensor:
     pad = (-(nv + cz)) % 32
     vs3 = vs + [None] * (3 - len(vs))
     small = torch.empty((B, H, W, nv + cz + pad), device=h.device, dtype=torch.float32)
-    slot = amax_slot(h.device)
+    slot = amax_slot(h.device, B)
     call("rac_tilecat_fwd", ptr(vs3[0]), vs3[0].shape[1] if vs3[0] is not None else 0, ptr(vs3[1]),
          vs3[1].shape[1] if vs3[1] is not None else 0, ptr(vs3[2]), vs3[2].shape[1] if vs3[2] is not None else 0,
-         None, 0, ptr(z), cz, pad, ptr(small), B, H * W, ptr(slot), stream_ptr())
+         None, 0, ptr(z), cz, pad, ptr(small), B, H * W, ptr(slot), 1, stream_ptr())
     tag_amax(small, slot)
 
     def build():
@@ -1173,7 +1202,7 @@ def embed_frozen(vs, h, z, weight, bias) -> torch.Tensor:
             parts.append(torch.zeros((w.shape[0], pad, w.shape[2], w.shape[3]), device=w.device, dtype=w.dtype))
         return torch.cat(parts, 1).contiguous(memory_format=torch.channels_last)
     w2 = _derived(weight, f"_rac_reordered_{nv}_{cz}_{pad}", build)
-    return conv_forward_split(h, small, w2, bias)
+    return conv_forward_split(h, small, w2, bias, per_image=True)
 
 
 class LstmCell(torch.autograd.Function):
@@ -1187,10 +1216,13 @@ class LstmCell(torch.autograd.Function):
         # under torch.no_grad(), and grad mode is always off inside forward()
         need_bwd = grad_mode and any(ctx.needs_input_grad)
         ctx.split = SPLIT_GEMM and split_supported(H, W, weight.shape[2], 2 * g, 4 * g, g)
+        frozen = not grad_mode  # no tape: scales per image, K never split (batch-invariant rollouts)
+        if ctx.split and frozen and not per_image_ok(H, W):
+            ctx.split = False
         if ctx.split:
-            slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True)
+            slabs, n_slabs, stride = conv_forward_split(x, h_prev, weight, want_slabs=True, per_image=frozen)
         else:
-            slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True)
+            slabs, n_slabs, stride = conv_forward(x, h_prev, weight, None, want_slabs=True, frozen=frozen)
         h = torch.empty_like(x)
         c = torch.empty_like(x)
         act = torch.empty((B, H, W, 4 * g), device=x.device, dtype=torch.float32) if need_bwd else None
@@ -1371,7 +1403,8 @@ def vgg_up_frozen_ok(x_low, skip, weight) -> bool:
 
 def vgg_up_frozen(x_low, skip, weight, scale, shift) -> torch.Tensor:
     """LeakyReLU(BatchNorm_eval(conv3x3([UpsamplingNearest2d(2)(x_low) | skip]))) without the upsampled tensor."""
-    return conv_forward_split(x_low, skip, weight, None, act=ACT_LEAKY, scale=scale, shift=shift, x0_up=True)
+    return conv_forward_split(x_low, skip, weight, None, act=ACT_LEAKY, scale=scale, shift=shift, x0_up=True,
+                              per_image=True)
 
 
 def first_layer_ok(img, mask, weight) -> bool:
@@ -1386,9 +1419,9 @@ def first_layer_frozen(img, zero_mask, mask, weight, scale, shift) -> torch.Tens
     B, _, H, W = img.shape
     Cm = mask.shape[1] if mask is not None else 0
     out = torch.empty((B, H, W, 64), device=img.device, dtype=torch.float32)
-    slot = amax_slot(img.device)
+    slot = amax_slot(img.device, B)  # one maximum per image: the frozen model's scales are per image
     call("rac_first_layer_fwd", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(weight_mem(weight.detach())), ptr(scale),
-         ptr(shift), ACT_LEAKY, ptr(out), ptr(slot), B, H, W, 64, stream_ptr())
+         ptr(shift), ACT_LEAKY, ptr(out), ptr(slot), 1, B, H, W, 64, stream_ptr())
     return tag_amax(out, slot)
 
 

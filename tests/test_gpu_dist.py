@@ -71,8 +71,8 @@ def _worker(rank, world, port, q):
         dbg_1 = pol.traj_sampler.generate_model_rollouts(prob["actions"].clone(), start, goal, ret_obs=True,
                                                          ret_step_cost=True)
         ns.cem_shard = True
-        # per-candidate math is batch-independent (eval BN; the operand scales of the split-precision convs are powers
-        # of two): sharded == single rank bit for bit, the appended opt_traj included
+        # per-candidate math is batch-independent by construction (eval BN; the frozen model's split-precision convs take
+        # one operand scale per image and never split K): sharded == single rank bit for bit, opt_traj included
         out["cem_equal"] = bool(np.array_equal(ro_sh["sum_cost"], ro_1["sum_cost"])
                                 and ro_sh["optimal_sum_cost"] == ro_1["optimal_sum_cost"])
         out["debug_equal"] = bool(np.array_equal(dbg_sh["obs"], dbg_1["obs"]) and np.array_equal(dbg_sh["step_cost"], dbg_1["step_cost"])
@@ -80,6 +80,22 @@ def _worker(rank, world, port, q):
         out["dbg"] = [float(np.abs(dbg_sh["obs"] - dbg_1["obs"]).max()),
                       float(np.abs(dbg_sh["step_cost"] - dbg_1["step_cost"]).max() / np.abs(dbg_1["step_cost"]).max()),
                       [int(i) for i in dbg_sh["topk_idx"]], [int(i) for i in dbg_1["topk_idx"]]]
+        # the same at the benchmarked width (g 512 / z 64): 37 candidates in ragged shards and batches of 8 against one
+        # un-sharded pass of all 37 -- per-image operand scales and an unsplit K make a cost independent of its batch
+        cfg5, ns5 = _ns(dev, g_dim=512, z_dim=64, candidates_batch_size=8)
+        cfg5.g_dim, cfg5.z_dim = 512, 64
+        big = SVGConvModel(ns5)
+        big.load_state_dict({k: v.clone() for k, v in orc.make_weights(cfg5, seed=9, action_gain=200.0).items()})
+        big.eval()
+        prob5 = syn.synth_cem_problem(seed=6, N=37, T=3, goal_blend=0.15)
+        pol5 = CEMPolicy(ns5, big, horizon=4, opt_iter=1, action_candidates=37, topk=5, init_std=0.03)
+        s5, g5 = State(img=prob5["start_img"]), DemoGoalState(imgs=prob5["goal_imgs"], masks=prob5["goal_masks"])
+        c_sh = pol5.traj_sampler.generate_model_rollouts(prob5["actions"].clone(), s5, g5)["sum_cost"]
+        ns5.cem_shard, ns5.candidates_batch_size = False, 37
+        c_1 = pol5.traj_sampler.generate_model_rollouts(prob5["actions"].clone(), s5, g5)["sum_cost"]
+        out["g512_equal"] = bool(np.array_equal(c_sh, c_1) and np.unique(c_1).size > 30)
+        del big, pol5
+        torch.cuda.empty_cache()
         torch.manual_seed(100 + rank)  # different RNG per rank: the candidate draw must still agree (rank-0 broadcast)
         out["action"] = pol.get_action(start, goal, 0, 0).tolist()
 
@@ -127,6 +143,7 @@ def test_ranks_sharing_one_gpu(world):
     for r in res:
         assert "error" not in r, r.get("error")
     assert all(r["cem_equal"] and r["debug_equal"] for r in res), [(r["cem_equal"], r["debug_equal"], r["dbg"]) for r in res]
+    assert all(r["g512_equal"] for r in res)
     assert all(r["action"] == res[0]["action"] for r in res)
     # identical inputs exclude slope flips; what is left is the all-reduce's summation order
     assert all(r["ddp_err"] < 1e-5 for r in res), res

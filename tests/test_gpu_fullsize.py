@@ -185,3 +185,118 @@ def test_cem_rollouts_cfg3_full_size(dev, ra):
     for i in np.nonzero(resolvable)[0]:
         assert got[order[i]] > got[order[i + 1]]
     print(f"cfg3 full size ({'ra' if ra else 'vanilla'}): sum_cost rel err {err:.1e}, min gap {gaps.min():.1e}")
+
+
+@pytest.mark.parametrize("ra", [False, True])
+def test_cem_costs_do_not_depend_on_batching(dev, ra):
+    """A candidate's cost must not depend on `candidates_batch_size` or on which other candidates share its pass (the
+    reference's per-candidate arithmetic is batch-independent, trajectory_sampler.py:123-174): the frozen model scales
+    every image by its own maximum and never splits K, so sum_cost is the same BITS for one pass of 1000, five of 200,
+    ragged batches of 137, the candidates in reverse order, and a lone candidate.  g 512 / z 64, 4 model steps."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    flags = FLAGSETS["ra"] if ra else FLAGSETS["vanilla"]
+    N, T = 1000, 4
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=2, candidates_batch_size=N, sample_mean=True,
+                  reward_type="dontcare" if ra else "dense", topk=5, **flags)
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=6, N=N, T=T, with_robot=ra, goal_blend=0.15)
+    model = build_model(cfg, sd, dev)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+
+    def run(per, idx=None):
+        ns = ns_for(cfg, dev, candidates_batch_size=per)
+        acts = prob["actions"] if idx is None else prob["actions"][idx]
+        rm = None
+        if ra:
+            rm = FakeRobotModel(prob["states"] if idx is None else prob["states"][:, idx],
+                                prob["masks"] if idx is None else prob["masks"][:, idx])
+        return TrajectorySampler(ns, model, robot_model=rm).generate_model_rollouts(acts.clone(), start, goal)["sum_cost"]
+
+    full = run(1000)
+    assert np.all(np.isfinite(full)) and np.unique(full).size > 900
+    for per in (200, 137):
+        assert np.array_equal(run(per), full), per
+    rev = np.arange(N - 1, -1, -1)
+    assert np.array_equal(run(1000, rev), full[rev])
+    few = np.array([977, 3, 500])
+    assert np.array_equal(run(3, few), full[few])
+    assert np.array_equal(run(1, few[:1]), full[few[:1]])
+
+
+ELITE_SLOTS = [17, 923, 401, 655, 88, 760, 333, 512]  # where the graded candidates sit among the 1000
+
+
+def demo_problem(ra, N, T, seed=6):
+    """A planning problem whose elites are well separated (K / K+1 cost gap >= 1e-3): candidate N of the
+    draw is the DEMONSTRATION -- the planner's per-step goal images are the model's own rollout of it (how the reference
+    is driven: DemoGoalState.imgs holds one goal frame per step, trajectory_sampler.py:154) -- and the candidates at
+    ELITE_SLOTS are graded blends demo + 0.1 k (candidate - demo), k = 1..8 (with the demo's robot states / masks)."""
+    prob = syn.synth_cem_problem(seed=seed, N=N + 1, T=T, with_robot=ra, goal_blend=0.15)
+    acts = prob["actions"]
+    demo = acts[N].clone()
+    for k, j in enumerate(ELITE_SLOTS, start=1):
+        acts[j] = demo + 0.1 * k * (acts[j] - demo)
+        if ra:
+            prob["states"][:, j] = prob["states"][:, N]
+            prob["masks"][:, j] = prob["masks"][:, N]
+    return prob, demo
+
+
+@pytest.mark.parametrize("ra", [False, True])
+def test_cem_elite_indices_cfg3_full_size(dev, ra):
+    """north_star: "CEM elite indices are bit-exact" -- at the benchmarked size.  1000 candidates x 14 steps in ONE pass
+    on the GPU; the oracle then re-rolls the GPU's OWN top 32 plus 32 random others: sum_cost <= 1e-5 relative, the
+    oracle's top 5 (indices AND order) equal the GPU's, and the margins that make this a statement about all 1000
+    candidates are asserted: rank 5 / rank 6 gap >= 1e-3 relative, rank 5 / rank 33 gap far above the error bound."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    flags = FLAGSETS["ra"] if ra else FLAGSETS["vanilla"]
+    N, T, K = 1000, 14, 5
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=2, candidates_batch_size=N, sample_mean=True,
+                  reward_type="dontcare" if ra else "dense", topk=K, **flags)
+    sd = orc.make_weights(cfg, seed=9, action_gain=1000.0)
+    prob, demo = demo_problem(ra, N, T)
+    model = build_model(cfg, sd, dev)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    sl = lambda key, idx: prob[key][:, idx] if ra else None
+    # the demonstration's frames (GPU rollout of candidate N) become the per-step goal images, as uint8 like a camera's
+    one = TrajectorySampler(ns_for(cfg, dev), model,
+                            robot_model=FakeRobotModel(sl("states", [N]), sl("masks", [N])) if ra else None)
+    placeholder = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    obs = one.generate_model_rollouts(demo[None].clone(), start, placeholder, ret_obs=True)["obs"][0]  # (T,3,H,W)
+    goal_imgs = [np.clip(np.rint(obs[t].transpose(1, 2, 0) * 255), 0, 255).astype(np.uint8) for t in range(T)]
+    goal_masks = [prob["goal_masks"][0]] * T
+    goal = DemoGoalState(imgs=goal_imgs, masks=goal_masks)
+    cand = np.arange(N)
+    sampler = TrajectorySampler(ns_for(cfg, dev), model,
+                                robot_model=FakeRobotModel(sl("states", cand), sl("masks", cand)) if ra else None)
+    got = sampler.generate_model_rollouts(prob["actions"][:N].clone(), start, goal)["sum_cost"]
+    assert got.shape == (N,) and np.all(np.isfinite(got))
+    order = np.argsort(-got, kind="stable")
+    top = order[:32]
+    rest = np.random.RandomState(0).choice(order[32:], 32, replace=False)
+    idx = np.concatenate([top, rest])
+    sub = orc.Cfg(**{**cfg.__dict__, "candidates_batch_size": len(idx)})
+    ref = orc.cem_rollouts(sd, sub, prob["actions"][idx], prob["start_img"], goal_imgs, goal_masks,
+                           sl("states", idx), sl("masks", idx))["sum_cost"]
+    scale = np.abs(ref).max()
+    abs_err = np.abs(got[idx] - ref)
+    err = float(abs_err.max() / scale)                    # the other tests' convention: relative to the largest cost
+    err_own = float((abs_err[:32] / np.abs(ref[:32])).max())  # each of the GPU's top 32 against ITS OWN cost
+    c = got[order]
+    gaps = (c[:K] - c[1:K + 1]) / np.abs(c[1:K + 1])      # rank 1/2 ... rank K/K+1, relative to the worse of the pair
+    far = float((c[K - 1] - c[31]) / abs(c[31]))
+    print(f"cfg3 elites ({'ra' if ra else 'vanilla'}): top-{K} {list(order[:K])} costs {' '.join(f'{v:.5g}' for v in c[:K + 1])}; "
+          f"sum_cost err {err:.1e} of max |cost| {scale:.4g}, {err_own:.1e} of each elite's own cost; "
+          f"relative gaps {' '.join(f'{g:.1e}' for g in gaps)}; rank {K} / rank 32 gap {far:.1e}")
+    assert err < 1e-5, err
+    assert err_own < 1e-4, err_own            # north_star's tolerance, on costs that measure small frame differences
+    assert gaps[K - 1] >= 1e-3, gaps          # the fixture keeps the K / K+1 gap the survey asks for
+    assert (c[:K] - c[1:K + 1]).min() > 100 * abs_err[:32].max() and c[K - 1] - c[31] > 100 * abs_err.max()
+    ref_order = idx[np.argsort(-ref, kind="stable")]
+    assert list(ref_order[:K]) == list(order[:K]), (ref_order[:K], order[:K])
+    # and through the policy's own selection (cem.py:96-97): torch.topk over the full cost vector
+    import torch as _t
+    assert list(_t.from_numpy(got).topk(K)[1].numpy()) == list(order[:K])

@@ -210,7 +210,8 @@ def test_first_layer_from_planes(dev, B, H, W, Cm, zero):
     out = ops.first_layer_frozen(img.to(dev), None if zm is None else zm.to(dev), None if mask is None else mask.to(dev),
                                  wd, scale.to(dev), shift.to(dev))
     assert relerr(from_map(out), ref) < 2e-6
-    assert int(ops.amax_tag(out).item()) == int(out.abs().max().view(torch.int32).item())
+    # one maximum per image (the frozen model scales every image on its own)
+    assert torch.equal(ops.amax_tag(out).cpu(), out.abs().amax((1, 2, 3)).view(torch.int32).cpu())
 
 
 @pytest.mark.parametrize("B,h,w,C0,C1,Cout", [(2, 8, 8, 64, 64, 64), (3, 32, 32, 64, 64, 64), (2, 16, 16, 128, 128, 128),
@@ -226,7 +227,7 @@ def test_conv_reads_half_resolution_source(dev, B, h, w, C0, C1, Cout):
     assert ops.vgg_up_frozen_ok(d, sk, wt)
     got = ops.vgg_up_frozen(d, sk, wt, scale, shift)
     up = ops.Upsample2.apply(d)
-    want = ops.conv_forward_split(up, sk, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift)
+    want = ops.conv_forward_split(up, sk, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift, per_image=True)
     assert torch.equal(got, want)
     ref = F.leaky_relu(F.conv2d(torch.cat([F.interpolate(from_map(d).double(), scale_factor=2, mode="nearest"),
                                            from_map(sk).double()], 1), wt.cpu().double(), None, 1, 1)
@@ -511,6 +512,42 @@ def test_weight_frag_split(dev, shape):
     a, b = rnd(6, 4096, scale=3.0).to(dev), rnd(7, 512, scale=5.0).to(dev)
     s2 = ops.amax_of(a, b)
     assert int(s2.cpu()) == int(torch.maximum(a.abs().max(), b.abs().max()).cpu().view(torch.int32))
+
+
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,k", [(5, 8, 8, 64, 64, 256, 5), (3, 6, 8, 128, 0, 128, 3), (3, 16, 16, 64, 64, 128, 3),
+                                                  (2, 64, 64, 64, 0, 64, 3), (4, 32, 32, 128, 0, 32, 3)])
+def test_per_image_scales_make_a_conv_batch_invariant(dev, B, H, W, C0, C1, Cout, k):
+    """`per_image` (the frozen model): every image is scaled by its own max |x|, K is never split -> an image's output is
+    the same bits alone, in any batch and at any position in it, even next to images 1e4 times larger; accuracy as the
+    per-tensor form.  Producers leave one maximum per image (conv epilogue, tilecat, rac_absmax_rows)."""
+    from robot_aware_control_amd import ops
+    mags = torch.tensor([1.0, 3e-4, 2e3, 0.07, 11.0])[:B].view(B, 1, 1, 1)
+    x0 = to_map(rnd(61, B, C0, H, W) * mags, dev)
+    x1 = to_map(rnd(62, B, C1, H, W) * mags, dev) if C1 else None
+    wt = cl_weight(rnd(63, Cout, C0 + C1, k, k) * 0.05).to(dev)
+    bias = rnd(64, Cout, scale=0.1).to(dev)
+    full = ops.conv_forward_split(x0, x1, wt, bias, per_image=True)
+    slots = ops.amax_tag(full)
+    assert slots.numel() == B
+    assert torch.equal(slots.cpu(), full.abs().amax((1, 2, 3)).view(torch.int32).cpu())
+    for order in ([B - 1], [1, 0], list(range(B - 1, -1, -1))):  # alone, a pair, everything reversed
+        idx = torch.tensor(order, device=dev)
+        sub = ops.conv_forward_split(x0[idx].contiguous(), None if x1 is None else x1[idx].contiguous(), wt, bias,
+                                     per_image=True)
+        assert torch.equal(sub, full[idx]), order
+    x = from_map(x0) if x1 is None else torch.cat([from_map(x0), from_map(x1)], 1)
+    ref = F.conv2d(x.double(), wt.cpu().double(), bias.cpu().double(), 1, k // 2)
+    got = from_map(full).double()
+    for b in range(B):  # every image to fp32 level against ITS OWN magnitude
+        assert float((got[b] - ref[b]).abs().max() / ref[b].abs().max()) < 4e-6, b  # (K up to 3200 fp32 sums)
+    # slabs for the ConvLSTM cell: one slab, same bits as the finished conv minus the bias
+    slabs, n, _ = ops.conv_forward_split(x0, x1, wt, want_slabs=True, per_image=True)
+    assert n == 1 and torch.equal(slabs[0], ops.conv_forward_split(x0, x1, wt, None, per_image=True))
+    # measured per image when no producer left a tag
+    plain = x0.clone()
+    assert torch.equal(ops.amax_for(plain, per_image=True).cpu(), plain.abs().amax((1, 2, 3)).view(torch.int32).cpu())
+    h = ops.tag_amax(x0.clone(), ops.amax_one(dev))  # a bound of 1 serves either granularity
+    assert ops.amax_for(h, per_image=True).numel() == B and ops.amax_for(h).numel() == 1
 
 
 def test_weight_parts_refreshed_in_one_launch(dev):
