@@ -41,7 +41,7 @@ SPLIT_PEAK_TFLOPS = F16_MFMA_PEAK_TFLOPS / 3
 F32_MFMA_PEAK_TFLOPS = 157.3
 TRAIN_FWD_GFLOP_PER_SAMPLE_STEP = 36.26   # SURVEY.md 8d, hook-counted on the reference (g512/z64, 64x64, RA flags)
 CEM_FWD_GFLOP_PER_CAND_STEP = 24.46
-CEM_CHECK_IDX = np.r_[0:22, 489:510, 979:1000]  # the 64 candidates the oracle re-rolls (first / middle / last)
+CEM_CHECK_TOP, CEM_CHECK_OTHERS = 32, 32  # the oracle re-rolls the GPU's own top 32 candidates and 32 random others
 
 RA = dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=True,
           reconstruction_loss="dontcare_l1")
@@ -156,7 +156,18 @@ def phase_breakdown(events, steps):
     return {k: round(v, 3) for k, v in out.items()}
 
 
-def bench_train(args, dev, rank, world, distributed):
+def train_workload_name(args, cf):
+    if args.cfg5:
+        base = "SVG train step, per-GPU shard of BASELINE configs[4]: 128x128, bs 8/GPU, n_past 1, n_future 10"
+    elif args.h48:
+        base = "SVG train step at the reference's default frame size 48x64 (side config): bs 16/GPU, n_past 1, n_future 5"
+    else:
+        base = "SVG train step, BASELINE configs[1]: 64x64, bs 16/GPU, n_past 1, n_future 5"
+    gn = ", --lstm_group_norm True (NormConvLSTMCell, side config)" if args.group_norm else ""
+    return f"{base}, g_dim {cf.g_dim}, z_dim {cf.z_dim}, robot-aware flags (dontcare_l1){gn}"
+
+
+def build_train(args, dev):
     cf = namespace(dev, lstm_group_norm=args.group_norm)
     if args.h48:  # the reference's default frame size (config/__init__.py:166-171): 48 x 64 -> 6 x 8 latent maps
         cf.image_height = 48
@@ -166,12 +177,26 @@ def bench_train(args, dev, rank, world, distributed):
     log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
     tr.model.train()
+    return cf, tr
+
+
+def bench_train(args, dev, rank, world, distributed, exact_of=None):
+    """`exact_of`: the result of the split-precision run whose first step (same weights, data, noise) this run repeats
+    with every conv on the exact-fp32 MFMA kernels (ops.SPLIT_GEMM off): a shorter timed region, no CPU check."""
+    cf, tr = build_train(args, dev)
     B, T = cf.batch_size, cf.n_past + cf.n_future
-    want_check = rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.h48 or args.cfg5 or args.group_norm)
+    want_check = (rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.h48 or args.cfg5 or args.group_norm)
+                  and exact_of is None)
     check = None
-    if want_check:  # the very first step runs on recorded noise so that the CPU oracle can repeat it exactly
+    if exact_of is not None and exact_of["check"] is not None:
+        ck = exact_of["check"]
+        tr.model.load_state_dict({k: v.clone() for k, v in ck["sd"].items()})
+        sd0, eps = ck["sd"], ck["eps"]
+        want_check = True
+    elif want_check:  # the very first step runs on recorded noise so that the CPU oracle can repeat it exactly
         sd0 = {k: v.detach().cpu().clone() for k, v in tr.model.state_dict().items()}
         eps = syn.synth_eps(seed=77, steps=T - 1, B=B, z=cf.z_dim, h=cf.image_height // 8, w=cf.image_width // 8)
+    if want_check:
         queue = [e for pair in eps for e in pair]
         tr.model.eps_source = lambda shape: queue.pop(0)
     batches = [syn.synth_video(seed=100 + rank * 1000 + i, T=T, B=B, H=cf.image_height, W=cf.image_width)
@@ -184,7 +209,8 @@ def bench_train(args, dev, rank, world, distributed):
             tr.model.eps_source = None
     torch.cuda.synchronize()
     log("allocator primed")
-    for i in range(args.warmup):
+    steps, warmup = (args.steps, args.warmup) if exact_of is None else (args.exact_steps, 2)
+    for i in range(warmup):
         tr._train_step(batches_dev[i % 2])
         torch.cuda.synchronize()
     g = cf.g_dim
@@ -194,94 +220,129 @@ def bench_train(args, dev, rank, world, distributed):
     tr.phase_events = []
     barrier_sync(distributed)
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         tr._train_step(batches_dev[i % 2])
     barrier_sync(distributed)
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, dev, distributed)
-    log(f"train: {args.steps} steps in {dt:.3f} s")
+    log(f"train{'' if exact_of is None else ' (exact fp32)'}: {steps} steps in {dt:.3f} s")
     ops.PROFILE = None
     events, tr.phase_events = tr.phase_events, None
     starts = [e for n, e in events if n == "start"]
     step_ms = [a.elapsed_time(b) for a, b in zip(starts[:-1], starts[1:])]
-    frames = world * B * T * args.steps
+    frames = world * B * T * steps
     fwd_gflop = 145.03 if args.cfg5 else TRAIN_FWD_GFLOP_PER_SAMPLE_STEP  # 128x128 / 64x64 train forward
     if args.h48:
         fwd_gflop *= 48.0 / 64.0  # every conv's FLOPs scale with the pixel count
     step_flop = 3 * B * (T - 1) * fwd_gflop * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
-    return {"frames_per_s": frames / dt, "ms_per_step": dt / args.steps * 1e3,
+    return {"frames_per_s": frames / dt, "ms_per_step": dt / steps * 1e3,
             "median_ms_per_step": float(np.median(step_ms)) if step_ms else None,
-            "step_tflops_per_gpu": step_flop / (dt / args.steps) / 1e12, "step_tflop": step_flop / 1e12, "kernel": kern,
-            "global_batch": world * B, "phases": phase_breakdown(events, args.steps),
-            "rank_ms_per_step": [x / args.steps * 1e3 for x in per_rank(dt_local, dev, distributed, world)],
-            "check": check, "cf": cf}
+            "step_tflops_per_gpu": step_flop / (dt / steps) / 1e12, "step_tflop": step_flop / 1e12, "kernel": kern,
+            "global_batch": world * B, "phases": phase_breakdown(events, steps), "steps": steps,
+            "rank_ms_per_step": [x / steps * 1e3 for x in per_rank(dt_local, dev, distributed, world)],
+            "check": check, "cf": cf, "workload": train_workload_name(args, cf)}
 
 
-def bench_cem(args, dev, rank, world, distributed):
+class SyntheticRobotInputs:
+    """`predict_batch` of the robot-aware planner for the benchmark: AtlasRobotModel (states and masks of every
+    candidate from one launch, robot_atlas.py) over the synthetic arm atlas of synthetic.synth_arm_atlas -- the MuJoCo
+    renders of the reference's analytical models cannot be produced in this image."""
+
+    def __init__(self, dev):
+        from robot_aware_control_amd.robot_atlas import AtlasRobotModel
+        a = syn.synth_arm_atlas(device=dev)
+        self.model = AtlasRobotModel(a["atlas"], a["x0"], a["y0"], a["dx"], a["dy"], push_height=0.12, device=dev)
+
+    def predict_batch(self, data, thick=True):
+        return self.model.predict_batch(data, thick)
+
+
+def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
+    """`ra`: the robot-aware planner (mask + future mask + robot state into the model, dontcare cost; per-candidate
+    states / masks produced on the device).  `exact_of`: repeat the split-precision run's problem with the same weights
+    on the exact-fp32 MFMA kernels (one timed iteration)."""
     n_per_gpu, horizon = args.cem_candidates, 15
-    cf = namespace(dev, model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
-                   reconstruction_loss="l1", candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
-                   lstm_group_norm=args.group_norm)
+    flags = dict(RA, reward_type="dontcare") if ra else dict(model_use_mask=False, model_use_future_mask=False,
+                                                             model_use_robot_state=False, reconstruction_loss="l1")
+    cf = namespace(dev, candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
+                   lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic", **flags)
     model = SVGConvModel(cf)
+    if exact_of is not None and exact_of["check"] is not None:
+        model.load_state_dict({k: v.clone() for k, v in exact_of["check"]["sd"].items()})
     if distributed:
         dist.broadcast(model.flat_parameters()[0], src=0)
     model.eval()
     N = n_per_gpu * world
     prob = syn.synth_cem_problem(seed=0, N=N, T=horizon - 1)
-    pol = CEMPolicy(cf, model, horizon=horizon, opt_iter=10, action_candidates=N, topk=5, init_std=0.015)
-    start = State(img=prob["start_img"])
+    robot = SyntheticRobotInputs(dev) if ra else None
+    pol = CEMPolicy(cf, model, horizon=horizon, opt_iter=10, action_candidates=N, topk=5, init_std=0.015,
+                    robot_model=robot)
+    start = State(img=prob["start_img"], state=np.array([0.28, 0.0, 0.12, 0.0, 0.0], np.float32),
+                  qpos=np.zeros(5, np.float32))
     goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     g = cf.g_dim
-    log(f"cem: model built, {N} candidates")
+    tag = ("cem-ra" if ra else "cem") + ("" if exact_of is None else " (exact fp32)")
+    log(f"{tag}: model built, {N} candidates")
     small = syn.synth_cem_problem(seed=0, N=N, T=2)
     pol.traj_sampler.generate_model_rollouts(small["actions"], start, goal)  # allocator priming, 2 model steps
-    for _ in range(args.cem_warmup):
+    iters, warm = (args.cem_iters, args.cem_warmup) if exact_of is None else (1, 0)
+    for _ in range(warm):
         pol.traj_sampler.generate_model_rollouts(prob["actions"], start, goal)
-        log("cem warmup iteration done")
+        log(f"{tag} warmup iteration done")
     prof = {"match": (ops.FWD, 5, 2 * g, 4 * g), "events": []}
     ops.PROFILE = prof
     pol.traj_sampler.time_gather = distributed
     gather_s = []
     barrier_sync(distributed)
     t0 = time.perf_counter()
-    for _ in range(args.cem_iters):
+    for _ in range(iters):
         ro = pol.traj_sampler.generate_model_rollouts(prob["actions"], start, goal)
         gather_s.append(pol.traj_sampler.last_gather_s)
     barrier_sync(distributed)
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, dev, distributed)
-    log(f"cem: {args.cem_iters} iterations in {dt:.3f} s")
+    log(f"{tag}: {iters} iterations in {dt:.3f} s")
     ops.PROFILE = None
     pol.traj_sampler.time_gather = False
     assert len(ro["sum_cost"]) == N and np.all(np.isfinite(ro["sum_cost"]))
-    # secondary metric: the whole planner call -- sampling, rollouts, cost gather, top-k, refit --
-    # at a reduced iteration count (the per-iteration cost does not depend on it)
-    pol.optimization_iter = 2
+    it_flop_per_gpu = n_per_gpu * (horizon - 1) * CEM_FWD_GFLOP_PER_CAND_STEP * 1e9
+    kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
+    out = {"rollouts_per_s": N * iters / dt, "s_per_iter": dt / iters, "iters": iters,
+           "tflops_per_gpu": it_flop_per_gpu / (dt / iters) / 1e12, "kernel": kern, "candidates": N,
+           "candidates_batch_size": args.cem_batch, "check": None,
+           "rank_s_per_iter": [x / iters for x in per_rank(dt_local, dev, distributed, world)],
+           "cost_allgather_ms": float(np.mean(gather_s)) * 1e3 if distributed else None, "get_action": None}
+    if exact_of is not None:
+        if exact_of["check"] is not None:
+            out["check_sum_cost"] = ro["sum_cost"][exact_of["check"]["idx"]].copy()
+        return out
+    # secondary metric (SURVEY 8d): the whole planner call at the config's opt_iter -- sampling, robot inputs, rollouts,
+    # cost gather, top-k, refit
+    pol.optimization_iter = args.cem_opt_iter
     barrier_sync(distributed)
     t1 = time.perf_counter()
     pol.get_action(start, goal, 0, 0)
     barrier_sync(distributed)
     dt_ga = max_over_ranks(time.perf_counter() - t1, dev, distributed)
-    it_flop_per_gpu = n_per_gpu * (horizon - 1) * CEM_FWD_GFLOP_PER_CAND_STEP * 1e9
-    kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
-    check = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and N >= 1000 and not args.group_norm:
-        check = {"sd": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "prob": prob,
-                 "gpu_sum_cost": ro["sum_cost"][CEM_CHECK_IDX].copy()}
-    return {"rollouts_per_s": N * args.cem_iters / dt, "s_per_iter": dt / args.cem_iters,
-            "tflops_per_gpu": it_flop_per_gpu / (dt / args.cem_iters) / 1e12, "kernel": kern, "candidates": N,
-            "candidates_batch_size": args.cem_batch, "check": check,
-            "rank_s_per_iter": [x / args.cem_iters for x in per_rank(dt_local, dev, distributed, world)],
-            "cost_allgather_ms": float(np.mean(gather_s)) * 1e3 if distributed else None,
-            "get_action": {"value": N * 2 / dt_ga, "unit": "candidate-rollouts/s", "opt_iter": 2,
-                           "note": "CEMPolicy.get_action end to end (sampling, rollouts, cost gather, top-k, refit)"}}
+    out["get_action"] = {"value": N * args.cem_opt_iter / dt_ga, "unit": "candidate-rollouts/s",
+                         "opt_iter": args.cem_opt_iter, "s_per_call": dt_ga,
+                         "note": "CEMPolicy.get_action end to end (sampling, rollouts, cost gather, top-k, refit)"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and N >= 1000 and not args.group_norm and not ra:
+        # the oracle re-rolls the GPU's OWN best candidates (the elite set must be right, not 64 arbitrary costs) + others
+        order = np.argsort(-ro["sum_cost"], kind="stable")
+        idx = np.concatenate([order[:CEM_CHECK_TOP],
+                              np.random.RandomState(0).choice(order[CEM_CHECK_TOP:], CEM_CHECK_OTHERS, replace=False)])
+        out["check"] = {"sd": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "prob": prob,
+                        "idx": idx, "gpu_sum_cost": ro["sum_cost"][idx].copy(), "gpu_top": order[:5].copy()}
+    return out
 
 
 def cpu_baseline(train, cem):
     """The oracle (CPU restatement of the reference path, pinned by tests/golden) on this host's cores: a bounded sample
-    of the same workloads -- configs[1] at its full batch (1 warm-up step + 2 timed), 64 of the 1000 candidates of
-    configs[2] in one pass -- and, with the same numbers, the parity check of what was just benchmarked."""
+    of the same workloads -- configs[1] at its full batch (1 warm-up step + 3 timed), 64 of the 1000 candidates of
+    configs[2] in one pass (the GPU's own top 32 and 32 random others) -- and, with the same numbers, the parity check
+    of what was just benchmarked: losses <= 1e-4, costs <= 1e-5, the oracle's top 5 equal to the GPU's."""
     from oracle import svg_oracle as orc
     torch.set_num_threads(host_threads())
     cores = torch.get_num_threads()
@@ -297,35 +358,88 @@ def cpu_baseline(train, cem):
         worst = max(abs(ck["gpu_losses"][k] - ref[k]) / (abs(ref[k]) + 1e-12) for k in ref)
         assert worst <= 1e-4, ("GPU train step drifted from the oracle", ck["gpu_losses"], ref)
         out["checked"]["train_losses_rel_err"] = worst
+        ck["oracle_losses"] = dict(ref)
         times = []
-        for i in (1, 2):
+        for i in (1, 2, 3):
             data = syn.synth_video(seed=100 + i % 2, T=T, B=B)
             t0 = time.perf_counter()
             orc.train_step(ts, data, None, None, do_update=True)
             times.append(time.perf_counter() - t0)
             log(f"cpu baseline train step {i}: {times[-1]:.1f} s")
         out["value"] = B * T / float(np.mean(times))
-        sample.append(f"train: configs[1] at batch {B}, 1 warm-up + 2 timed optimiser steps ({np.mean(times):.1f} s each)")
+        sample.append(f"train: configs[1] at batch {B}, 1 warm-up + {len(times)} timed optimiser steps "
+                      f"({np.mean(times):.1f} s each, min {min(times):.1f}, max {max(times):.1f})")
     if cem is not None and cem["check"] is not None:
         ck = cem["check"]
-        n = len(CEM_CHECK_IDX)
+        idx = ck["idx"]
+        n = len(idx)
         ccfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=n, candidates_batch_size=n, sample_mean=True, reward_type="dense",
                        model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
                        reconstruction_loss="l1")
         prob = ck["prob"]
         t0 = time.perf_counter()
-        ref = orc.cem_rollouts(ck["sd"], ccfg, prob["actions"][CEM_CHECK_IDX], prob["start_img"], prob["goal_imgs"],
+        ref = orc.cem_rollouts(ck["sd"], ccfg, prob["actions"][idx], prob["start_img"], prob["goal_imgs"],
                                prob["goal_masks"])["sum_cost"]
         t_cem = time.perf_counter() - t0
+        ck["oracle_sum_cost"] = ref
         err = float(np.abs(ck["gpu_sum_cost"] - ref).max() / np.abs(ref).max())
         assert err <= 1e-5, ("GPU rollout costs drifted from the oracle", err)
         out["checked"]["cem_sum_cost_rel_err"] = err
+        # elite set: the oracle's ranking of the GPU's top 32 must start with the GPU's top 5, in order, wherever
+        # neighbours are further apart than the error (this synthetic goal is far from every rollout: costs differ by
+        # ~1e-4 relative, SURVEY.md 7 "hard parts"; tests/test_gpu_fullsize.py pins a fixture with gaps >= 1e-2)
+        top_ref = idx[np.argsort(-ref, kind="stable")][:5]
+        g = np.sort(ck["gpu_sum_cost"])[::-1]
+        gaps = (g[:5] - g[1:6]) / np.abs(ref).max()
+        agree = [int(a) == int(b) for a, b in zip(top_ref, ck["gpu_top"])]
+        out["checked"]["cem_top5_identical"] = bool(all(agree))
+        out["checked"]["cem_top5_min_gap_rel"] = float(gaps.min())
+        assert all(a or gap <= 10 * err for a, gap in zip(agree, np.minimum(gaps, np.r_[np.inf, gaps[:-1]]))), \
+            ("GPU elite set differs from the oracle's beyond rounding", top_ref, ck["gpu_top"], gaps, err)
         out["cem_value"], out["cem_unit"] = n / t_cem, "candidate-rollouts/s"
-        sample.append(f"cem: {n} of the 1000 candidates x 14 steps in one pass ({t_cem:.1f} s)")
+        sample.append(f"cem: {n} of the 1000 candidates (the GPU's top {CEM_CHECK_TOP} + {CEM_CHECK_OTHERS} others) x 14 "
+                      f"steps in one pass ({t_cem:.1f} s)")
         if "value" not in out:
             out["value"], out["unit"] = out["cem_value"], out["cem_unit"]
     out["sample"] = "; ".join(sample)
     return out
+
+
+def exact_fp32_runs(args, dev, rank, world, distributed, train, cem):
+    """The same workloads with every conv on the exact-fp32 MFMA kernels (ops.SPLIT_GEMM off; v_mfma_f32_32x32x2_f32,
+    peak 157.3 TFLOP/s): what the split-precision operand format buys, and what it costs in accuracy -- the first train
+    step and the checked rollout costs of both builds side by side (and against the oracle when it ran)."""
+    keep = ops.SPLIT_GEMM
+    ops.SPLIT_GEMM = False
+    try:
+        out, err = {"arith": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32), same kernels otherwise", "peak": F32_MFMA_PEAK_TFLOPS}, {}
+        if train is not None:
+            ex = bench_train(args, dev, rank, world, distributed, exact_of=train)
+            torch.cuda.empty_cache()
+            k = ex["kernel"] or {"tflops": None, "avg_ms": None}
+            out["train"] = {"ms_per_step": ex["ms_per_step"], "frames_per_s": ex["frames_per_s"], "steps": ex["steps"],
+                            "step_tflops": ex["step_tflops_per_gpu"], "step_frac": ex["step_tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS,
+                            "gate_gemm_tflops": k["tflops"], "gate_gemm_avg_launch_ms": k["avg_ms"],
+                            "gate_gemm_frac": (k["tflops"] / F32_MFMA_PEAK_TFLOPS) if k["tflops"] else None}
+            if train["check"] is not None and ex["check"] is not None:
+                a, b = train["check"]["gpu_losses"], ex["check"]["gpu_losses"]
+                err["train_losses_split_vs_exact_fp32"] = max(abs(a[q] - b[q]) / (abs(b[q]) + 1e-12) for q in b)
+                train["check"]["exact_losses"] = dict(b)
+        if cem is not None:
+            ex = bench_cem(args, dev, rank, world, distributed, exact_of=cem)
+            torch.cuda.empty_cache()
+            k = ex["kernel"] or {"tflops": None, "avg_ms": None}
+            out["cem"] = {"rollouts_per_s": ex["rollouts_per_s"], "s_per_iteration": ex["s_per_iter"], "iterations": ex["iters"],
+                          "tflops": ex["tflops_per_gpu"], "frac": ex["tflops_per_gpu"] / F32_MFMA_PEAK_TFLOPS,
+                          "gate_gemm_tflops": k["tflops"], "gate_gemm_avg_launch_ms": k["avg_ms"],
+                          "gate_gemm_frac": (k["tflops"] / F32_MFMA_PEAK_TFLOPS) if k["tflops"] else None}
+            if cem["check"] is not None and "check_sum_cost" in ex:
+                a, b = cem["check"]["gpu_sum_cost"], ex["check_sum_cost"]
+                err["cem_sum_cost_split_vs_exact_fp32"] = float(np.abs(a - b).max() / np.abs(b).max())
+                cem["check"]["exact_sum_cost"] = b
+        return out, err
+    finally:
+        ops.SPLIT_GEMM = keep
 
 
 def main():
@@ -338,6 +452,10 @@ def main():
     ap.add_argument("--cem-batch", type=int, default=1000, help="candidates per GPU pass")
     ap.add_argument("--cem-iters", type=int, default=2)
     ap.add_argument("--cem-warmup", type=int, default=1)
+    ap.add_argument("--cem-opt-iter", type=int, default=10, help="CEM iterations of the timed get_action call")
+    ap.add_argument("--exact-steps", type=int, default=5, help="timed train steps of the exact-fp32 comparison run")
+    ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 comparison runs")
+    ap.add_argument("--no-cem-ra", action="store_true", help="skip the robot-aware planner workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h48", action="store_true",
                     help="train workload on 48x64 frames, the reference's default --image_height (not the headline)")
@@ -370,19 +488,27 @@ def main():
 
     out = {"metric": "SVG train frames/sec + CEM candidate-rollouts/sec, 64x64", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "fp32", "data": "synthetic"}
+           "vs_baseline": None, "data": "synthetic",
+           "dtype": "fp32 (conv operands as two fp16 parts = 22 significant bits, fp32 accumulate; see fp32_exact)"}
     train = cem = None
     if args.workload in ("both", "train"):
         train = bench_train(args, dev, rank, world, distributed)
         torch.cuda.empty_cache()
+    cem_ra = None
     if args.workload in ("both", "cem"):
         cem = bench_cem(args, dev, rank, world, distributed)
+        torch.cuda.empty_cache()
+        if not args.no_cem_ra and not args.group_norm:
+            cem_ra = bench_cem(args, dev, rank, world, distributed, ra=True)
+            torch.cuda.empty_cache()
+    exact = arith_err = None
+    if not args.no_exact and not (args.h48 or args.cfg5 or args.group_norm):
+        exact, arith_err = exact_fp32_runs(args, dev, rank, world, distributed, train, cem)
 
     if train is not None:
         out.update(value=train["frames_per_s"], unit="frames/s", ms_per_step=train["ms_per_step"],
                    median_ms_per_step=train["median_ms_per_step"],
-                   config={"workload": "SVG train step, BASELINE configs[1]: 64x64, bs 16/GPU, n_past 1, n_future 5, "
-                                       "g_dim 512, z_dim 64, robot-aware flags (dontcare_l1)",
+                   config={"workload": train["workload"],
                            "global_batch": train["global_batch"], "parallelism": f"ddp{world}",
                            "algorithmic_tflop_per_step_per_gpu": train["step_tflop"]})
         k = train["kernel"]
@@ -400,6 +526,9 @@ def main():
                            "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                            "step_achieved": train["step_tflops_per_gpu"], "step_peak": SPLIT_PEAK_TFLOPS,
                            "step_frac": train["step_tflops_per_gpu"] / SPLIT_PEAK_TFLOPS}
+        if not (args.h48 or args.cfg5 or args.group_norm):
+            out["roofline"]["kernel"] = ("conv16_tile_kernel: FWD 5x5 ConvLSTM gate conv as GEMM (M=%d, N=2048, K=25600)"
+                                         % (train["cf"].batch_size * 64))
         out["time_breakdown_ms"] = train["phases"]
         if distributed:
             out["ranks"] = {"train_ms_per_step": train["rank_ms_per_step"]}
@@ -428,10 +557,46 @@ def main():
                                  "peak": gate["peak"], "unit": "TFLOP/s", "frac": gate["frac"],
                                  "traffic": gate["traffic"], "traffic_source": gate["traffic_source"]})
         out["cem"] = cem_obj
+    if cem_ra is not None:
+        k = cem_ra["kernel"] or {"split": True, "tflops": cem_ra["tflops_per_gpu"], "avg_ms": None, "launches": 0}
+        out["cem_ra"] = {"value": cem_ra["rollouts_per_s"], "unit": "candidate-rollouts/s",
+                         "s_per_iteration": cem_ra["s_per_iter"],
+                         "config": {"workload": "robot-aware CEM rollouts: configs[2] geometry with mask + future mask + robot "
+                                                "state into the model, dontcare cost; states and masks of all candidates from "
+                                                "AtlasRobotModel on the device (synthetic arm atlas, 5 mm grid), inside the "
+                                                "timed region",
+                                    "candidates": cem_ra["candidates"], "candidates_batch_size": cem_ra["candidates_batch_size"],
+                                    "parallelism": f"candidate-shard{world}"},
+                         "achieved_tflops_per_gpu": cem_ra["tflops_per_gpu"],
+                         "frac_of_split_peak": cem_ra["tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
+                         "gate_gemm_tflops": k["tflops"], "get_action": cem_ra["get_action"]}
+        if distributed:
+            out["cem_ra"]["ranks"] = {"s_per_iteration": cem_ra["rank_s_per_iter"],
+                                      "cost_allgather_ms": cem_ra["cost_allgather_ms"]}
+    if exact is not None:
+        out["fp32_exact"] = exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(train, cem)
         if cb.get("sample"):
             out["cpu_baseline"] = cb
+        # split-precision vs exact fp32 vs the oracle, on the same first train step and the same checked candidates
+        if arith_err is not None:
+            if train is not None and train["check"] is not None and "oracle_losses" in train["check"]:
+                ck = train["check"]
+                rel = lambda a, b: max(abs(a[q] - b[q]) / (abs(b[q]) + 1e-12) for q in b)
+                arith_err["train_losses_split_vs_oracle"] = rel(ck["gpu_losses"], ck["oracle_losses"])
+                if "exact_losses" in ck:
+                    arith_err["train_losses_exact_fp32_vs_oracle"] = rel(ck["exact_losses"], ck["oracle_losses"])
+            if cem is not None and cem["check"] is not None and "oracle_sum_cost" in cem["check"]:
+                ck = cem["check"]
+                rel = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+                arith_err["cem_sum_cost_split_vs_oracle"] = rel(ck["gpu_sum_cost"], ck["oracle_sum_cost"])
+                if "exact_sum_cost" in ck:
+                    arith_err["cem_sum_cost_exact_fp32_vs_oracle"] = rel(ck["exact_sum_cost"], ck["oracle_sum_cost"])
+    if arith_err:
+        arith_err["note"] = ("max relative error: train = the first optimiser step's loss terms, cem = sum_cost of the 64 "
+                             "checked candidates (relative to the largest)")
+        out["arith_error"] = arith_err
     if rank == 0:
         print(json.dumps(out))
     if distributed:

@@ -65,3 +65,37 @@ def synth_cem_problem(seed: int, N: int, T: int, H: int = 64, W: int = 64, with_
             (_rng(seed, 13).random((T + 1, N, 1, H, W), dtype=np.float32) < mask_p).astype(np.float32))
         out["goal_masks"] = [(_rng(seed, 14).random((1, H, W), dtype=np.float32) < mask_p)]
     return out
+
+
+def synth_arm_atlas(nx: int = 108, ny: int = 121, H: int = 64, W: int = 64, x_range=(0.015, 0.55),
+                    y_range=(-0.3, 0.3), device="cpu") -> dict:
+    """A synthetic robot-mask atlas for `robot_atlas.AtlasRobotModel` (5 mm grid over the workspace of
+    src/cem/trajectory_sampler.py:22-23): node (j, i) holds the mask of an "arm" drawn from the image's bottom centre to
+    the end effector at (x_i, y_j) seen by a fixed top-down camera -- a disc of radius 6 px plus a 3 px thick link.
+    Stands in for the MuJoCo renders of the analytical robot models, which this image cannot produce."""
+    xs = torch.linspace(x_range[0], x_range[1], nx, dtype=torch.float64)
+    ys = torch.linspace(y_range[0], y_range[1], ny, dtype=torch.float64)
+    m = arm_mask(xs.view(1, nx).expand(ny, nx).reshape(-1), ys.view(ny, 1).expand(ny, nx).reshape(-1), H, W, x_range,
+                 y_range, device).view(ny, nx, H, W)
+    return {"atlas": m, "x0": float(xs[0]), "y0": float(ys[0]), "dx": float(xs[1] - xs[0]), "dy": float(ys[1] - ys[0])}
+
+
+def arm_mask(x, y, H: int = 64, W: int = 64, x_range=(0.015, 0.55), y_range=(-0.3, 0.3), device="cpu") -> torch.Tensor:
+    """uint8 (n, H, W) masks of the synthetic arm with its end effector at the positions (x[k], y[k]): the "exact
+    render" that `synth_arm_atlas` samples on a grid."""
+    x = torch.as_tensor(x, dtype=torch.float64).to(device)
+    y = torch.as_tensor(y, dtype=torch.float64).to(device)
+    u = ((y - y_range[0]) / (y_range[1] - y_range[0]) * (W - 1)).float().view(-1, 1, 1)   # pixel column
+    v = ((x_range[1] - x) / (x_range[1] - x_range[0]) * (H - 1)).float().view(-1, 1, 1)   # pixel row
+    yy = torch.arange(H, device=device, dtype=torch.float32).view(1, H, 1)
+    xx = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, W)
+    out = []
+    bx, by = (W - 1) / 2, float(H - 1)
+    for lo in range(0, u.shape[0], 2048):
+        uu, vv = u[lo:lo + 2048], v[lo:lo + 2048]
+        m = (xx - uu) ** 2 + (yy - vv) ** 2 <= 36
+        dx, dy = uu - bx, vv - by
+        t = (((xx - bx) * dx + (yy - by) * dy) / (dx * dx + dy * dy).clamp_min(1e-6)).clamp(0, 1)
+        m |= (xx - (bx + t * dx)) ** 2 + (yy - (by + t * dy)) ** 2 <= 9
+        out.append(m.to(torch.uint8))
+    return torch.cat(out, 0)

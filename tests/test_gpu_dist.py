@@ -147,3 +147,37 @@ def test_ranks_sharing_one_gpu(world):
     assert all(r["action"] == res[0]["action"] for r in res)
     # identical inputs exclude slope flips; what is left is the all-reduce's summation order
     assert all(r["ddp_err"] < 1e-5 for r in res), res
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2` end to end, launched the way the driver launches it (torch.distributed.run, one process per
+    rank), before an 8-GPU node ever runs it: both ranks share this box's one MI355X and gloo stands in for RCCL
+    (RAC_BENCH_ONE_GPU / RAC_DIST_BACKEND, the script's own rehearsal switches).  A fresh child process tree: nothing
+    that has touched the GPU re-launches itself."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RAC_DIST_BACKEND="gloo", RAC_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--cem-candidates", "64", "--cem-batch", "64", "--cem-iters", "1", "--cem-opt-iter", "2",
+           "--exact-steps", "2"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "ddp2" and out["config"]["global_batch"] == 32
+    assert len(out["ranks"]["train_ms_per_step"]) == 2 and all(v > 0 for v in out["ranks"]["train_ms_per_step"])
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "allreduce_exposed" in out["time_breakdown_ms"]
+    cem = out["cem"]
+    assert cem["config"]["parallelism"] == "candidate-shard2" and cem["config"]["candidates"] == 128
+    assert cem["ranks"]["cost_allgather_ms"] is not None and len(cem["ranks"]["s_per_iteration"]) == 2
+    assert out["cem_ra"]["value"] > 0 and out["fp32_exact"]["train"]["ms_per_step"] > 0
+    assert "cpu_baseline" not in out  # rank 0 at N = 1 only
