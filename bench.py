@@ -4,7 +4,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Workloads (synthetic 64x64 video, random-init weights of the named architecture, fp32 storage and accumulation):
+Workloads (synthetic 64x64 video; random weights of the named architecture, scaled so that activations stay O(1) and the
+predicted frames depend on the actions -- synthetic.synth_state_dict; fp32 storage and accumulation):
   train: BASELINE.json configs[1] -- bs 16 per GPU, n_past 1, n_future 5, g_dim 512, z_dim 64, robot-aware
          flags (mask + future mask + robot state, dontcare_l1).  One step = zero_grad, 5-step BPTT forward,
          losses, backward, (N>1: RCCL gradient all-reduce), fused Adam, loss readback.  `value` = frames/s.
@@ -176,6 +177,8 @@ def build_train(args, dev):
         cf.batch_size, cf.n_future = 8, 10
     log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
+    # random weights that keep activations O(1) and make the predictions depend on the actions (synth_state_dict)
+    tr.model.load_state_dict(syn.synth_state_dict(tr.model, seed=11))
     tr.model.train()
     return cf, tr
 
@@ -268,6 +271,7 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
     cf = namespace(dev, candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
                    lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic", **flags)
     model = SVGConvModel(cf)
+    model.load_state_dict(syn.synth_state_dict(model, seed=12))
     if exact_of is not None and exact_of["check"] is not None:
         model.load_state_dict({k: v.clone() for k, v in exact_of["check"]["sd"].items()})
     if distributed:

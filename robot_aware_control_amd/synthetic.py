@@ -99,3 +99,43 @@ def arm_mask(x, y, H: int = 64, W: int = 64, x_range=(0.015, 0.55), y_range=(-0.
         m |= (xx - (bx + t * dx)) ** 2 + (yy - (by + t * dy)) ** 2 <= 9
         out.append(m.to(torch.uint8))
     return torch.cat(out, 0)
+
+
+def synth_state_dict(model, seed: int = 0, action_gain: float = 200.0, action_dim: int = 5) -> dict:
+    """A deterministic random state_dict for `model` (name-keyed Philox streams, so every host and every rank produces
+    the same bytes) whose activations stay O(1) through the 19 vgg layers and whose predictions DEPEND on the actions:
+    conv weights He-scaled (gate convs 1/sqrt(fan_in), mu / logvar heads half of that), the action channels of the
+    prior / frame-predictor input convs amplified by `action_gain`, BatchNorm affine and running statistics near (1, 0).
+    With nn-style N(0, 0.02) weights (base.py:26-36) an untrained model's frames sit at sigmoid(~0) and candidates'
+    costs differ by less than fp32 resolves: nothing a parity check or an elite selection could be judged on."""
+    import math
+    import zlib
+    out = {}
+    for key, ref in model.state_dict().items():
+        shape = tuple(ref.shape)
+        rng = np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), seed]))
+        normal = lambda std, mean=0.0: torch.from_numpy(
+            (rng.standard_normal(shape, dtype=np.float32) * np.float32(std) + np.float32(mean)).astype(np.float32))
+        if key.endswith("num_batches_tracked"):
+            out[key] = torch.zeros((), dtype=torch.int64)
+        elif key.endswith("running_mean"):
+            out[key] = normal(0.1)
+        elif key.endswith("running_var"):
+            out[key] = torch.from_numpy(rng.uniform(0.5, 1.5, shape).astype(np.float32))
+        elif len(shape) == 4:
+            transposed = key == "decoder.upc5.1.weight"  # ConvTranspose2d stores (cin, cout, k, k)
+            fan_in = (shape[0] if transposed else shape[1]) * shape[2] * shape[3]
+            std = math.sqrt(2.0 / fan_in)
+            if "gates" in key:
+                std = math.sqrt(1.0 / fan_in)
+            if "mu_net" in key or "logvar_net" in key:
+                std = 0.5 * math.sqrt(1.0 / fan_in)
+            w = normal(std)
+            if key in ("prior_input_conv.weight", "frame_pred_input_conv.weight"):
+                w[:, :action_dim] *= action_gain
+            out[key] = w
+        elif ".main.1." in key or "_norm." in key or ("gates.1." in key):  # BatchNorm / GroupNorm affine
+            out[key] = normal(0.1, 1.0 if key.endswith("weight") else 0.0)
+        else:  # conv biases
+            out[key] = normal(0.05)
+    return out

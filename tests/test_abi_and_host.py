@@ -24,6 +24,79 @@ def test_library_exports_every_declared_symbol():
     assert lib.rac_device_arch() == b"gfx950"
 
 
+def _prototypes():
+    """name -> (return type, [parameter C types]) for every `rac_*` prototype of include/rac_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "rac_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    out = {}
+    for ret, name, params in re.findall(r"\b(int|int64_t|const char\*)\s+(rac_\w+)\s*\(([^)]*)\)\s*;", hdr):
+        params = " ".join(params.split())
+        types = []
+        if params != "void":
+            for prm in params.split(","):
+                prm = prm.strip()
+                m = re.match(r"^(.*?)(\w+)(\[\w*\])?$", prm)  # type, name, optional array suffix
+                types.append((m.group(1).strip() + (" *" if m.group(3) else "")).replace(" *", "*").replace("* ", "*"))
+        out[name] = (ret, types)
+    return out
+
+
+def test_ctypes_signatures_match_the_header():
+    """_lib._SIGS is written by hand: every export's arity and every parameter's type class is checked against the
+    prototype the header declares (a missing / extra / reordered argument would otherwise shift everything behind it)."""
+    import ctypes as C
+    from robot_aware_control_amd import _lib
+    protos = _prototypes()
+    assert set(protos) == set(_lib._SIGS)
+    structs = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs}
+
+    def expected(ctype):
+        t = re.sub(r"\bconst\b", "", ctype).replace(" ", "")
+        if t in ("int32_t", "int"):
+            return C.c_int32
+        if t == "int64_t":
+            return C.c_int64
+        if t == "float":
+            return C.c_float
+        m = re.match(r"^(rac_\w+)\*$", t)
+        if m and m.group(1) in structs:
+            return C.POINTER(structs[m.group(1)])
+        if t.endswith("**"):       # host array of device pointers
+            return C.POINTER(C.c_void_p)
+        assert t.endswith("*"), ctype
+        return C.c_void_p
+
+    for name, (ret, types) in protos.items():
+        sig = _lib._SIGS[name]
+        assert len(sig) == len(types), (name, len(sig), types)
+        for i, (have, ctype) in enumerate(zip(sig, types)):
+            assert have is expected(ctype) or have == expected(ctype), (name, i, ctype, have)
+        want_ret = {"int": C.c_int, "int64_t": C.c_int64, "const char*": C.c_char_p}[ret]
+        assert _lib._RET.get(name, C.c_int) is want_ret, (name, ret)
+
+
+def test_compiled_consumer_sees_the_same_structs():
+    """tests/abi_consumer.cpp (C++, include/rac_hip.h, -lrac_hip; built by __graft_entry__.build()): the library answers
+    with the header's ABI version, and the struct layouts a C++ translation unit sees are the ctypes mirrors'."""
+    import ctypes as C
+    import subprocess
+    import __graft_entry__ as entry
+    from robot_aware_control_amd import _lib
+    exe = entry.build_abi_consumer()
+    res = subprocess.run([exe], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    kv = dict(line.split() for line in res.stdout.splitlines())
+    assert int(kv["rac_version"]) == int(kv["RAC_ABI_VERSION"]) == _lib.ABI_VERSION and kv["arch"] == "gfx950"
+    for cname, cls in (("rac_conv_args", _lib.ConvArgs), ("rac_wgrad_args", _lib.WgradArgs),
+                       ("rac_absmax_job", _lib.AbsmaxJob), ("rac_frag_job", _lib.FragJob)):
+        assert int(kv[f"sizeof_{cname}"]) == C.sizeof(cls), cname
+    for key, val in kv.items():
+        m = re.match(r"offsetof_(rac_conv_args|rac_wgrad_args|rac_frag_job)_(\w+)", key)
+        if m:
+            cls = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs, "rac_frag_job": _lib.FragJob}[m.group(1)]
+            assert getattr(cls, m.group(2)).offset == int(val), key
+
+
 def test_ops_refuse_cpu_tensors():
     """No CPU fallback: the product path fails loudly off the GPU."""
     from robot_aware_control_amd import RacError, ops

@@ -680,3 +680,16 @@ def test_wgrad_split_precision(dev, case, presplit, monkeypatch):
         wd5 = cl_weight(w.detach()).to(dev).requires_grad_(True)
         ops.conv_wgrad_split_acc(to_map(gy, dev), x0, z1, wd5)  # every step zero: the x1 half stays untouched
         assert relerr(wd5.grad.cpu(), wz.grad.double()) < 3e-6 and float(wd5.grad[:, C0:].abs().max()) == 0.0
+
+
+def test_compiled_cpp_consumer_calls_the_library(dev):
+    """tests/abi_consumer.cpp: a C++ host compiled against include/rac_hip.h and linked with -lrac_hip (no Python, no torch)
+    makes one rac_conv2d call on its own hipMalloc'ed buffers and stream, checks it against a host loop, and gets
+    RAC_EINVAL + a message for a bad argument."""
+    import subprocess
+    import __graft_entry__ as entry
+    exe = entry.build_abi_consumer()
+    res = subprocess.run([exe, "gpu"], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    kv = dict(line.split() for line in res.stdout.splitlines())
+    assert float(kv["conv_max_rel_err"]) < 1e-5 and int(kv["bad_ksize_rc"]) == -1
