@@ -161,197 +161,243 @@ def random_color_jitter(brightness, contrast, saturation, hue):
     return apply
 
 
-class RoboNetDataset(data.Dataset):
-    """Same contract as the reference class (robonet_dataset.py:23-171): item = dict(images (T,3,h,w) in [0,1],
-    states (T,R) normalised, actions (T-1,A), masks (T,1,h,w) in {0,1}, robot, folder, file_path, idx, qpos (T,Q))."""
+# --------------------------------------------------------------------------- #
+# numeric preprocessing: one table entry per robot viewpoint, whole-trajectory array ops
+# --------------------------------------------------------------------------- #
+# The reference spreads this over per-item methods with per-robot branches (robonet_dataset.py:173-256,300-432).  Here
+# the branches are DATA: a `Viewpoint` says where a robot's bounds come from and how its stored end-effector positions
+# become metric world positions; `NumericPipeline` then maps the (T, .) arrays of a whole window at once.  The
+# floating-point expressions keep the reference's order of operations in float32 (tests/golden/dataset_item.npz pins
+# them bit for bit).
+WORKSPACE_BOX = (np.array([0.015, -0.3, 0.1, 0, 0], dtype=np.float32),      # robonet_dataset.py:203-207: the planner's
+                 np.array([0.55, 0.3, 0.4, 1, 1], dtype=np.float32))         # workspace for the authors' own robots
+FRANKA_TO_LOCOBOT_XY = np.array([-0.365, -0.06103333])                       # LOCO_FRANKA_DIFF, robonet_dataset.py:21
+FRANKA_PUSH_HEIGHT = 0.14
 
-    def __init__(self, hdf5_list, robot_list, config, augment_img=False, load_snippet=False):
-        self._traj_names = hdf5_list
-        self._traj_robots = robot_list
+
+class Viewpoint:
+    """What distinguishes one robot viewpoint's numeric preprocessing (robonet_dataset.py:200-208,305-322)."""
+    __slots__ = ("name", "file_bounds", "stored_metric", "shift_xy", "fixed_z", "default_robot")
+
+    def __init__(self, name: str):
+        self.name = name
+        own_rig = "locobot" in name or "franka" in name
+        self.file_bounds = not own_rig       # RoboNet files carry low_bound / high_bound; the authors' rigs use the box
+        self.stored_metric = own_rig         # RoboNet stores NORMALISED eef positions, the authors' rigs metric ones
+        franka = "franka" in name and "locobot" not in name
+        self.shift_xy = FRANKA_TO_LOCOBOT_XY if franka else None
+        self.fixed_z = FRANKA_PUSH_HEIGHT if franka else None
+        self.default_robot = "locobot" if "locobot" in name else ("franka" if "franka" in name else None)
+
+    def bounds(self, traj):
+        if self.file_bounds:
+            return traj["low_bound"][:], traj["high_bound"][:]
+        return WORKSPACE_BOX[0].copy(), WORKSPACE_BOX[1].copy()
+
+    def metric_eef(self, states, low, high):
+        """(T, 3) end-effector positions in the metric world frame, as a view / copy of states[:, :3]."""
+        eef = states[:, :3]
+        if not self.stored_metric:
+            return denormalize(eef, low[:3], high[:3])
+        if self.shift_xy is not None:
+            eef[:, :2] += self.shift_xy
+            eef[:, 2] = self.fixed_z
+        return eef
+
+
+def _homogeneous(points):
+    """(n, 3) -> (4, n) homogeneous columns (float64, as np.ones promotes in the reference)."""
+    return np.concatenate([points, np.ones((points.shape[0], 1))], 1).T
+
+
+def _apply(matrix, points):
+    return (matrix @ _homogeneous(points)).T[:, :3]
+
+
+def fit_width(x, width):
+    """Zero-pad the last axis of a (T, d) array up to `width` (robonet_dataset.py:209-229)."""
+    if x.shape[-1] == width:
+        return x
+    assert width > x.shape[-1]
+    return np.pad(x, [(0, 0), (0, width - x.shape[-1])])
+
+
+def imputed_gripper_actions(actions, next_gripper, g_low, g_high):
+    """`--impute_autograsp_action`: append the gripper command implied by the NEXT state's gripper reading, open / closed
+    around the midpoint of its bounds (robonet_dataset.py:181-190), for all steps at once."""
+    mid = (g_high + g_low) / 2.0
+    cmd = np.where(next_gripper > mid, g_high, g_low).astype(np.float64)[:, None]
+    return np.concatenate((actions, cmd), axis=-1)
+
+
+class NumericPipeline:
+    """Bounds, states and actions of one viewpoint under one `--preprocess_action` strategy, for whole windows."""
+
+    def __init__(self, viewpoint: str, strategy: str):
+        self.view = Viewpoint(viewpoint)
+        self.strategy = strategy
+        self.camera = "camera" in strategy
+        self.w2c = self.c2w = None
+        if self.camera:
+            w2c, c2w = _camera_dicts()
+            self.w2c, self.c2w = w2c[viewpoint], c2w[viewpoint]
+
+    def bounds(self, raw_low, raw_high):
+        """Camera strategies normalise in the camera frame: the box's 8 corners are transformed and re-boxed
+        (robonet_dataset.py:231-255)."""
+        low, high = raw_low.copy(), raw_high.copy()
+        if self.camera:
+            corners = np.array([[x, y, z] for x in (low[0], high[0]) for y in (low[1], high[1]) for z in (low[2], high[2])])
+            cam = _apply(self.w2c, corners)
+            low[:3], high[:3] = cam.min(0), cam.max(0)
+        return low, high
+
+    def states(self, states, low, high):
+        """Stored states -> states normalised by (low, high), positions in the strategy's frame."""
+        out = states.copy()
+        eef = self.view.metric_eef(out, low, high)
+        if self.camera:
+            eef = _apply(self.w2c, eef)
+        out[:, :3] = normalize(eef, low[:3], high[:3])
+        out[:, 4] = normalize(out[:, 4], low[4], high[4])
+        return out
+
+    def actions(self, norm_states, actions, low, high):
+        if self.strategy == "raw":
+            return torch.from_numpy(actions)
+        if self.strategy != "camera_raw":
+            raise NotImplementedError(self.strategy)  # state_infer / camera_state_infer: as the reference
+        # displacement of the eef in the camera frame.  The reference zeroes the recorded actions first
+        # (robonet_dataset.py:383-384), so the "next" position equals the current one: kept, it is its arithmetic.
+        out = np.zeros_like(actions)
+        world = _apply(self.c2w, denormalize(norm_states[:, :3], low[:3], high[:3]))[:-1]
+        out[:, :3] = _apply(self.w2c, world + out[:, :3]) - _apply(self.w2c, world)
+        return torch.from_numpy(out)
+
+
+class ImagePipeline:
+    """uint8 frames / float masks of a window -> (T, C, h, w) tensors (robonet_dataset.py:257-300): ToTensor + bilinear
+    resize of the whole window in one call; with augmentation one crop and one colour jitter per trajectory."""
+
+    def __init__(self, height: int, width: int, augment: bool):
+        self.h, self.w, self.augment = height, width, augment
+
+    def __call__(self, frames, masks):
+        video = _resize(_to_tensor(frames), self.h, self.w)
+        mask = _resize(_to_tensor(masks), self.h, self.w)
+        if self.augment:
+            shrink = random.randint(0, 5)
+            th, tw = self.h - shrink, self.w - shrink
+            top = left = 0
+            if shrink:  # tf.RandomCrop.get_params draws the corner from the torch generator, row first
+                top = int(torch.randint(0, self.h - th + 1, size=(1,)).item())
+                left = int(torch.randint(0, self.w - tw + 1, size=(1,)).item())
+            jitter = random_color_jitter((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
+            window = (slice(None), slice(None), slice(top, top + th), slice(left, left + tw))
+            video = jitter(_resize(video[window], self.h, self.w))
+            mask = _resize(mask[window], self.h, self.w)
+        return video, mask.type(torch.bool).type(torch.float32)
+
+
+class RoboNetDataset(data.Dataset):
+    """Trajectory files -> the reference's item dict (robonet_dataset.py:23-171): images (T,3,h,w) in [0,1], states (T,R)
+    normalised, actions (T-1,A), masks (T,1,h,w) in {0,1}, qpos (T,Q), robot, folder, file_path, idx (+ low / high /
+    raw_* for finetune_* experiments, high_movement with --load_movement_info)."""
+
+    def __init__(self, hdf5_list, robot_list, config, augment_img=False, load_snippet=False, rng_seed=None):
+        self._traj_names, self._traj_robots = hdf5_list, robot_list
         self._config = config
         self._data_root = config.data_root
-        if config.load_movement_info:  # robonet_dataset.py:36-48
-            movement_vp = {}
-            for name in self._traj_names:
-                folder = os.path.basename(os.path.dirname(name))
-                if folder in movement_vp:
-                    continue
-                with open(os.path.join(os.path.dirname(name), "obj_movement.pkl"), "rb") as f:
-                    movement_vp[folder] = pickle.load(f)
-            self._movement_vp = movement_vp
-        self._video_length = config.video_length
-        if load_snippet:
-            self._video_length = config.n_past + config.n_future
+        self._video_length = (config.n_past + config.n_future) if load_snippet else config.video_length
         self._action_dim = config.action_dim
-        self._impute_autograsp_action = getattr(config, "impute_autograsp_action", False)
-        self._augment_img = augment_img
-        self._rng = np.random.RandomState(config.seed)
+        self._impute = getattr(config, "impute_autograsp_action", False)
+        self._images = ImagePipeline(config.image_height, config.image_width, augment_img)
+        self._pipelines = {}
+        # window starts: the reference's RandomState(config.seed); data-parallel ranks pass their own seed
+        self._rng = np.random.RandomState(config.seed if rng_seed is None else rng_seed)
+        self._movement = self._movement_tables() if config.load_movement_info else None
         self._memory = {}
         if getattr(config, "preload_ram", False):
-            for i in range(len(self._traj_names)):
-                self._memory[i] = self.__getitem__(i)
+            self._memory = {i: self[i] for i in range(len(self))}
 
     def __len__(self):
         return len(self._traj_names)
+
+    def _movement_tables(self):
+        """folder -> {file path: high-movement flag} (obj_movement.pkl next to the trajectories, :36-48)."""
+        tables = {}
+        for folder_path in {os.path.dirname(n) for n in self._traj_names}:
+            with open(os.path.join(folder_path, "obj_movement.pkl"), "rb") as f:
+                tables[os.path.basename(folder_path)] = pickle.load(f)
+        return tables
+
+    def pipeline(self, viewpoint: str) -> NumericPipeline:
+        pipe = self._pipelines.get(viewpoint)
+        if pipe is None:
+            pipe = self._pipelines[viewpoint] = NumericPipeline(viewpoint, self._config.preprocess_action)
+        return pipe
+
+    def _window(self, length: int, path: str):
+        assert length >= self._video_length, f"{length}, {path}"
+        if length == self._video_length:
+            return 0, length
+        start = self._rng.randint(0, length - self._video_length + 1)
+        return start, start + self._video_length
+
+    def read_actions(self, traj, start, end, g_low, g_high):
+        """(end - start, A) float32 actions of the window; files with one dimension less get the imputed gripper
+        command when `--impute_autograsp_action` is set."""
+        actions = traj["actions"][:].astype(np.float32)
+        have = actions.shape[1]
+        if have != self._action_dim:
+            if not (self._impute and have + 1 == self._action_dim):
+                raise ValueError(f"file adim {have}, target adim {self._action_dim}")
+            actions = imputed_gripper_actions(actions, traj["states"][:][1:, -1], g_low, g_high).astype(np.float32)
+        return actions[start:end]
 
     def __getitem__(self, idx):
         if idx in self._memory:
             return self._memory[idx]
         cf = self._config
-        name = self._traj_names[idx]
-        robot_viewpoint = self._traj_robots[idx]
+        name, viewpoint = self._traj_names[idx], self._traj_robots[idx]
         path = os.path.join(self._data_root, name)
-        with open_trajectory(path) as hf:
-            assert "frames" in hf or "observations" in hf
-            image_key = "observations" if "observations" in hf else "frames"
-            mask_key = "masks" if "masks" in hf else "mask"
-            ep_len = hf[image_key].shape[0]
-            assert ep_len >= self._video_length, f"{ep_len}, {path}"
-            start, end = 0, ep_len
-            if ep_len > self._video_length:
-                start = self._rng.randint(0, ep_len - self._video_length + 1)
-                end = start + self._video_length
-            images = hf[image_key][start:end]
-            raw_low, raw_high = self._load_bounds(hf, robot_viewpoint)
-            g_low, g_high = raw_low[4], raw_high[4]
-            states = self._load_states(hf, start, end)
-            actions = self._load_actions(hf, g_low, g_high, start, end - 1)
+        pipe = self.pipeline(viewpoint)
+        with open_trajectory(path) as traj:
+            frames_key = "observations" if "observations" in traj else "frames"
+            assert frames_key in traj, path
+            masks_key = "masks" if "masks" in traj else "mask"
+            s, e = self._window(traj[frames_key].shape[0], path)
+            frames = traj[frames_key][s:e]
+            masks = traj[masks_key][s:e].astype(np.float32)
+            raw_low, raw_high = pipe.view.bounds(traj)
+            raw_states = fit_width(traj["states"][s:e].astype(np.float32), cf.robot_dim)
+            raw_actions = self.read_actions(traj, s, e - 1, raw_low[4], raw_high[4])
+            qpos = fit_width(traj["qpos"][s:e].astype(np.float32), cf.robot_joint_dim)
+            robot = traj.attrs["robot"] if "robot" in traj.attrs else pipe.view.default_robot
+            robot = robot.decode() if isinstance(robot, bytes) else str(robot)
+        if not len(frames) == len(raw_states) == len(raw_actions) + 1 == len(masks):
+            raise AssertionError(f"{path}, {frames.shape}, {raw_states.shape}, {raw_actions.shape}, {masks.shape}")
+        if getattr(cf, "model_use_heatmap", False):
+            raise NotImplementedError  # as the reference (robonet_dataset.py:130-133)
+        low, high = pipe.bounds(raw_low, raw_high)
+        images, masks = self._images(frames, masks)
+        states = pipe.states(raw_states, low, high)
+        actions = pipe.actions(states, raw_actions, low, high)
+        folder = os.path.basename(os.path.dirname(name))
+        item = {"images": images, "states": states, "actions": actions, "masks": masks, "robot": robot, "folder": folder,
+                "file_path": path, "idx": idx, "qpos": qpos}
+        if "finetune" in cf.experiment:  # the robot model of finetune_* windows needs the bounds (:148-166)
+            item["low"], item["high"] = low, high
             if cf.preprocess_action != "raw":
-                raw_states, raw_actions = states.copy(), actions.copy()
-            masks = hf[mask_key][start:end].astype(np.float32)
-            qpos = self._load_qpos(hf, start, end)
-            assert len(images) == len(states) == len(actions) + 1 == len(masks), \
-                f"{path}, {images.shape}, {states.shape}, {actions.shape}, {masks.shape}"
-            low, high = self._preprocess_bounds(raw_low, raw_high, idx)
-            images, masks = self._preprocess_images_masks(images, masks)
-            states = self._preprocess_states(states, low, high, robot_viewpoint, idx)
-            actions = self._preprocess_actions(states, actions, low, high, idx)
-            if "robot" in hf.attrs:
-                robot = hf.attrs["robot"]
-                robot = robot.decode() if isinstance(robot, bytes) else str(robot)
-            elif "locobot" in robot_viewpoint:
-                robot = "locobot"
-            elif "franka" in robot_viewpoint:
-                robot = "franka"
-            folder = os.path.basename(os.path.dirname(name))
-            if getattr(cf, "model_use_heatmap", False):
-                raise NotImplementedError  # as the reference (robonet_dataset.py:130-133)
-        out = {"images": images, "states": states, "actions": actions, "masks": masks, "robot": robot,
-               "folder": folder, "file_path": path, "idx": idx, "qpos": qpos}
-        if "finetune" in cf.experiment:  # robonet_dataset.py:148-166
-            out["low"], out["high"] = low, high
-            if cf.preprocess_action == "raw":
-                pass
-            elif "camera" in cf.preprocess_action:
-                out["raw_low"], out["raw_high"], out["raw_actions"] = raw_low, raw_high, raw_actions
-                raw_states[:, :3] = normalize(raw_states[:, :3], raw_low[:3], raw_high[:3])
-                raw_states[:, 4] = normalize(raw_states[:, 4], raw_low[4], raw_high[4])
-                out["raw_states"] = raw_states
-            else:
-                raise NotImplementedError
-        if cf.load_movement_info:
-            out["high_movement"] = self._movement_vp[folder][path]
-        return out
-
-    # ---- loaders (robonet_dataset.py:173-229) ----
-    def _load_actions(self, fp, gripper_low, gripper_high, start, end):
-        actions = fp["actions"][:].astype(np.float32)
-        a_T, adim = actions.shape[0], actions.shape[1]
-        if self._action_dim == adim:
-            return actions[start:end]
-        if self._impute_autograsp_action and adim + 1 == self._action_dim:
-            action_append = np.zeros((a_T, 1))
-            next_state = fp["states"][:][1:, -1]
-            high_val, low_val = gripper_high[-1], gripper_low[-1]
-            midpoint = (high_val + low_val) / 2.0
-            for t, s in enumerate(next_state):
-                action_append[t, 0] = high_val if s > midpoint else low_val
-            return np.concatenate((actions, action_append), axis=-1)[start:end].astype(np.float32)
-        raise ValueError(f"file adim {adim}, target adim {self._action_dim}")
-
-    def _load_bounds(self, fp, robot_viewpoint):
-        if "locobot" in robot_viewpoint or "franka" in robot_viewpoint:
-            return (np.array([0.015, -0.3, 0.1, 0, 0], dtype=np.float32),
-                    np.array([0.55, 0.3, 0.4, 1, 1], dtype=np.float32))
-        return fp["low_bound"][:], fp["high_bound"][:]
-
-    def _pad_last(self, x, dim):
-        if x.shape[-1] != dim:
-            assert dim > x.shape[-1]
-            x = np.pad(x, [(0, 0), (0, dim - x.shape[-1])])
-        return x
-
-    def _load_states(self, fp, start, end):
-        return self._pad_last(fp["states"][start:end].astype(np.float32), self._config.robot_dim)
-
-    def _load_qpos(self, fp, start, end):
-        return self._pad_last(fp["qpos"][start:end].astype(np.float32), self._config.robot_joint_dim)
-
-    # ---- preprocessing (robonet_dataset.py:231-356) ----
-    def _preprocess_bounds(self, low, high, idx):
-        low, high = low.copy(), high.copy()
-        if "camera" in self._config.preprocess_action:
-            world2cam = _camera_dicts()[0][self._traj_robots[idx]]
-            xs, ys, zs = (low[0], high[0]), (low[1], high[1]), (low[2], high[2])
-            box = np.array([[x, y, z, 1.0] for x in xs for y in ys for z in zs]).T  # the 8 corners, homogeneous
-            c_box = ((world2cam @ box).T)[:, :3]
-            low[:3], high[:3] = np.min(c_box, 0), np.max(c_box, 0)
-        return low, high
-
-    def _preprocess_images_masks(self, images, masks):
-        cf = self._config
-        h, w = cf.image_height, cf.image_width
-        video = _resize(_to_tensor(images), h, w)
-        mask = _resize(_to_tensor(masks), h, w)
-        if not self._augment_img:
-            return video, mask.type(torch.bool).type(torch.float32)
-        # one random crop and one colour jitter per trajectory (robonet_dataset.py:261-291)
-        rand_crop = random.randint(0, 5)
-        th, tw = h - rand_crop, w - rand_crop
-        if (th, tw) == (h, w):
-            i = j = 0
-        else:  # tf.RandomCrop.get_params draws i then j from the torch generator
-            i = int(torch.randint(0, h - th + 1, size=(1,)).item())
-            j = int(torch.randint(0, w - tw + 1, size=(1,)).item())
-        jitter = random_color_jitter((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
-        video = jitter(_resize(video[:, :, i:i + th, j:j + tw], h, w))
-        mask = _resize(mask[:, :, i:i + th, j:j + tw], h, w).type(torch.bool).type(torch.float32)
-        return video, mask
-
-    def _preprocess_states(self, states, low, high, robot_viewpoint, idx):
-        states = states.copy()
-        if "locobot" in robot_viewpoint:
-            eef_pos = states[:, :3]
-        elif "franka" in robot_viewpoint:
-            eef_pos = states[:, :3]
-            eef_pos[:, :2] += np.array([-0.365, -0.06103333])  # LOCO_FRANKA_DIFF (robonet_dataset.py:21)
-            eef_pos[:, 2] = 0.14
-        else:
-            eef_pos = denormalize(states[:, :3], low[:3], high[:3])
-        if "camera" in self._config.preprocess_action:
-            world2cam = _camera_dicts()[0][self._traj_robots[idx]]
-            eef_pos = np.concatenate([eef_pos, np.ones((eef_pos.shape[0], 1))], 1).T
-            eef_pos = ((world2cam @ eef_pos).T)[:, :3]
-        states[:, :3] = normalize(eef_pos, low[:3], high[:3])
-        states[:, 4] = normalize(states[:, 4], low[4], high[4])
-        return states
-
-    def _preprocess_actions(self, states, actions, low, high, idx):
-        strategy = self._config.preprocess_action
-        if strategy == "raw":
-            return torch.from_numpy(actions)
-        if strategy != "camera_raw":
-            raise NotImplementedError  # state_infer / camera_state_infer: as the reference
-        w_to_c, c_to_w = (d[self._traj_robots[idx]] for d in _camera_dicts())
-        states = states.copy()
-        actions = np.zeros_like(actions)  # sic (robonet_dataset.py:383-384): the recorded actions are discarded
-        c_eef = denormalize(states[:, :3], low[:3], high[:3])
-        c_eef = np.concatenate([c_eef, np.ones((c_eef.shape[0], 1))], 1).T
-        eef = ((c_to_w @ c_eef).T)[:-1, :3]
-        nxt = eef + actions[:, :3]
-        hom = lambda p: np.concatenate([p, np.ones((p.shape[0], 1))], 1).T
-        actions[:, :3] = ((w_to_c @ hom(nxt)).T)[:, :3] - ((w_to_c @ hom(eef)).T)[:, :3]
-        return torch.from_numpy(actions)
+                if not pipe.camera:
+                    raise NotImplementedError
+                world = raw_states.copy()  # world-frame states, normalised by the file's own bounds
+                world[:, :3] = normalize(world[:, :3], raw_low[:3], raw_high[:3])
+                world[:, 4] = normalize(world[:, 4], raw_low[4], raw_high[4])
+                item.update(raw_low=raw_low, raw_high=raw_high, raw_actions=raw_actions.copy(), raw_states=world)
+        if self._movement is not None:
+            item["high_movement"] = self._movement[folder][path]
+        return item
 
 
 # --------------------------------------------------------------------------- #
@@ -392,14 +438,41 @@ def collate(items):
     return data.default_collate(items)
 
 
+def _dist_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 def create_loaders(config):
+    """robonet_dataloaders.py:21-80.  Under torch.distributed (one process per GPU) the TRAIN loader shards the files
+    with a DistributedSampler (same seed on every rank: disjoint shards of one shuffle, reshuffled per epoch through
+    `set_epoch`, which `get_batch` calls) and each rank draws its own window starts; otherwise the ranks would train
+    on identical batches and the gradient all-reduce would average copies of one gradient."""
     X_train, X_test, y_train, y_test = split_files(config)
-    train_data = RoboNetDataset(X_train, y_train, config, augment_img=getattr(config, "img_augmentation", False))
+    world, rank = _dist_info()
+    train_data = RoboNetDataset(X_train, y_train, config, augment_img=getattr(config, "img_augmentation", False),
+                                rng_seed=config.seed + rank if world > 1 else None)
     test_data = RoboNetDataset(X_test, y_test, config)
-    mk = lambda ds, bs: data.DataLoader(ds, num_workers=config.data_threads, batch_size=bs, shuffle=True, drop_last=False,
-                                        pin_memory=True, generator=torch.Generator().manual_seed(config.seed),
-                                        persistent_workers=config.data_threads > 0)
-    return mk(train_data, config.batch_size), mk(test_data, config.test_batch_size)
+    common = dict(num_workers=config.data_threads, drop_last=False, pin_memory=True,
+                  persistent_workers=config.data_threads > 0)
+    if world > 1:
+        sampler = data.distributed.DistributedSampler(train_data, num_replicas=world, rank=rank, shuffle=True,
+                                                      seed=config.seed)
+        train = data.DataLoader(train_data, batch_size=config.batch_size, sampler=sampler, **common)
+    else:
+        train = data.DataLoader(train_data, batch_size=config.batch_size, shuffle=True,
+                                generator=torch.Generator().manual_seed(config.seed), **common)
+    test = data.DataLoader(test_data, batch_size=config.test_batch_size, shuffle=True,
+                           generator=torch.Generator().manual_seed(config.seed), **common)
+    return train, test
+
+
+def _start_epoch(loader, epoch: int):
+    sampler = getattr(loader, "sampler", None)
+    if hasattr(sampler, "set_epoch"):
+        sampler.set_epoch(epoch)
 
 
 # --------------------------------------------------------------------------- #
@@ -441,7 +514,10 @@ class DevicePrefetcher:
     def _run(self):
         torch.cuda.set_device(self.device)
         try:
+            epoch = 0
             while not self._stop:
+                _start_epoch(self.loader, epoch)
+                epoch += 1
                 for batch in self.loader:
                     if self._stop:
                         return
@@ -474,7 +550,10 @@ def get_batch(loader, device, prefetch: bool = True):
     if prefetch and torch.device(device).type == "cuda":
         yield from DevicePrefetcher(loader, device)
         return
+    epoch = 0
     while True:
+        _start_epoch(loader, epoch)
+        epoch += 1
         for batch in loader:
             yield process_batch(batch, device)
 

@@ -38,19 +38,26 @@ def test_numeric_preprocessing_vs_reference_golden(golden_dir):
     class FP(dict):
         attrs = {}
     fp = FP({k[3:]: g[k] for k in g.files if k.startswith("in_")})
+    ds = object.__new__(D.RoboNetDataset)  # the window reader without files
+    ds._action_dim, ds._impute = 4, False
     for tag, view in (("sawyer", "sawyer_sudri0_c0"), ("locobot", "locobot_c0"), ("franka", "franka_c0")):
-        ds = object.__new__(D.RoboNetDataset)
-        ds._config = argparse.Namespace(robot_dim=5, robot_joint_dim=7, preprocess_action="raw")
-        ds._action_dim, ds._impute_autograsp_action, ds._traj_robots = 4, False, [view]
-        low, high = ds._load_bounds(fp, view)
-        states, actions, qpos = ds._load_states(fp, 2, 8), ds._load_actions(fp, low[4], high[4], 2, 7), ds._load_qpos(fp, 2, 8)
-        plow, phigh = ds._preprocess_bounds(low, high, 0)
-        pstates = ds._preprocess_states(states, plow, phigh, view, 0)
-        pact = ds._preprocess_actions(pstates, actions, plow, phigh, 0)
+        pipe = D.NumericPipeline(view, "raw")
+        low, high = pipe.view.bounds(fp)
+        states = D.fit_width(fp["states"][2:8].astype(np.float32), 5)
+        actions = ds.read_actions(fp, 2, 7, low[4], high[4])
+        qpos = D.fit_width(fp["qpos"][2:8].astype(np.float32), 7)
+        plow, phigh = pipe.bounds(low, high)
+        pstates = pipe.states(states, plow, phigh)
+        pact = pipe.actions(pstates, actions, plow, phigh)
         for name, val in (("low", low), ("high", high), ("states", states), ("actions", actions), ("qpos", qpos),
                           ("pstates", pstates), ("pactions", pact.numpy())):
             ref = g[f"{tag}_{name}"]
             assert val.dtype == ref.dtype and np.array_equal(val, ref), (tag, name)
+    # --impute_autograsp_action: the vectorised form of the reference's per-step loop (robonet_dataset.py:181-190)
+    nxt = fp["states"][:][1:, -1]
+    want = np.array([[1.0 if s_ > 0.5 else 0.0] for s_ in nxt])
+    got = D.imputed_gripper_actions(fp["actions"][:].astype(np.float32), nxt, 0.0, 1.0)
+    assert got.shape[1] == fp["actions"].shape[1] + 1 and np.array_equal(got[:, -1:], want)
     assert np.array_equal(D.normalize(g["norm_in"], fp["low_bound"], fp["high_bound"]), g["norm"])
     assert np.array_equal(D.denormalize(g["norm_in"], fp["low_bound"], fp["high_bound"]), g["denorm"])
 

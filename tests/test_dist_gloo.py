@@ -70,3 +70,49 @@ def test_allreduce_and_cost_gather_world2():
         res = _run(N)
         assert all(r[1] and r[2] for r in res), res
         assert res[0][3] == res[1][3] == [0, 1, 2]
+
+
+def _data_worker(rank, world, port, root, q):
+    import argparse
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from robot_aware_control_amd import data as D
+    c = argparse.Namespace(data_root=root, load_movement_info=False, video_length=8, n_past=1, n_future=2, action_dim=4,
+                           robot_dim=5, robot_joint_dim=7, impute_autograsp_action=False, image_width=64, image_height=48,
+                           seed=3, preload_ram=False, preprocess_action="raw", experiment="train_robonet",
+                           model_use_heatmap=False, train_val_split=0.75, img_augmentation=False, data_threads=0,
+                           batch_size=3, test_batch_size=2)
+    train_loader, _ = D.create_loaders(c)
+    gen = D.get_batch(train_loader, torch.device("cpu"), prefetch=False)
+    epochs = []
+    for _ in range(2):  # two epochs of this rank's shard (12 files / 2 ranks / batch 3 = 2 batches each)
+        epochs.append([int(i) for _ in range(2) for i in next(gen)["idx"]])
+    starts = train_loader.dataset._rng.randint(0, 1 << 30)  # the ranks' window-start streams differ
+    q.put((rank, epochs, int(starts)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_ranks_train_on_different_batches(tmp_path):
+    """create_loaders under torch.distributed: the train files are sharded over the ranks (DistributedSampler, reshuffled
+    per epoch), and each rank draws its own window starts -- identical batches on every rank would make the gradient
+    all-reduce average copies of one gradient (trainer.py has no distributed code to compare with: design of this repo)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import make_synthetic_robonet as mk
+    root = str(tmp_path)
+    assert mk.write(root, per_view=4, length=10, seed=1) == 16
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_data_worker, args=(r, 2, port, root, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, e0, s0), (_, e1, s1) = res
+    for a, b in zip(e0, e1):  # per epoch: disjoint shards that together cover the 12 training files
+        assert not set(a) & set(b) and sorted(a + b) == list(range(12)), (a, b)
+    assert e0[0] != e0[1]  # set_epoch: a new shuffle every epoch
+    assert s0 != s1
