@@ -253,9 +253,7 @@ class SyntheticRobotInputs:
     renders of the reference's analytical models cannot be produced in this image."""
 
     def __init__(self, dev):
-        from robot_aware_control_amd.robot_atlas import AtlasRobotModel
-        a = syn.synth_arm_atlas(device=dev)
-        self.model = AtlasRobotModel(a["atlas"], a["x0"], a["y0"], a["dx"], a["dy"], push_height=0.12, device=dev)
+        self.model = syn.SyntheticArmModel(dev).atlas(108, 121)  # 5 mm grid over the workspace
 
     def predict_batch(self, data, thick=True):
         return self.model.predict_batch(data, thick)

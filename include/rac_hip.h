@@ -382,11 +382,12 @@ int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask
  *                  reference's float32 / float64 promotion;
  *   masks[t][n]  = atlas[nearest grid node of (x, y)]: robot masks rendered ONCE by the analytical model on a regular
  *                  grid of end-effector positions (node (i, j) at (x0 + i dx, y0 + j dy); uint8 [ny][nx][HW]).
- * actions [T][N][A] time-first, start_state / low / high [5]; outputs states [T+1][N][5], masks [T+1][N][HW] fp32. */
+ * actions [T][N][A] time-first; start_state / low / high [5], or [N][5] with per_sample != 0 (the windows of a training
+ * batch: every sample has its own start and bounds); outputs states [T+1][N][5], masks [T+1][N][HW] fp32. */
 int rac_cem_robot_inputs(const float* actions, const float* start_state, const float* low, const float* high,
                          const uint8_t* atlas, int32_t nx, int32_t ny, float x0, float y0, float dx, float dy,
                          float diff_x, float diff_y, float push_height, float* states, float* masks, int32_t T,
-                         int32_t N, int32_t A, int32_t HW, void* stream);
+                         int32_t N, int32_t A, int32_t HW, int32_t per_sample, void* stream);
 
 /* torch.optim.Adam step (trainer.py:109-110,461), fused over one flat buffer. step >= 1. */
 int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -112,7 +112,7 @@ _SIGS = {
     "rac_kl_bwd": [vp, vp, vp, vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "rac_psnr_ssim": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "rac_cem_step_tail": [vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, i32, vp],
-    "rac_cem_robot_inputs": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp, vp, i32, i32, i32, i32, vp],
+    "rac_cem_robot_inputs": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
     "rac_version": [],
     "rac_device_arch": [],

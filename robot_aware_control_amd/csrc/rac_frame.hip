@@ -430,24 +430,28 @@ using namespace rac;
 // One workgroup per (t, n): thread 0 re-accumulates the <= T actions, all threads copy the H*W mask bytes as floats.
 struct RobotAtlasP {
   const float* actions;   // [T][N][A] (time first), world-frame displacements
-  const float* start;     // [5] normalised start state (states[0] of every candidate)
-  const float* low;       // [5]
-  const float* high;      // [5]
+  const float* start;     // [5] normalised start state (states[0] of every candidate), or [N][5] with per_sample
+  const float* low;       // [5] / [N][5]
+  const float* high;      // [5] / [N][5]
   const unsigned char* atlas;  // [ny][nx][HW]
   float* states;          // [T+1][N][5]
   float* masks;           // [T+1][N][HW]
   int T, N, A, HW, nx, ny;
   float x0, y0, inv_dx, inv_dy;  // grid: node (i, j) = (x0 + i / inv_dx, y0 + j / inv_dy) in the states' world frame
   float diff_x, diff_y, push_height;
+  int per_sample;         // start / low / high hold one row per candidate (trainer windows: every sample has its own)
 };
 
 __global__ void robot_atlas_kernel(RobotAtlasP p) {
   __shared__ int node;
   const int n = blockIdx.x, t = blockIdx.y;
   if (threadIdx.x == 0) {
+    const float* start = p.start + (p.per_sample ? (long)n * 5 : 0L);
+    const float* low = p.low + (p.per_sample ? (long)n * 5 : 0L);
+    const float* high = p.high + (p.per_sample ? (long)n * 5 : 0L);
     // denormalise the start, shift into the robot's own frame (float32, as the numpy / torch code does)
     float den[5];
-    for (int k = 0; k < 5; ++k) den[k] = p.start[k] * (p.high[k] - p.low[k]) + p.low[k];
+    for (int k = 0; k < 5; ++k) den[k] = start[k] * (high[k] - low[k]) + low[k];
     float raw[5];
     if (t == 0) {
       raw[0] = (den[0] - p.diff_x) + p.diff_x, raw[1] = (den[1] - p.diff_y) + p.diff_y;
@@ -462,7 +466,7 @@ __global__ void robot_atlas_kernel(RobotAtlasP p) {
       raw[2] = p.push_height, raw[3] = 0.f, raw[4] = 0.f;
     }
     float* o = p.states + ((long)t * p.N + n) * 5;
-    for (int k = 0; k < 5; ++k) o[k] = (raw[k] - p.low[k]) / (p.high[k] - p.low[k]);
+    for (int k = 0; k < 5; ++k) o[k] = (raw[k] - low[k]) / (high[k] - low[k]);
     int ix = (int)rintf((raw[0] - p.x0) * p.inv_dx), iy = (int)rintf((raw[1] - p.y0) * p.inv_dy);
     ix = ix < 0 ? 0 : (ix >= p.nx ? p.nx - 1 : ix);
     iy = iy < 0 ? 0 : (iy >= p.ny ? p.ny - 1 : iy);
@@ -610,12 +614,12 @@ int rac_cem_step_tail(const float* x4, const float* curr, const float* next_mask
 int rac_cem_robot_inputs(const float* actions, const float* start_state, const float* low, const float* high,
                          const uint8_t* atlas, int32_t nx, int32_t ny, float x0, float y0, float dx, float dy,
                          float diff_x, float diff_y, float push_height, float* states, float* masks, int32_t T,
-                         int32_t N, int32_t A, int32_t HW, void* stream) {
+                         int32_t N, int32_t A, int32_t HW, int32_t per_sample, void* stream) {
   RAC_REQUIRE(actions && start_state && low && high && atlas && states && masks, "rac_cem_robot_inputs: null pointer");
   RAC_REQUIRE(T >= 0 && N > 0 && A >= 2 && HW > 0 && nx > 0 && ny > 0 && dx > 0.f && dy > 0.f && T < 65535,
               "rac_cem_robot_inputs: bad sizes");
   RobotAtlasP p{actions, start_state, low, high, atlas, states, masks, T, N, A, HW, nx, ny, x0, y0, 1.f / dx, 1.f / dy,
-                diff_x, diff_y, push_height};
+                diff_x, diff_y, push_height, per_sample ? 1 : 0};
   hipLaunchKernelGGL(robot_atlas_kernel, dim3(N, T + 1), dim3(256), 0, ST(stream), p);
   return check_launch("rac_cem_robot_inputs");
 }

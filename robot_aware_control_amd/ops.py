@@ -366,29 +366,33 @@ def tag_amax(t: torch.Tensor, slot: torch.Tensor) -> torch.Tensor:
     """Remember a tensor's max-|x| slot on the tensor object (producers that know a bound, or consumers that already
     measured it, save the next consumer a reduction pass)."""
     t._rac_amax = slot
-    return t
+    t._rac_amax_ver = t._version  # an in-place change afterwards (autograd accumulating a second gradient into this
+    return t                      # buffer: `old.add_(new)`) bumps the version: the tag no longer describes the tensor
 
 
 def amax_tag(t):
-    return None if t is None else getattr(t, "_rac_amax", None)
+    if t is None or getattr(t, "_rac_amax_ver", None) != t._version:
+        return None
+    return getattr(t, "_rac_amax", None)
 
 
 def retag(t, slot):
     """Saved tensors come back from autograd as new Python objects: put the slot measured in forward() back on."""
     if t is not None and slot is not None:
         t._rac_amax = slot
+        t._rac_amax_ver = t._version
     return t
 
 
 def amax_for(t: torch.Tensor, per_image: bool = False) -> torch.Tensor:
     """The tensor's slot (per_image: its B slots), measured now unless a producer left a tag of that kind."""
-    slot = getattr(t, "_rac_amax", None)
+    slot = amax_tag(t)  # (None for a tensor modified since it was tagged)
     want = t.shape[0] if per_image else 1
     if slot is not None and getattr(slot, "_rac_bound1", False):
         return amax_one(t.device, want)  # |t| <= 1 whatever the granularity
     if slot is None or slot.numel() != want:
         slot = amax_of(t, per_image=per_image)
-        t._rac_amax = slot
+        tag_amax(t, slot)
     return slot
 
 

@@ -36,10 +36,14 @@ WORKSPACE_HIGH = (0.55, 0.3, 0.4, 1.0, 1.0)
 
 class AtlasRobotModel:
     def __init__(self, atlas: torch.Tensor, x0: float, y0: float, dx: float, dy: float, push_height: float,
-                 frame_diff=(0.0, 0.0), device=None):
+                 frame_diff=(0.0, 0.0), device=None, preprocess_action: str = "raw", exact=None):
         """atlas: uint8 / bool (ny, nx, H, W), node (i, j) rendered with the end effector at (x0 + i dx, y0 + j dy) in
         the frame of the (de-normalised) states handed to `predict_batch`; `frame_diff`: offset of the robot's own
-        frame, subtracted before and added after the propagation as the reference does (LOCO_WX250S_DIFF, ...)."""
+        frame, subtracted before and added after the propagation as the reference does (LOCO_WX250S_DIFF, ...).
+        `preprocess_action`: the config's strategy -- anything but "raw" makes `predict_batch` read the world-frame
+        `raw_actions / raw_states / raw_low / raw_high` of the batch, as the analytical models do
+        (locobot_model.py:113-127).  `exact`: the model the atlas was rendered from (kept by `build`): the planner can
+        re-roll its final elites with exactly rendered masks (TrajectorySampler, `cem_exact_elites`)."""
         dev = torch.device(device if device is not None else "cuda")
         if dev.type != "cuda":
             raise _lib.RacError("AtlasRobotModel runs on the GPU (no CPU fallback)")
@@ -49,6 +53,8 @@ class AtlasRobotModel:
         self.push_height = float(push_height)
         self.diff = (float(frame_diff[0]), float(frame_diff[1]))
         self.device = dev
+        self.preprocess_action = preprocess_action
+        self.exact = exact
 
     # ------------------------------------------------------------------ build / cache
     @classmethod
@@ -80,7 +86,7 @@ class AtlasRobotModel:
         atlas = torch.cat(tiles, 0)
         atlas = atlas.view(ny, nx, atlas.shape[-2], atlas.shape[-1])
         return cls(atlas, xs[0], ys[0], (xs[-1] - xs[0]) / max(nx - 1, 1), (ys[-1] - ys[0]) / max(ny - 1, 1), push_height,
-                   frame_diff, device)
+                   frame_diff, device, exact=robot_model)
 
     def save(self, path):
         np.savez_compressed(path, atlas=np.packbits(self.atlas.cpu().numpy(), axis=-1), shape=np.array(self.atlas.shape),
@@ -96,23 +102,30 @@ class AtlasRobotModel:
 
     # ------------------------------------------------------------------ the analytical models' contract
     def predict_batch(self, data, thick=True):
-        """data: states (T+1, N, 5) whose row 0 is the normalised start state (the same for every candidate),
-        actions (T, N, A) world-frame displacements, low / high (N, 5).  Returns device tensors
+        """data: states (T+1, N, 5) whose row 0 holds each sample's normalised start state, actions (T, N, A) world-frame
+        displacements, low / high (N, 5) -- with a non-"raw" `preprocess_action` the batch's `raw_*` entries instead
+        (world-frame actions and states, the file's own bounds).  Every sample is propagated from ITS start with ITS
+        bounds (a planner's candidates share them; the windows of a training batch do not).  Returns device tensors
         (states (T+1, N, 5) normalised, masks (T+1, N, 1, H, W) in {0, 1})."""
         dev = self.device
-        T1, N, _ = data["states"].shape
+        pre = "" if self.preprocess_action == "raw" else "raw_"
+        if pre and any(pre + k not in data for k in ("actions", "states", "low", "high")):
+            raise KeyError(f"preprocess_action={self.preprocess_action!r}: the batch must carry raw_actions, raw_states, "
+                           f"raw_low and raw_high (robonet_dataset.py:148-166)")
+        src_states, src_actions = data[pre + "states"], data[pre + "actions"]
+        T1, N, _ = src_states.shape
         T = T1 - 1
-        actions = data["actions"].to(dev, torch.float32).contiguous()
+        actions = src_actions.to(dev, torch.float32).contiguous()
         if T and tuple(actions.shape[:2]) != (T, N):
-            raise ValueError(f"actions {tuple(actions.shape)} do not match states {tuple(data['states'].shape)}")
+            raise ValueError(f"actions {tuple(actions.shape)} do not match states {tuple(src_states.shape)}")
         A = actions.shape[2] if T else 2
-        start = data["states"][0, 0].to(dev, torch.float32).contiguous()
-        low, high = data["low"][0].to(dev, torch.float32).contiguous(), data["high"][0].to(dev, torch.float32).contiguous()
+        rows = lambda t: torch.as_tensor(t).to(dev, torch.float32).reshape(-1, 5).expand(N, 5).contiguous()
+        start, low, high = rows(src_states[0]), rows(data[pre + "low"]), rows(data[pre + "high"])
         states = torch.empty((T1, N, 5), device=dev, dtype=torch.float32)
         masks = torch.empty((T1, N, 1, self.H, self.W), device=dev, dtype=torch.float32)
         if not T:
             actions = torch.zeros((1, N, 2), device=dev)
         _lib.call("rac_cem_robot_inputs", actions.data_ptr(), start.data_ptr(), low.data_ptr(), high.data_ptr(),
                   self.atlas.data_ptr(), self.nx, self.ny, self.x0, self.y0, self.dx, self.dy, self.diff[0], self.diff[1],
-                  self.push_height, states.data_ptr(), masks.data_ptr(), T, N, A, self.H * self.W, _lib.stream_ptr())
+                  self.push_height, states.data_ptr(), masks.data_ptr(), T, N, A, self.H * self.W, 1, _lib.stream_ptr())
         return states, masks

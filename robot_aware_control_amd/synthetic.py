@@ -139,3 +139,36 @@ def synth_state_dict(model, seed: int = 0, action_gain: float = 200.0, action_di
         else:  # conv biases
             out[key] = normal(0.05)
     return out
+
+
+class SyntheticArmModel:
+    """The analytical robot models' `predict_batch` contract (src/dataset/wx250s/wx250s_model.py:121-163) over the
+    synthetic arm: states by the same propagation as `AtlasRobotModel` (pinned to the reference's goldens), masks
+    rendered EXACTLY at every candidate's end-effector position (`arm_mask`) -- what an atlas of these masks
+    approximates by its nearest grid node.  Stands in for the MuJoCo renders in tests and the benchmark."""
+
+    def __init__(self, device, push_height: float = 0.12, H: int = 64, W: int = 64, frame_diff=(0.0, 0.0)):
+        from .robot_atlas import WORKSPACE_HIGH, WORKSPACE_LOW, AtlasRobotModel
+        self.device, self.H, self.W = torch.device(device), H, W
+        self.x_range, self.y_range = (WORKSPACE_LOW[0], WORKSPACE_HIGH[0]), (WORKSPACE_LOW[1], WORKSPACE_HIGH[1])
+        self._states = AtlasRobotModel(torch.zeros((1, 1, H, W), dtype=torch.uint8), 0.0, 0.0, 1.0, 1.0, push_height,
+                                       frame_diff, device)
+        self.calls = 0
+
+    def atlas(self, nx: int, ny: int):
+        """AtlasRobotModel over a (ny, nx) grid of this arm's renders, remembering this model as its `exact` source."""
+        from .robot_atlas import AtlasRobotModel
+        a = synth_arm_atlas(nx, ny, self.H, self.W, self.x_range, self.y_range, self.device)
+        return AtlasRobotModel(a["atlas"], a["x0"], a["y0"], a["dx"], a["dy"], self._states.push_height,
+                               self._states.diff, self.device, exact=self)
+
+    def predict_batch(self, data, thick=True):
+        self.calls += 1
+        states, _ = self._states.predict_batch(data, thick)
+        T1, N, _ = states.shape
+        low = torch.as_tensor(data["low"]).to(self.device, torch.float32).reshape(-1, 5)[:, :2]
+        high = torch.as_tensor(data["high"]).to(self.device, torch.float32).reshape(-1, 5)[:, :2]
+        xy = states[..., :2] * (high - low) + low  # metric end-effector positions, (T+1, N, 2)
+        masks = arm_mask(xy[..., 0].reshape(-1), xy[..., 1].reshape(-1), self.H, self.W, self.x_range, self.y_range,
+                         self.device)
+        return states, masks.view(T1, N, 1, self.H, self.W).float()

@@ -58,6 +58,7 @@ class TrajectorySampler(object):
         self.low = torch.tensor([[0.015, -0.3, 0.1, 0, 0]], dtype=torch.float32)   # trajectory_sampler.py:22-23
         self.high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
         self.robot_model = robot_model
+        self._refining = False  # inside the exact re-roll of the elites (no sharding, no nested refinement)
         self._robot_ctor = (cam_ext, franka_ik, wx250s_bot, push_height, default_pitch, default_roll)
         if os.environ.get("RAC_GC_FREEZE", "0") == "1":  # opt-in, see PredictionTrainer.__init__
             import gc
@@ -83,8 +84,9 @@ class TrajectorySampler(object):
                                                          cam_ext=cam_ext)
         return self.robot_model
 
-    def _predict_robot(self, action_sequences, start, N, T):
-        """states (T+1,N,5) normalised, masks (T+1,N,1,H,W) for every candidate (trajectory_sampler.py:86-109)."""
+    def _robot_data(self, action_sequences, start, N, T):
+        """The batch `predict_batch` is asked about: every candidate starts from the current robot state
+        (trajectory_sampler.py:86-99)."""
         cfg = self.cfg
         states = torch.zeros((T + 1, N, 5), dtype=torch.float32)
         qpos = torch.zeros((T + 1, N, cfg.robot_joint_dim), dtype=torch.float32)
@@ -95,9 +97,34 @@ class TrajectorySampler(object):
                                                  else LOCO_WX250S_DIFF)
         states[0, :] = (start_state - self.low) / (self.high - self.low)  # robonet_dataset.normalize
         qpos[0, :] = torch.tensor(start.qpos)
-        start_data = {"states": states, "qpos": qpos, "actions": action_sequences.permute(1, 0, 2),
-                      "low": self.low.repeat(N, 1), "high": self.high.repeat(N, 1)}
-        return self._get_robot_model().predict_batch(start_data, thick=True)
+        return {"states": states, "qpos": qpos, "actions": action_sequences.permute(1, 0, 2),
+                "low": self.low.repeat(N, 1), "high": self.high.repeat(N, 1)}
+
+    def _predict_robot(self, action_sequences, start, N, T):
+        """states (T+1,N,5) normalised, masks (T+1,N,1,H,W) for every candidate (trajectory_sampler.py:86-109)."""
+        return self._get_robot_model().predict_batch(self._robot_data(action_sequences, start, N, T), thick=True)
+
+    def _refine_elites(self, sum_cost, action_sequences, start, goal):
+        """`cfg.cem_exact_elites = M` with an atlas robot model that remembers the model it was rendered from
+        (`AtlasRobotModel.exact`): the M best candidates of the atlas pass are rolled out again with EXACTLY rendered
+        masks (the reference's own `predict_batch`, trajectory_sampler.py:86-109 -- M per-candidate renders instead of
+        N) and their costs replaced, so the elite set is the one exact masks give whenever it lies inside the screened
+        top M.  Every rank re-rolls the same M candidates (no collective)."""
+        M = int(getattr(self.cfg, "cem_exact_elites", 0) or 0)
+        exact = getattr(self.robot_model, "exact", None)
+        if M <= 0 or exact is None or self._refining or not self._needs_robot():
+            return sum_cost
+        n = len(sum_cost)
+        top = np.sort(np.argsort(-sum_cost, kind="stable")[:min(M, n)])
+        atlas_model, self.robot_model, self._refining = self.robot_model, exact, True
+        try:
+            redo = self.generate_model_rollouts(action_sequences[:n][torch.from_numpy(top)].clone(), start, goal)
+        finally:
+            self.robot_model, self._refining = atlas_model, False
+        sum_cost = sum_cost.copy()
+        sum_cost[top] = redo["sum_cost"]
+        self.last_refined = top
+        return sum_cost
 
     @torch.no_grad()
     def generate_model_rollouts(self, action_sequences, start: State, goal: DemoGoalState, opt_traj=None,
@@ -134,7 +161,7 @@ class TrajectorySampler(object):
         # the debug outputs (predicted frames / per-step costs of the elites, indexed over ALL candidates) are not
         # gathered: a call that asks for them rolls every candidate out on every rank
         if (dist.is_available() and dist.is_initialized() and getattr(cfg, "cem_shard", True)
-                and not (ret_obs or ret_step_cost)):
+                and not (ret_obs or ret_step_cost) and not self._refining):
             world, rank = dist.get_world_size(), dist.get_rank()
         lo, hi = shard_bounds(N, world, rank)
         n_local = hi - lo
@@ -197,6 +224,7 @@ class TrajectorySampler(object):
             if ret_obs:
                 rollouts["optimal_obs"] = all_obs[-1].numpy()
             sum_cost = sum_cost[:-1]
+        sum_cost = self._refine_elites(sum_cost, action_sequences, start, goal)
         rollouts["sum_cost"] = sum_cost
         if ret_obs:
             topk_idx = np.argsort(sum_cost)[-cfg.topk:]

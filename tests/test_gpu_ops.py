@@ -693,3 +693,33 @@ def test_compiled_cpp_consumer_calls_the_library(dev):
     assert res.returncode == 0, res.stdout + res.stderr
     kv = dict(line.split() for line in res.stdout.splitlines())
     assert float(kv["conv_max_rel_err"]) < 1e-5 and int(kv["bad_ksize_rc"]) == -1
+
+
+def test_amax_tag_does_not_survive_gradient_accumulation(dev):
+    """A conv output with TWO consumers: autograd sums their gradients, possibly in place into the first one's buffer,
+    whose max-|x| tag (left by the data-gradient kernel that produced it) then under-estimates the sum.  The tag carries
+    the tensor version it was measured at, so the accumulated gradient is measured again: dx and dW stay at fp32 level
+    even when the second gradient is 300 times the first."""
+    from robot_aware_control_amd import ops
+    B, H, W, C = 4, 8, 8, 128
+    x = to_map(rnd(71, B, C, H, W), dev).requires_grad_(True)
+    ws = [cl_weight(rnd(72 + i, C, C, 3, 3) * 0.05).to(dev).requires_grad_(True) for i in range(3)]
+    bs = [rnd(75 + i, C, scale=0.1).to(dev).requires_grad_(True) for i in range(3)]
+    y = ops.ConvBias.apply(x, None, ws[0], bs[0], ops.ACT_NONE)
+    a = ops.ConvBias.apply(y, None, ws[1], bs[1], ops.ACT_NONE)
+    b = ops.ConvBias.apply(y, None, ws[2], bs[2], ops.ACT_NONE)
+    ga, gb = to_map(rnd(78, B, C, H, W), dev), to_map(rnd(79, B, C, H, W) * 300.0, dev)
+    torch.autograd.backward([a, b], [ga, gb])
+    xr = from_map(x.detach()).double().requires_grad_(True)
+    wr = [w.detach().cpu().double().requires_grad_(True) for w in ws]
+    yr = F.conv2d(xr, wr[0], bs[0].detach().cpu().double(), 1, 1)
+    ar = F.conv2d(yr, wr[1], bs[1].detach().cpu().double(), 1, 1)
+    br = F.conv2d(yr, wr[2], bs[2].detach().cpu().double(), 1, 1)
+    torch.autograd.backward([ar, br], [from_map(ga).double(), from_map(gb).double()])
+    assert relerr(from_map(x.grad), xr.grad) < 2e-6
+    assert relerr(ws[0].grad.cpu(), wr[0].grad) < 2e-6
+    # the mechanism itself: an in-place change invalidates the tag
+    t = ops.tag_amax(x.detach().clone(), ops.amax_slot(dev))
+    assert ops.amax_tag(t) is not None
+    t.add_(1.0)
+    assert ops.amax_tag(t) is None and int(ops.amax_for(t).item()) == int(t.abs().max().view(torch.int32).item())

@@ -153,3 +153,60 @@ def test_robot_aware_get_action_without_per_candidate_python(dev, atlas_model):
     a, b = acts["atlas_trace"][1], acts["toy_trace"][1]
     assert np.abs(a["sum_cost"] - b["sum_cost"]).max() / np.abs(b["sum_cost"]).max() < 2e-2
     assert acts["atlas"].shape == (T, 2) and np.all(np.isfinite(acts["atlas"]))
+
+
+def test_atlas_masks_quantified_and_exact_elites(dev):
+    """How much do nearest-grid-node masks cost?  cfg3 geometry (1000 candidates x 14 steps, g 512 / z 64, robot-aware
+    flags, dontcare cost) with the synthetic arm: costs and elite sets of atlas masks at 20 / 10 / 5 / 2.5 mm grid spacing
+    against EXACTLY rendered masks for every candidate -- and the remedy that does not depend on the spacing: with
+    `cem_exact_elites = 20` the 20 best candidates of the atlas pass are re-rolled with exact masks, after which the
+    top 5 (indices, order, and cost BITS: rollouts are batch-invariant) are the exact run's."""
+    from robot_aware_control_amd.model import SVGConvModel
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    flags = dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=True, reconstruction_loss="dontcare_l1")
+    N, T, K = 1000, 14, 5
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=2, candidates_batch_size=N, sample_mean=True, reward_type="dontcare",
+                  topk=K, **flags)
+    d = dict(cfg.__dict__)
+    d.update(device=dev, debug_cem=False, log_dir="/tmp/rac_test", img_cost_threshold=None, img_cost_world_norm=True,
+             experiment="control_toy", robot_joint_dim=5, cem_shard=True, cem_exact_elites=0)
+    ns = argparse.Namespace(**d)
+    model = SVGConvModel(ns)
+    model.load_state_dict(syn.synth_state_dict(model, seed=9))
+    model.eval()
+    prob = syn.synth_cem_problem(seed=11, N=N, T=T, goal_blend=0.15)
+    arm = syn.SyntheticArmModel(dev)
+    start = State(img=prob["start_img"], state=np.array([0.28, 0.0, 0.12, 0.0, 0.0], np.float32), qpos=np.zeros(5, np.float32))
+    goal_mask = syn.arm_mask([0.40], [0.10]).numpy().astype(bool)
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=[goal_mask])
+    exact = TrajectorySampler(ns, model, robot_model=arm).generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+    order = np.argsort(-exact, kind="stable")
+    scale = np.abs(exact).max()
+    print(f"exact masks: top-{K} {list(order[:K])}, K/K+1 gap {(exact[order[K - 1]] - exact[order[K]]) / scale:.1e}")
+    rows = []
+    for nx, ny, mm in ((28, 31, 20), (54, 61, 10), (108, 121, 5), (215, 241, 2.5)):
+        rm = arm.atlas(nx, ny)
+        _, m_atlas = rm.predict_batch(TrajectorySampler(ns, model, robot_model=rm)._robot_data(prob["actions"], start, N, T))
+        _, m_exact = arm.predict_batch(TrajectorySampler(ns, model, robot_model=rm)._robot_data(prob["actions"], start, N, T))
+        pix = float((m_atlas != m_exact).float().mean())
+        got = TrajectorySampler(ns, model, robot_model=rm).generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+        err = float(np.abs(got - exact).max() / scale)
+        o = np.argsort(-got, kind="stable")
+        same5 = len(set(o[:K]) & set(order[:K]))
+        in20 = len(set(order[:K]) & set(o[:20]))
+        ns.cem_exact_elites = 20
+        calls = arm.calls
+        ref = TrajectorySampler(ns, model, robot_model=rm).generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+        ns.cem_exact_elites = 0
+        assert arm.calls == calls + 1  # ONE exact predict_batch, for the 20 finalists
+        o2 = np.argsort(-ref, kind="stable")
+        fixed = list(o2[:K]) == list(order[:K]) and np.array_equal(ref[o2[:K]], exact[order[:K]])
+        rows.append((mm, pix, err, same5, in20, fixed))
+        print(f"atlas {mm} mm ({nx}x{ny} nodes): {100 * pix:.2f} % of mask pixels differ, max cost error {err:.1e} of max |cost|, "
+              f"{same5}/{K} of the exact top-{K} in the atlas top-{K}, {in20}/{K} in its top-20; exact-elite refinement "
+              f"restores the exact top-{K}: {fixed}")
+    errs = [r[2] for r in rows]
+    assert errs[-1] <= errs[0] and rows[2][1] < 0.01        # finer grids cost less; < 1 % of pixels at 5 mm
+    assert all(r[4] == K for r in rows[1:])                  # the exact elites survive the atlas screening (<= 10 mm)
+    assert all(r[5] for r in rows[1:])                       # ... so re-rolling 20 finalists restores them, bit for bit
