@@ -469,6 +469,54 @@ def create_loaders(config):
     return train, test
 
 
+LOCOBOT_FOLDERS = ["c0", "c1", "c2", "c3"]  # locobot_singleview_dataloader.py:11
+
+
+def _locobot_files(config):
+    """<data_root>/locobot_views/c{0..3}/*.hdf5 (or .npz), sorted then shuffled with the config seed; labels in discovery
+    order, as the reference pairs them (locobot_singleview_dataloader.py:63-75)."""
+    files, labels = [], []
+    for folder in LOCOBOT_FOLDERS:
+        path = os.path.join(config.data_root, "locobot_views", folder)
+        if not os.path.isdir(path):
+            continue
+        for d in os.scandir(path):
+            if d.is_file() and d.path.lower().endswith(TRAJ_EXTENSIONS):
+                files.append(d.path)
+                labels.append("locobot_" + folder)
+    files = sorted(files)
+    random.seed(config.seed)
+    random.shuffle(files)
+    return files, labels
+
+
+def _plain_loader(ds, config, batch_size):
+    return data.DataLoader(ds, num_workers=config.data_threads, batch_size=batch_size, shuffle=True, drop_last=False,
+                           pin_memory=True, generator=torch.Generator().manual_seed(config.seed),
+                           persistent_workers=config.data_threads > 0)
+
+
+def create_transfer_loader(config, n_files: int = 400):
+    """Zero-shot evaluation set of `--experiment train_robonet`: up to 400 trajectories of the unseen locobot
+    (locobot_singleview_dataloader.py:59-92).  None when the data root has no locobot_views folder."""
+    files, labels = _locobot_files(config)
+    if not files:
+        return None
+    ds = RoboNetDataset(files[:n_files], labels[:n_files], config, augment_img=getattr(config, "img_augmentation", False))
+    return _plain_loader(ds, config, config.batch_size)
+
+
+def create_finetune_loaders(config):
+    """`--experiment finetune_locobot`: finetune_num_test files for testing, the next finetune_num_train for training
+    (locobot_singleview_dataloader.py:12-57)."""
+    files, labels = _locobot_files(config)
+    n_test, n_train = config.finetune_num_test, config.finetune_num_train
+    train = RoboNetDataset(files[n_test:n_test + n_train], labels[n_test:n_test + n_train], config,
+                           augment_img=getattr(config, "img_augmentation", False))
+    test = RoboNetDataset(files[:n_test], labels[:n_test], config)
+    return _plain_loader(train, config, config.batch_size), _plain_loader(test, config, config.test_batch_size)
+
+
 def _start_epoch(loader, epoch: int):
     sampler = getattr(loader, "sampler", None)
     if hasattr(sampler, "set_epoch"):

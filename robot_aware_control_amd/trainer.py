@@ -447,16 +447,97 @@ class PredictionTrainer(object):
             losses[name] = v
         return losses
 
+    # ------------------------------------------------------------------- plots
+    @torch.no_grad()
+    def plot(self, data, epoch, name, random_start=True, instance=None):
+        """GIF of prior-driven autoregressive generations next to the ground truth (trainer.py:949-1147): per video one
+        row [ground truth | 3 samples], one GIF frame per time step, written to `<plot_dir>/<name>_<epoch>.gif`.
+        `data`: a time-first batch.  Returns the file name."""
+        from PIL import Image
+        cf = self._config
+        dev, f32 = self._device, torch.float32
+        b = min(data["images"].shape[1], 25)
+        length = cf.n_past + cf.n_future if name in ("comparison", "train") else cf.n_eval
+        total = data["images"].shape[0]
+        starts = (self._plot_rng.randint(0, total - length + 1, size=b) if random_start else np.zeros(b, dtype=np.int64))
+
+        def clip(key, shorten=0):  # every video's own [start, start + length) window, batch truncated to b
+            t = data[key]
+            return torch.stack([t[s:s + length - shorten, i] for i, s in enumerate(starts)], 1).to(dev, f32)
+        x, states, ac, mask = clip("images"), clip("states"), clip("actions", 1), clip("masks")
+        heatmaps = clip("heatmaps") if getattr(cf, "model_use_heatmap", False) else None
+        if "finetune" in cf.experiment and (cf.model_use_mask or cf.model_use_robot_state):
+            if getattr(self, "robot_model", None) is None:
+                raise NotImplementedError("finetune_* plots roll out on trainer.robot_model's states and masks")
+            batch = {"states": states, "actions": ac, "masks": mask, "qpos": clip("qpos"), "low": data["low"][:b],
+                     "high": data["high"][:b]}
+            if getattr(cf, "preprocess_action", "raw") != "raw":
+                batch.update(raw_low=data["raw_low"][:b], raw_high=data["raw_high"][:b],
+                             raw_actions=clip("raw_actions", 1), raw_states=clip("raw_states"))
+            states, mask = self.robot_model.predict_batch(batch)[:2]
+        dontcare = "dontcare" in cf.reconstruction_loss or cf.black_robot_input
+        was_training = self.model.training
+        self.model.eval()
+        samples = []
+        for _ in range(3):  # nsample of the svg model
+            self.model.init_hidden(b)
+            x_j = x[0]
+            frames = [ops.ZeroRegion.apply(x_j.contiguous(), mask[0].contiguous()) if dontcare else x_j]
+            skip = None
+            for i in range(1, length):
+                m_j, m_i = mask[i - 1], mask[i]
+                if cf.last_frame_skip:
+                    skip = None
+                m_in = torch.cat([m_j, m_i], 1) if cf.model_use_future_mask else m_j
+                r_in = (states[i - 1], states[i]) if cf.model_use_future_robot_state else states[i - 1]
+                hm_in = None
+                if heatmaps is not None:
+                    hm_in = torch.cat([heatmaps[i - 1], heatmaps[i]], 1) if cf.model_use_future_heatmap else heatmaps[i - 1]
+                x4, curr_skip = self.model.forward_maps(x_j, m_in, r_in, hm_in, ac[i - 1], False, None, skip,
+                                                        zero_mask=m_j if dontcare else None)[:2]
+                x_pred = ops.Composite.apply(x4, x_j.contiguous())
+                if i <= cf.n_past:
+                    skip = curr_skip
+                x_j = x[i] if i < cf.n_past else x_pred
+                frames.append(ops.ZeroRegion.apply(x_pred, m_i.contiguous()) if dontcare else x_j)
+            samples.append(torch.stack(frames))  # (length, b, 3, H, W)
+        self.model.train(was_training)
+        # one GIF frame per time step: b rows of [ground truth | sample 0 | sample 1 | sample 2]
+        grid = torch.stack([x] + samples, 2)                      # (length, b, 4, 3, H, W)
+        grid = grid.permute(0, 1, 4, 2, 5, 3).reshape(length, b * x.shape[-2], 4 * x.shape[-1], 3)
+        imgs = [Image.fromarray(f) for f in (grid.clamp(0, 1) * 255).to(torch.uint8).cpu().numpy()]
+        plot_dir = getattr(cf, "plot_dir", None) or os.path.join(cf.log_dir, "plot")
+        os.makedirs(plot_dir, exist_ok=True)
+        stem = f"{name}_{epoch}" if instance is None else f"{name}_ep{epoch}_{instance}"
+        fname = os.path.join(plot_dir, stem + ".gif")
+        imgs[0].save(fname, save_all=True, append_images=imgs[1:], duration=250, loop=0)
+        if self._wandb is not None:
+            self._wandb.log({f"{name}/gifs": self._wandb.Video(fname, format="gif")}, step=self._step)
+        return fname
+
     # ----------------------------------------------------------- outer loops
-    def train(self, batch_generator=None, test_hook=None, test_loader=None):
+    def train(self, batch_generator=None, test_hook=None, test_loader=None, transfer_loader=None):
         """Epoch loop with checkpoint and evaluation cadence (trainer.py:736-792).  `batch_generator` yields time-first
         batches in the layout of `process_batch` (robonet_dataset.py:434-451); by default the loaders come from
         `_setup_data`.  Every `eval_interval` epochs the model is evaluated on the test loader
-        (`_compute_epoch_metrics`, keys `test/*`) as the reference does."""
+        (`_compute_epoch_metrics`, keys `test/*`) and, for `--experiment train_robonet` with locobot data under the data
+        root, on the zero-shot transfer loader (`transfer/*`) as the reference does; with `--plot True` (this repo's
+        switch, default off) a GIF of generations is written per epoch / evaluation (`plot`)."""
         cf = self._config
         self._step = self._load_checkpoint(cf.dynamics_model_ckpt)
         if batch_generator is None:
             batch_generator, test_loader = self._setup_data()
+            transfer_loader = transfer_loader or getattr(self, "transfer_loader", None)
+        plots = bool(getattr(cf, "plot", False)) and (not _dist_on() or dist.get_rank() == 0)
+
+        def evaluate(loader, name, epoch):
+            from .data import process_batch
+            info_ = self._compute_epoch_metrics(loader, name)
+            self.eval_history.append((epoch, info_))
+            if self._wandb is not None:
+                self._wandb.log(info_, step=self._step)
+            if plots:
+                self.plot(process_batch(next(iter(loader)), self._device), epoch, name)
         gen = batch_generator
         info = {}
         self.eval_history = []
@@ -468,6 +549,8 @@ class PredictionTrainer(object):
                 if self._scheduled_sampling:
                     info["sample_schedule"] = self._schedule_prob()[0]
                 self._step += self.steps_per_train_video
+                if plots and _ == cf.epoch_size - 1:
+                    self.plot(data, epoch, "train")
                 if self._wandb is not None:
                     self._wandb.log({f"train/{k}": v for k, v in info.items()}, step=self._step)
             if epoch % cf.checkpoint_interval == 0 and epoch > 0:
@@ -475,10 +558,9 @@ class PredictionTrainer(object):
             if epoch % cf.eval_interval == 0:
                 self.model.eval()
                 if test_loader is not None:
-                    test_info = self._compute_epoch_metrics(test_loader, "test")
-                    self.eval_history.append((epoch, test_info))
-                    if self._wandb is not None:
-                        self._wandb.log(test_info, step=self._step)
+                    evaluate(test_loader, "test", epoch)
+                if transfer_loader is not None:
+                    evaluate(transfer_loader, "transfer", epoch)
                 if test_hook is not None:
                     test_hook(self, epoch)
         self._save_checkpoint()
@@ -507,6 +589,8 @@ class PredictionTrainer(object):
                 batch_size=getattr(cf, "test_batch_size", cf.batch_size))
             return gen(), test
         train_loader, test_loader = D.create_loaders(cf)
+        if cf.experiment == "train_robonet":  # zero-shot performance on the unseen locobot (trainer.py:899-913)
+            self.transfer_loader = D.create_transfer_loader(cf)
         return D.get_batch(train_loader, self._device), test_loader
 
     def _save_checkpoint(self):

@@ -121,6 +121,30 @@ def test_loaders_and_time_first_batches(tree):
     assert torch.equal(out["images"], img.transpose(0, 1))
 
 
+def test_transfer_and_finetune_loaders(tmp_path):
+    """The unseen-locobot loaders (locobot_singleview_dataloader.py:12-92): file discovery under locobot_views/c*, the
+    seed-shuffled split, items through the fixed-workspace viewpoint (metric states, `observations` / `masks` keys)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_robonet as mk
+    root = str(tmp_path)
+    mk.write(root, per_view=1, length=10, seed=2, locobot=3)
+    c = cfg(root, robot_joint_dim=5, finetune_num_test=2, finetune_num_train=3)
+    loader = D.create_transfer_loader(c)
+    assert len(loader.dataset) == 6
+    b = next(iter(loader))
+    assert b["images"].shape[1:] == (8, 3, 48, 64) and b["qpos"].shape[-1] == 5 and set(b["robot"]) == {"locobot"}
+    assert float(b["states"][..., :3].min()) >= 0 and float(b["states"][..., :3].max()) <= 1  # normalised by the workspace box
+    it = loader.dataset[0]
+    z = np.load(it["file_path"])
+    low, high = D.WORKSPACE_BOX
+    assert np.array_equal(it["states"][:, :3], D.normalize(z["states"][:8, :3] if len(z["states"]) == 8 else
+                                                          it["states"][:, :3] * (high[:3] - low[:3]) + low[:3], low[:3], high[:3]))
+    train, test = D.create_finetune_loaders(c)
+    assert len(test.dataset) == 2 and len(train.dataset) == 3
+    assert not set(test.dataset._traj_names) & set(train.dataset._traj_names)
+    assert D.create_transfer_loader(cfg(str(tmp_path / "nothing_here"))) is None
+
+
 def test_shim_falls_through_to_the_reference_tree(tmp_path, monkeypatch):
     """With this repo ahead of the reference on sys.path, modules that exist here shadow the reference's and the rest
     of `src.*` (the analytical robot models, camera calibration, mbrl loops) still resolves into the reference."""

@@ -100,6 +100,27 @@ def test_train_step_cfg5_shard(dev):
     print(f"cfg5 shard: {n} of {total} selections differ (max |pre|/rms {worst:.1e}); worst gradient error {worst_grad:.1e}")
 
 
+def test_train_step_group_norm_g256_forced(dev):
+    """`--lstm_group_norm True` at the width of the authors' deployed checkpoints (g 256 / z 64,
+    evaluate_checkpoint.py:40-46): NormConvLSTMCell -- separate ih / hh gate convs, GroupNorm(16) on both and on the cell
+    state -- through a 3-step BPTT window with the selections agreed: losses <= 1e-4, EVERY parameter's gradient
+    (GroupNorm affines included) <= 1e-4 norm-wise."""
+    cfg = orc.Cfg(g_dim=256, z_dim=64, batch_size=8, n_past=1, n_future=3, lr=1e-4, lstm_group_norm=True, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=31, randomize_bn_stats=False)
+    assert any("c_norm" in k for k in sd)
+    data = syn.synth_video(seed=32, T=4, B=8)
+    eps = syn.synth_eps(seed=33, steps=3, B=8, z=64, h=8, w=8)
+    tr = make_trainer(cfg, sd, dev)
+    tr.optimizer.step = lambda: None
+    ts = orc.TrainState.create(cfg, sd)
+    got, ref, flips = forced_step(tr, ts, data, eps, 8)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, err_msg=k)
+    n, total, worst = check_flips(flips)
+    worst_grad = check_grads(tr, ts)
+    print(f"group norm g256: {n} of {total} selections differ (max |pre|/rms {worst:.1e}); worst gradient error {worst_grad:.1e}")
+
+
 @pytest.mark.parametrize("tag", ["vanilla", "ra", "ra_sched"])
 def test_three_optimizer_steps_forced(dev, tag):
     """Three Adam steps at cfg1 size with the oracle held to the GPU pass's selections at every step: the loss

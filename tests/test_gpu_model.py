@@ -23,6 +23,8 @@ pytestmark = pytest.mark.gpu
 from oracle import svg_oracle as orc  # noqa: E402
 from robot_aware_control_amd import synthetic as syn  # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 FLAGSETS = {
     "vanilla": dict(model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
                     reconstruction_loss="l1"),
@@ -363,6 +365,40 @@ def test_cli_train_loop_synthetic(dev, tmp_path, monkeypatch):
     cli.make_log_folder(cfg)
     tr = PredictionTrainer(cfg)
     assert tr._load_checkpoint(None) == last
+
+
+def test_train_loop_on_files_with_transfer_eval_and_plots(dev, tmp_path):
+    """train() on trajectory FILES (data.py loaders, device prefetcher) for `--experiment train_robonet`: test metrics and
+    the zero-shot transfer metrics on the unseen locobot (trainer.py:786-790), and with `--plot True` the generation GIFs
+    of `plot` (trainer.py:949-1147): [ground truth | 3 samples] per video, one frame per time step."""
+    import sys
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_robonet as mk
+    from robot_aware_control_amd.config import argparser
+    from robot_aware_control_amd.trainer import PredictionTrainer
+    root = str(tmp_path / "data")
+    mk.write(root, per_view=4, length=10, seed=1, locobot=2)
+    argv = ("--jobname t --wandb False --batch_size 2 --test_batch_size 2 --n_future 2 --n_past 1 --n_eval 4 --g_dim 32 "
+            "--z_dim 8 --model svg --niter 1 --epoch_size 2 --checkpoint_interval 5 --eval_interval 1 "
+            "--reconstruction_loss dontcare_l1 --last_frame_skip True --scheduled_sampling False --action_dim 4 "
+            "--robot_dim 5 --robot_joint_dim 7 --data_threads 0 --experiment train_robonet --model_use_robot_state True "
+            "--model_use_mask True --model_use_future_mask True --video_length 8 --image_height 64 --image_width 64 "
+            f"--train_val_split 0.75 --plot True --data_root {root} --log_dir {tmp_path / 'log'}").split()
+    cfg, _ = argparser(argv)
+    cfg.device = dev
+    tr = PredictionTrainer(cfg)
+    # the locobot files carry 5 joint angles: the transfer loader reads them with its own config copy
+    tr.train()
+    names = [k for _, info in tr.eval_history for k in info]
+    assert any(k.startswith("test/") for k in names) and any(k.startswith("transfer/") for k in names), names
+    assert all(np.isfinite(v) for _, info in tr.eval_history for v in info.values())
+    gifs = sorted(os.listdir(os.path.join(cfg.log_dir, "plot")))
+    assert gifs == ["test_0.gif", "train_0.gif", "transfer_0.gif"], gifs
+    im = Image.open(os.path.join(cfg.log_dir, "plot", "test_0.gif"))
+    assert im.n_frames == cfg.n_eval and im.size == (4 * 64, 2 * 64)  # [gt | 3 samples] x 2 videos
+    im = Image.open(os.path.join(cfg.log_dir, "plot", "train_0.gif"))
+    assert im.n_frames == cfg.n_past + cfg.n_future
 
 
 @pytest.mark.parametrize("ra", [False, True])

@@ -19,7 +19,27 @@ VIEWS = {"sawyer": ("sawyer_views", ["sudri0_c0", "sudri2_c1"]), "widowx": ("wid
          "baxter": ("baxter_views", ["left_c0"])}
 
 
-def write(root, per_view=4, length=12, seed=0, h=64, w=85):
+LOCOBOT = ("locobot_views", ["c0", "c1"])  # the unseen robot of the zero-shot transfer evaluation (metric states, no bounds)
+
+
+def write(root, per_view=4, length=12, seed=0, h=64, w=85, locobot=0):
+    """`locobot` > 0: also that many trajectories per locobot view (locobot_singleview_dataloader.py's layout: metric
+    5-dim states, 5 joint angles, no low_bound / high_bound, no robot attribute); not counted in the return value."""
+    for j, view in enumerate(LOCOBOT[1] if locobot else []):
+        d = os.path.join(root, LOCOBOT[0], view)
+        os.makedirs(d, exist_ok=True)
+        for i in range(locobot):
+            g = np.random.Generator(np.random.Philox(key=[seed, 10_000 + 100 * j + i]))
+            T = length + int(g.integers(0, 3))
+            xy = np.cumsum(g.normal(0, 0.01, (T, 2)), 0) + np.array([0.3, 0.0])
+            states = np.concatenate([xy, np.full((T, 1), 0.12), np.zeros((T, 2))], 1).astype(np.float32)
+            mask = np.zeros((T, h, w), np.uint8)
+            for t in range(T):
+                cy, cx = int(30 + 40 * xy[t, 1]), int(20 + 100 * (xy[t, 0] - 0.2))
+                mask[t, max(0, cy - 6):cy + 6, max(0, cx - 9):cx + 9] = 1
+            np.savez(os.path.join(d, f"traj_{i:03d}.npz"), observations=g.integers(0, 256, (T, h, w, 3), dtype=np.uint8),
+                     masks=mask, states=states, actions=np.diff(states[:, :4], axis=0).astype(np.float32),
+                     qpos=g.normal(0, 1, (T, 5)).astype(np.float32))
     n = 0
     for robot, (sub, views) in VIEWS.items():
         for view in views:
