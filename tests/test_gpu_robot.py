@@ -192,6 +192,7 @@ def test_atlas_masks_quantified_and_exact_elites(dev):
         pix = float((m_atlas != m_exact).float().mean())
         got = TrajectorySampler(ns, model, robot_model=rm).generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
         err = float(np.abs(got - exact).max() / scale)
+        mean_err = float(np.abs(got - exact).mean() / scale)
         o = np.argsort(-got, kind="stable")
         same5 = len(set(o[:K]) & set(order[:K]))
         in20 = len(set(order[:K]) & set(o[:20]))
@@ -202,11 +203,13 @@ def test_atlas_masks_quantified_and_exact_elites(dev):
         assert arm.calls == calls + 1  # ONE exact predict_batch, for the 20 finalists
         o2 = np.argsort(-ref, kind="stable")
         fixed = list(o2[:K]) == list(order[:K]) and np.array_equal(ref[o2[:K]], exact[order[:K]])
-        rows.append((mm, pix, err, same5, in20, fixed))
-        print(f"atlas {mm} mm ({nx}x{ny} nodes): {100 * pix:.2f} % of mask pixels differ, max cost error {err:.1e} of max |cost|, "
+        rows.append((mm, pix, mean_err, same5, in20, fixed))
+        print(f"atlas {mm} mm ({nx}x{ny} nodes): {100 * pix:.2f} % of mask pixels differ, cost error mean {mean_err:.1e} / max "
+              f"{err:.1e} of max |cost|, "
               f"{same5}/{K} of the exact top-{K} in the atlas top-{K}, {in20}/{K} in its top-20; exact-elite refinement "
               f"restores the exact top-{K}: {fixed}")
-    errs = [r[2] for r in rows]
-    assert errs[-1] <= errs[0] and rows[2][1] < 0.01        # finer grids cost less; < 1 % of pixels at 5 mm
+    # finer grids differ in fewer pixels and cost less ON AVERAGE (the worst candidate's error is one silhouette pixel of
+    # one step, whatever the spacing: only exact masks remove it); < 1 % of pixels at 5 mm
+    assert rows[-1][1] < rows[0][1] and rows[-1][2] <= rows[0][2] and rows[2][1] < 0.01
     assert all(r[4] == K for r in rows[1:])                  # the exact elites survive the atlas screening (<= 10 mm)
     assert all(r[5] for r in rows[1:])                       # ... so re-rolling 20 finalists restores them, bit for bit
