@@ -186,6 +186,10 @@ typedef struct rac_wgrad_args {
                             their share of the x1 half of dw is skipped, not computed */
   int32_t presplit;      /* 1: dy / x0 / x1 point to the fp16 part pairs rac_split_steps wrote ([2][elements], split under
                             the SAME slot lists: every dy_amax for dy, every x0_amax and x1_amax for x0 and x1) */
+  int32_t all_ky;        /* 1 (ksize 3, Cout <= 128, H % 32 == 0, no presplit, no x1_zero_steps): one workgroup keeps all nine
+                            taps of its 64 x 64 (co, ci) tile, so dy and x leave HBM once per tile instead of once per kernel
+                            row -- the thin layers on 32x32 / 64x64 maps; nsplit then counts per tile, not per (tile, ky) */
+  int32_t reserved;
 } rac_wgrad_args;
 int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream);
 /* parts[t] ([2][n] halves) = the two fp16 parts of xs[t] (n floats, n % 8 == 0) under ONE power-of-two scale taken from the

@@ -1088,6 +1088,235 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The 3x3 weight gradient of the THIN layers (Cout <= 128 on 32x32 / 64x64 maps: K = 80 000 .. 330 000 pixels against a
+// 64 x 576 .. 128 x 2304 output): wgrad16_kernel gives each kernel ROW its own workgroup, so every dy tile is staged once
+// per (input-channel tile, ky) and every input column three times -- 645 MB fetched for a 0.3 MB result, 0.07-0.13 of the
+// pipe.  Here one workgroup (64 co x 64 ci) keeps ALL NINE taps: a K block is still 32 consecutive image rows x one
+// pixel column, but the input column is staged with one halo row above and below (34 rows) and the three vertical taps
+// read it at row offsets 0 / 1 / 2 -- dy and x leave HBM once per (co tile, ci tile).  Needs H % 32 == 0 (a 32-row group
+// never straddles two images: only its halo rows can fall outside, and they are zeroed as a whole).
+// LDS rows are [pixel row][256 B] with the 32-byte segments XOR-swizzled by the row index, as in wgrad16_kernel; a
+// fragment of a shifted window starts at an arbitrary row, so the two 4-row halves of a transposing read get their own
+// swizzled addresses.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
+  constexpr int KS = 3, NR = 4;
+  constexpr int DYB = 16384, XROWS = 34, XSLOT = 40 * 256, X_BASE = 2 * DYB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);  // waves along ci: 64 co x 16 ci each
+  const int co0 = blockIdx.x * 64, ci0 = blockIdx.y * 64;
+  const int split = blockIdx.z;
+  const bool first = ci0 < p.C0;
+  const int Cs = first ? p.C0 : p.Cin - p.C0;
+  const int cl0 = first ? ci0 : ci0 - p.C0;
+
+  unsigned amd = 0, amx = 0;
+  for (int t = 0; t < p.T; ++t) {
+    amd = max(amd, *p.dy_amax[t]);
+    amx = max(amx, *p.x0_amax[t]);
+    if (p.x1_amax[t]) amx = max(amx, *p.x1_amax[t]);
+  }
+  const int kd = scale_exp(amd), kxs = scale_exp(amx);
+  const float sd = pow2f(kd), sx = pow2f(kxs);
+
+  const int NG = p.T * p.G;
+  const int gpb = (NG + p.nsplit - 1) / p.nsplit;
+  const int g_begin = split * gpb;
+  const int g_end = min(NG, g_begin + gpb);
+  const int S = max(0, g_end - g_begin) * p.W;
+
+  // ---- staging roles ----
+  // dy: threads 0..127, row tid >> 2 of the 32-row block, 16-channel segment tid & 3 (co 64..127 of the rows stay zero)
+  const bool dy_role = tid < 128;
+  const int dkk = (tid >> 2) & 31, dsub = tid & 3;
+  const int dsw = (dkk & 3) | (((dkk >> 3) & 1) << 2);
+  const int dy_lds = dkk * 256 + ((dsub ^ dsw) * 32);
+  const bool dy_ch_ok = co0 + dsub * 16 < p.Cout;
+  // x: staged row i = tid >> 3 (and 32 + (tid >> 3) for tid < 16), 8 channels tid & 7; row i holds image row
+  // 32 * group + i - 1
+  const int ssub = tid & 7;
+  const bool x_ch_ok = cl0 + ssub * 8 < Cs;
+  auto x_lds_of = [&](int i) {
+    const int sw = (i & 3) | (((i >> 3) & 1) << 2);
+    return X_BASE + i * 256 + (((ssub >> 1) ^ sw) * 32) + (ssub & 1) * 16;
+  };
+  const int xi0 = tid >> 3, xi1 = 32 + (tid >> 3);
+  const bool x_two = tid < 16;
+  const int x_lds0 = x_lds_of(xi0), x_lds1 = x_lds_of(xi1);
+  int dg = g_begin, dc = 0, xg = g_begin, xc = 0;
+  u32x4 rd[4], rx[4];
+  auto issue_dy = [&]() {
+    if (dy_role) {
+      const int t = dg / p.G, gr = dg - t * p.G;
+      const int r = gr * 32 + dkk;
+      const bool ok = (r < p.R) & dy_ch_ok;
+      const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
+      const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+    }
+    if (++dc == p.W) dc = 0, ++dg;
+  };
+  auto issue_x = [&]() {
+    const int t = xg / p.G, gr = xg - t * p.G;
+    const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
+    const int r0 = gr * 32 - 1;
+    // the halo rows belong to the group's image unless the group starts / ends it
+    const bool top_ok = (gr * 32) % p.H != 0, bot_ok = (gr * 32 + 32) % p.H != 0;
+    {
+      const int r = r0 + xi0;
+      const bool ok = (r >= 0) & (r < p.R) & x_ch_ok & (xi0 != 0 || top_ok);
+      const unsigned off = (unsigned)(((long)r * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+      rx[0] = load16(rs, ok ? off : OOB);
+      rx[1] = load16(rs, ok ? off + 16u : OOB);
+    }
+    if (x_two) {  // rows 32 and 33
+      const int r = r0 + xi1;
+      const bool ok = (r < p.R) & x_ch_ok & (xi1 != 33 || bot_ok);
+      const unsigned off = (unsigned)(((long)r * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+      rx[2] = load16(rs, ok ? off : OOB);
+      rx[3] = load16(rs, ok ? off + 16u : OOB);
+    }
+    if (++xc == p.W) xc = 0, ++xg;
+  };
+  auto store_dy = [&](int buf) {
+    if (!dy_role) return;
+    u32x4 q0[2], q1[2];
+    split8h(rd[0], rd[1], sd, q0);
+    split8h(rd[2], rd[3], sd, q1);
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+      unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
+      *reinterpret_cast<u32x4*>(d) = q0[part];
+      *reinterpret_cast<u32x4*>(d + 16) = q1[part];
+    }
+  };
+  auto store_x = [&](int slot) {
+    u32x4 q[2];
+    split8h(rx[0], rx[1], sx, q);
+    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + x_lds0) = q[0];
+    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + (x_lds0 ^ 128)) = q[1];
+    if (x_two) {
+      split8h(rx[2], rx[3], sx, q);
+      *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + x_lds1) = q[0];
+      *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + (x_lds1 ^ 128)) = q[1];
+    }
+  };
+
+  // ---- fragment addresses (lane constants) ----
+  const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
+  const int fsw = fq | ((fg & 1) << 2);
+  const int lane_base = (8 * fg + fq) * 256 + fp * 8;
+  int offA[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) offA[t] = lane_base + ((t ^ fsw) * 32);
+  // input window of vertical tap ky: staged rows ky + (8 fg + fq) and + 4, each with the swizzle of ITS row
+  int offB[KS][2][2];  // [ky][part][half]
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = ky + 8 * fg + fq + 4 * h;
+      const int sw = (i & 3) | (((i >> 3) & 1) << 2);
+#pragma unroll
+      for (int part = 0; part < 2; ++part) offB[ky][part][h] = X_BASE + i * 256 + fp * 8 + (((part * 4 + wn) ^ sw) * 32);
+    }
+  typedef __fp16 h16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
+  auto frag2 = [&](int lo_addr, int hi_addr) {
+    const h16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds_raw, lo_addr));
+    const h16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16(RAC_LDS_PTR(h16x4, lds_raw, hi_addr));
+    return __builtin_bit_cast(f16x8, (h16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  f32x4 acc[KS][KS][4];
+#pragma unroll
+  for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[ky][k][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // zero what nobody stages: co 64..127 of the dy rows, rows 34..39 of the input slots
+#pragma unroll
+  for (int v = 0; v < 8; ++v) *reinterpret_cast<u32x4*>(lds_raw + (v * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+  for (int v = tid; v < NR * 6 * 16; v += 256)
+    *reinterpret_cast<u32x4*>(lds_raw + X_BASE + (v / 96) * XSLOT + XROWS * 256 + (v % 96) * 16) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  if (S > 0) {
+    for (int e = 0; e <= 1 && e < S; ++e) {  // input columns 0 and 1, the dy tile of column 0
+      issue_x();
+      store_x(e);
+    }
+    issue_dy();
+    store_dy(0);
+    __syncthreads();
+    int c = 0, sm = 0;
+    for (int s = 0; s < S; ++s) {
+      const bool more_dy = s + 1 < S, more_x = s + 2 < S;
+      if (more_dy) issue_dy();
+      if (more_x) issue_x();
+      const int dbuf = (s & 1) * DYB;
+      f16x8 fa[4][2];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        if ((unsigned)(c + k - 1) >= (unsigned)p.W) continue;  // uniform: the tap leaves the image row
+        int sl = sm + k - 1;
+        sl += sl < 0 ? NR : 0;
+        sl -= sl >= NR ? NR : 0;
+        const int so = sl * XSLOT;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+          f16x8 fb[2];
+#pragma unroll
+          for (int part = 0; part < 2; ++part) fb[part] = frag2(so + offB[ky][part][0], so + offB[ky][part][1]);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[ky][k][t] = mma3(fa[t], fb, acc[ky][k][t]);
+        }
+      }
+      if (more_dy) store_dy((s + 1) & 1);
+      if (more_x) {
+        int sl = sm + 2;
+        sl -= sl >= NR ? NR : 0;
+        store_x(sl);
+      }
+      __syncthreads();
+      c = (c + 1 == p.W) ? 0 : c + 1;
+      sm = (sm + 1 == NR) ? 0 : sm + 1;
+    }
+  }
+
+  const float id = pow2f(-kd), ix = pow2f(-kxs);
+  const int lr = lane & 15, lq = lane >> 4;
+  float* dst = split == 0 ? p.dw : p.slabs + (long)(split - 1) * p.slab_stride;
+  const bool add = split == 0 && p.accumulate;
+  const int cil = cl0 + wn * 16 + lr;
+  if (cil < Cs) {
+    const int ci = (first ? 0 : p.C0) + cil;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + t * 16 + 4 * lq + r;
+        if (co >= p.Cout) continue;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky)
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            const long idx = (((long)co * KS + ky) * KS + k) * p.Cin + ci;
+            const float v = acc[ky][k][t][r] * id * ix;
+            dst[idx] = add ? dst[idx] + v : v;
+          }
+      }
+  }
+}
+
 // out[i] += sum_s slabs[s * stride + i]
 __global__ void slab_accumulate_kernel(const float4* slabs, int n_slabs, long stride4, float4* out, long n4) {
   const long st = (long)gridDim.x * blockDim.x;
@@ -1406,6 +1635,25 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   p.x1_skip = a->x1_zero_steps;
   p.presplit = a->presplit ? 1 : 0;
   RAC_REQUIRE(!p.presplit || (a->Cout % 16 == 0 && p.C0 % 8 == 0), "rac_conv2d_wgrad_split: presplit operand alignment");
+  // thin 3x3 layers on large maps: all nine taps per workgroup, dy and x fetched once (wgrad16_allky_kernel)
+  static const char* noallky = getenv("RAC_WGRAD_ALLKY");
+  if (a->ksize == 3 && a->Cout <= 128 && a->H % 32 == 0 && !p.presplit && p.x1_skip == 0 && a->all_ky &&
+      !(noallky && atoi(noallky) == 0)) {
+    dim3 grid(cdiv(a->Cout, 64), cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64), p.nsplit);
+    const int lds = 2 * 16384 + 4 * 40 * 256;
+    static bool attr_allky = false;
+    if (!attr_allky) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad16_allky_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return RAC_ELAUNCH;
+      }
+      attr_allky = true;
+    }
+    hipLaunchKernelGGL(wgrad16_allky_kernel, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
+    return check_launch("rac_conv2d_wgrad_split(all taps)");
+  }
   const bool co64 = a->Cout <= 64;  // 64 co x 64 ci workgroups: no all-zero half of the 128-co tile
   const int ct = cdiv(a->Cout, co64 ? 64 : 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
   dim3 grid(ct, nt, a->ksize * p.nsplit);

@@ -659,6 +659,8 @@ DEFER_WGRAD = os.environ.get("RAC_DEFER_WGRAD", "1") == "1"
 WGRAD_PRESPLIT = os.environ.get("RAC_WGRAD_PRESPLIT", "1") == "1"
 # workgroups that stage one operand tile before splitting it once pays
 WGRAD_PRESPLIT_MIN_READERS = int(os.environ.get("RAC_WGRAD_PRESPLIT_MIN", "32"))
+# thin 3x3 layers on 32x32 / 64x64 maps: one workgroup keeps all nine taps (dy and x fetched once per tile)
+WGRAD_ALLKY = os.environ.get("RAC_WGRAD_ALLKY", "1") == "1"
 
 
 @contextlib.contextmanager
@@ -750,11 +752,20 @@ def _wgrad_split_batch(items, weight):
         chunk = sorted(chunk, key=lambda it: 0 if is_zero(it[2]) else 1)
         n_zero = sum(1 for it in chunk if is_zero(it[2]))
         T = len(chunk)
-        ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
+        readers = (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
+        presplit = WGRAD_PRESPLIT and readers >= WGRAD_PRESPLIT_MIN_READERS and Cin == ci_real
+        all_ky = WGRAD_ALLKY and k == 3 and Cout <= 128 and H % 32 == 0 and n_zero == 0 and not presplit
+        if all_ky:  # tiles are (co 64, ci 64) only: split K until the chip is full (a group = 32 image rows x W columns)
+            tiles_ak = _cdiv(Cout, 64) * (_cdiv(C0, 64) + _cdiv(Cin - C0, 64))
+            forced = os.environ.get("RAC_WGRAD_SPLITK")
+            ns = min(T * _cdiv(B * H, 32), int(forced) if forced else max(1, 512 // tiles_ak))
+        else:
+            ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
         a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
                       accumulate=0 if (Cin != ci_real and lo == 0) else 1,
-                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, presplit=0)
+                      dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, presplit=0,
+                      all_ky=1 if all_ky else 0, reserved=0)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
             assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
             a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
@@ -762,8 +773,7 @@ def _wgrad_split_batch(items, weight):
             a.x1_amax[t] = ptr(amax_for(x1_t)) if x1_t is not None else None
         # every operand tile is staged by one workgroup per input-channel tile and kernel row: where that is many (the
         # ConvLSTM gate weights: 48 .. 160), split the operands into their fp16 parts ONCE instead of in each of them
-        readers = (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
-        if WGRAD_PRESPLIT and readers >= WGRAD_PRESPLIT_MIN_READERS and Cin == ci_real:
+        if presplit:
             two = chunk[0][2] is not None
 
             def split(tensors, slots):

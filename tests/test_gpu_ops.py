@@ -617,12 +617,15 @@ def test_conv_split_rows_kernel(dev, case):
 
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3),
-                                  (2, 32, 32, 64, 64, 64, 3), (3, 16, 16, 128, 0, 64, 5), (2, 8, 8, 64, 0, 48, 3)])
+                                  (2, 32, 32, 64, 64, 64, 3), (3, 16, 16, 128, 0, 64, 5), (2, 8, 8, 64, 0, 48, 3),
+                                  (2, 64, 64, 64, 0, 64, 3), (1, 32, 32, 128, 0, 128, 3), (3, 32, 32, 96, 0, 96, 3),
+                                  (1, 64, 64, 64, 64, 64, 3)])
 @pytest.mark.parametrize("presplit", [False, True])
 def test_wgrad_split_precision(dev, case, presplit, monkeypatch):
     """Weight gradient on the split-precision pipe against fp64, next to the exact-fp32 MFMA kernel; accumulation into
     .grad; the deferred (time-batched) form.  `presplit`: the operands are split into their fp16 parts once by
-    rac_split_steps (what the ConvLSTM gate weights get) instead of inside the kernel."""
+    rac_split_steps (what the ConvLSTM gate weights get) instead of inside the kernel.  The 3x3 cases with Cout <= 128 on
+    32x32 / 64x64 maps take the all-taps kernel (wgrad16_allky_kernel) unless presplit."""
     from robot_aware_control_amd import ops
     monkeypatch.setattr(ops, "WGRAD_PRESPLIT_MIN_READERS", 1 if presplit else 10 ** 9)
     B, H, W, C0, C1, Cout, k = case
@@ -642,6 +645,16 @@ def test_wgrad_split_precision(dev, case, presplit, monkeypatch):
     assert e_split < 3e-6 and e_split < 4 * e_fp32 + 3e-7, (e_split, e_fp32)
     ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wd)  # accumulates
     assert relerr(wd.grad.cpu(), 2 * ref) < 3e-6
+    if k == 3 and Cout <= 128 and H % 32 == 0 and not presplit:
+        # the all-taps form against the kernel-row form: same sums, another association
+        monkeypatch.setattr(ops, "WGRAD_ALLKY", False)
+        wrow = cl_weight(w.detach()).to(dev).requires_grad_(True)
+        ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wrow)
+        monkeypatch.setattr(ops, "WGRAD_ALLKY", True)
+        wall = cl_weight(w.detach()).to(dev).requires_grad_(True)
+        ops.conv_wgrad_split_acc(to_map(gy, dev), x0, x1, wall)
+        assert relerr(wall.grad.cpu(), ref) < 3e-6 and relerr(wrow.grad.cpu(), ref) < 3e-6
+        assert relerr(wall.grad.cpu(), wrow.grad.cpu().double()) < 2e-6
     # no atomics: the same operands give the same bits, K split (slabs + fixed-order accumulate) included
     for forced in (None, "3"):
         reps = []
