@@ -189,7 +189,8 @@ typedef struct rac_wgrad_args {
   int32_t all_ky;        /* 1 (ksize 3, Cout <= 128, H % 32 == 0, no presplit, no x1_zero_steps): one workgroup keeps all nine
                             taps of its 64 x 64 (co, ci) tile, so dy and x leave HBM once per tile instead of once per kernel
                             row -- the thin layers on 32x32 / 64x64 maps; nsplit then counts per tile, not per (tile, ky) */
-  int32_t reserved;
+  int32_t col_segments;  /* all_ky: K is split into (32-row group, column segment) units, col_segments (| W) per image row,
+                            so that nsplit may reach T * groups * col_segments workgroups per tile (0 / 1: whole rows) */
 } rac_wgrad_args;
 int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream);
 /* parts[t] ([2][n] halves) = the two fp16 parts of xs[t] (n floats, n % 8 == 0) under ONE power-of-two scale taken from the

@@ -53,7 +53,7 @@ class WgradArgs(C.Structure):
         ("dy", vp * WGRAD_MAX_STEPS), ("x0", vp * WGRAD_MAX_STEPS), ("x1", vp * WGRAD_MAX_STEPS),
         ("dy_amax", vp * WGRAD_MAX_STEPS), ("x0_amax", vp * WGRAD_MAX_STEPS), ("x1_amax", vp * WGRAD_MAX_STEPS),
         ("dw", vp), ("slabs", vp), ("slab_stride", i64), ("x1_zero_steps", i32), ("presplit", i32),
-        ("all_ky", i32), ("reserved", i32),
+        ("all_ky", i32), ("col_segments", i32),
     ]
 
 

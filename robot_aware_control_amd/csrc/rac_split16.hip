@@ -847,6 +847,7 @@ struct Wgrad16P {
   int Bimg, H, W, Cin, Cout, C0, T;
   int R, G;      // image rows (Bimg * H) and 32-row groups per step
   int nsplit, accumulate;
+  int nseg;      // wgrad16_allky_kernel: column segments per image row (K units = groups x segments)
   int x1_skip;   // leading steps whose x1 is all zeros: the workgroups of the x1 half start behind them
   int presplit;  // the operand pointers are fp16 part pairs [2][elements] (rac_split_steps), already scaled
   const float* dy[RAC_WGRAD_MAX_STEPS];
@@ -1122,11 +1123,13 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
   const int kd = scale_exp(amd), kxs = scale_exp(amx);
   const float sd = pow2f(kd), sx = pow2f(kxs);
 
-  const int NG = p.T * p.G;
-  const int gpb = (NG + p.nsplit - 1) / p.nsplit;
-  const int g_begin = split * gpb;
-  const int g_end = min(NG, g_begin + gpb);
-  const int S = max(0, g_end - g_begin) * p.W;
+  // K units: (32-row group, column segment) pairs -- p.nseg segments of cseg columns per image row; a workgroup walks
+  // its units one after the other (each with its own 1-column halo left and right)
+  const int cseg = p.W / p.nseg;
+  const int NU = p.T * p.G * p.nseg;
+  const int upw = (NU + p.nsplit - 1) / p.nsplit;
+  const int u_begin = split * upw;
+  const int u_end = min(NU, u_begin + upw);
 
   // ---- staging roles ----
   // dy: threads 0..127, row tid >> 2 of the 32-row block, 16-channel segment tid & 3 (co 64..127 of the rows stay zero)
@@ -1146,22 +1149,20 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
   const int xi0 = tid >> 3, xi1 = 32 + (tid >> 3);
   const bool x_two = tid < 16;
   const int x_lds0 = x_lds_of(xi0), x_lds1 = x_lds_of(xi1);
-  int dg = g_begin, dc = 0, xg = g_begin, xc = 0;
   u32x4 rd[4], rx[4];
-  auto issue_dy = [&]() {
+  auto issue_dy = [&](int gidx, int col) {  // dy tile of column `col` of group `gidx` (= step * G + group)
     if (dy_role) {
-      const int t = dg / p.G, gr = dg - t * p.G;
+      const int t = gidx / p.G, gr = gidx - t * p.G;
       const int r = gr * 32 + dkk;
       const bool ok = (r < p.R) & dy_ch_ok;
       const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
-      const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
+      const unsigned off = (unsigned)(((long)r * p.W + col) * p.Cout + co0 + dsub * 16) * 4u;
 #pragma unroll
       for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
     }
-    if (++dc == p.W) dc = 0, ++dg;
   };
-  auto issue_x = [&]() {
-    const int t = xg / p.G, gr = xg - t * p.G;
+  auto issue_x = [&](int gidx, int col) {
+    const int t = gidx / p.G, gr = gidx - t * p.G;
     const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
     const int r0 = gr * 32 - 1;
     // the halo rows belong to the group's image unless the group starts / ends it
@@ -1169,18 +1170,17 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
     {
       const int r = r0 + xi0;
       const bool ok = (r >= 0) & (r < p.R) & x_ch_ok & (xi0 != 0 || top_ok);
-      const unsigned off = (unsigned)(((long)r * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+      const unsigned off = (unsigned)(((long)r * p.W + col) * Cs + cl0 + ssub * 8) * 4u;
       rx[0] = load16(rs, ok ? off : OOB);
       rx[1] = load16(rs, ok ? off + 16u : OOB);
     }
     if (x_two) {  // rows 32 and 33
       const int r = r0 + xi1;
       const bool ok = (r < p.R) & x_ch_ok & (xi1 != 33 || bot_ok);
-      const unsigned off = (unsigned)(((long)r * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
+      const unsigned off = (unsigned)(((long)r * p.W + col) * Cs + cl0 + ssub * 8) * 4u;
       rx[2] = load16(rs, ok ? off : OOB);
       rx[3] = load16(rs, ok ? off + 16u : OOB);
     }
-    if (++xc == p.W) xc = 0, ++xg;
   };
   auto store_dy = [&](int buf) {
     if (!dy_role) return;
@@ -1245,20 +1245,28 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
   for (int v = tid; v < NR * 6 * 16; v += 256)
     *reinterpret_cast<u32x4*>(lds_raw + X_BASE + (v / 96) * XSLOT + XROWS * 256 + (v % 96) * 16) = u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
-  if (S > 0) {
-    for (int e = 0; e <= 1 && e < S; ++e) {  // input columns 0 and 1, the dy tile of column 0
-      issue_x();
-      store_x(e);
+  for (int u = u_begin; u < u_end; ++u) {
+    const int gidx = u / p.nseg, c0 = (u - gidx * p.nseg) * cseg, c1 = c0 + cseg;
+    // ring slot of column c: (c - c0 + 1) & 3 -- the left halo column c0 - 1 in slot 0
+    if (c0 > 0) {
+      issue_x(gidx, c0 - 1);
+      store_x(0);
     }
-    issue_dy();
+    issue_x(gidx, c0);
+    store_x(1);
+    if (c0 + 1 < p.W) {
+      issue_x(gidx, c0 + 1);
+      store_x(2);
+    }
+    issue_dy(gidx, c0);
     store_dy(0);
     __syncthreads();
-    int c = 0, sm = 0;
-    for (int s = 0; s < S; ++s) {
-      const bool more_dy = s + 1 < S, more_x = s + 2 < S;
-      if (more_dy) issue_dy();
-      if (more_x) issue_x();
-      const int dbuf = (s & 1) * DYB;
+    for (int c = c0; c < c1; ++c) {
+      const bool more_dy = c + 1 < c1;
+      const bool more_x = more_dy && c + 2 < p.W;  // column c + 2 serves step c + 1 (its right neighbour)
+      if (more_dy) issue_dy(gidx, c + 1);
+      if (more_x) issue_x(gidx, c + 2);
+      const int dbuf = ((c - c0) & 1) * DYB;
       f16x8 fa[4][2];
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -1267,10 +1275,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         if ((unsigned)(c + k - 1) >= (unsigned)p.W) continue;  // uniform: the tap leaves the image row
-        int sl = sm + k - 1;
-        sl += sl < 0 ? NR : 0;
-        sl -= sl >= NR ? NR : 0;
-        const int so = sl * XSLOT;
+        const int so = ((c - c0 + k) & (NR - 1)) * XSLOT;
 #pragma unroll
         for (int ky = 0; ky < KS; ++ky) {
           f16x8 fb[2];
@@ -1280,15 +1285,9 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
           for (int t = 0; t < 4; ++t) acc[ky][k][t] = mma3(fa[t], fb, acc[ky][k][t]);
         }
       }
-      if (more_dy) store_dy((s + 1) & 1);
-      if (more_x) {
-        int sl = sm + 2;
-        sl -= sl >= NR ? NR : 0;
-        store_x(sl);
-      }
+      if (more_dy) store_dy((c - c0 + 1) & 1);
+      if (more_x) store_x((c - c0 + 3) & (NR - 1));
       __syncthreads();
-      c = (c + 1 == p.W) ? 0 : c + 1;
-      sm = (sm + 1 == NR) ? 0 : sm + 1;
     }
   }
 
@@ -1625,7 +1624,8 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   RAC_REQUIRE(rowbytes * a->Cout < 0xFFFFFF00L && rowbytes * (p.C0 > a->Cin - p.C0 ? p.C0 : a->Cin - p.C0) < 0xFFFFFF00L,
               "rac_conv2d_wgrad_split: operand larger than 4 GiB");
   p.nsplit = a->nsplit >= 1 ? a->nsplit : 1;
-  RAC_REQUIRE(p.nsplit <= a->T * p.G && p.nsplit <= 1024, "rac_conv2d_wgrad_split: more K splits than 32-row groups");
+  RAC_REQUIRE(p.nsplit <= a->T * p.G * (a->all_ky && a->col_segments > 1 ? a->col_segments : 1) && p.nsplit <= 1024,
+              "rac_conv2d_wgrad_split: more K splits than 32-row groups (x column segments)");
   const long n = (long)a->Cout * a->ksize * a->ksize * a->Cin;
   RAC_REQUIRE(p.nsplit == 1 || (a->slabs && a->slab_stride >= n), "rac_conv2d_wgrad_split: slabs for the K split");
   p.accumulate = a->accumulate;
@@ -1639,6 +1639,9 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   static const char* noallky = getenv("RAC_WGRAD_ALLKY");
   if (a->ksize == 3 && a->Cout <= 128 && a->H % 32 == 0 && !p.presplit && p.x1_skip == 0 && a->all_ky &&
       !(noallky && atoi(noallky) == 0)) {
+    p.nseg = a->col_segments > 1 ? a->col_segments : 1;
+    RAC_REQUIRE(a->W % p.nseg == 0 && p.nsplit <= a->T * p.G * p.nseg,
+                "rac_conv2d_wgrad_split: col_segments must divide W; nsplit <= T * groups * col_segments");
     dim3 grid(cdiv(a->Cout, 64), cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64), p.nsplit);
     const int lds = 2 * 16384 + 4 * 40 * 256;
     static bool attr_allky = false;

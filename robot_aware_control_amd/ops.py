@@ -755,17 +755,23 @@ def _wgrad_split_batch(items, weight):
         readers = (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
         presplit = WGRAD_PRESPLIT and readers >= WGRAD_PRESPLIT_MIN_READERS and Cin == ci_real
         all_ky = WGRAD_ALLKY and k == 3 and Cout <= 128 and H % 32 == 0 and n_zero == 0 and not presplit
-        if all_ky:  # tiles are (co 64, ci 64) only: split K until the chip is full (a group = 32 image rows x W columns)
+        nseg = 1
+        if all_ky:
+            # tiles are (co 64, ci 64) only: K is split into (32-row group, column segment) units until ~2.5 workgroups
+            # sit on every CU -- these layers move few FLOPs per byte, so it is bytes in flight that hide the HBM latency
             tiles_ak = _cdiv(Cout, 64) * (_cdiv(C0, 64) + _cdiv(Cin - C0, 64))
+            groups = T * _cdiv(B * H, 32)
+            while nseg * 2 <= W // 8 and W % (nseg * 2) == 0 and tiles_ak * groups * nseg < 640:
+                nseg *= 2
             forced = os.environ.get("RAC_WGRAD_SPLITK")
-            ns = min(T * _cdiv(B * H, 32), int(forced) if forced else max(1, 512 // tiles_ak))
+            ns = min(groups * nseg, int(forced) if forced else max(1, 1024 // tiles_ak), 1024)
         else:
             ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
         a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
                       accumulate=0 if (Cin != ci_real and lo == 0) else 1,
                       dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, presplit=0,
-                      all_ky=1 if all_ky else 0, reserved=0)
+                      all_ky=1 if all_ky else 0, col_segments=nseg)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):
             assert dy_t.shape == dy.shape and dy_t.is_contiguous() and x0_t.is_contiguous()
             a.dy[t], a.x0[t], a.x1[t] = ptr(dy_t), ptr(x0_t), ptr(x1_t)
