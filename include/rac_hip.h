@@ -398,6 +398,39 @@ int rac_cem_robot_inputs(const float* actions, const float* start_state, const f
 int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, int32_t step, void* stream);
 
+/* The optimiser step of the split-precision conv weights fused with the refresh of their operand parts: per job (one
+ * conv weight, [Cout][k][k][Cin] slices of the flat parameter / gradient / moment buffers) Adam as rac_adam_step, the
+ * fp16 fragment parts of the UPDATED weight (forward and / or transposed, as rac_weight_frag_split writes them) and the
+ * exact max |p_new| folded into amax_out (zero on entry).  The parts are scaled by the power of two that *scale_slot
+ * implies, which must be an upper bound of max |p_new|: the caller derives it from the previous exact maximum and the
+ * largest step Adam can take (rac_amax_bound), and hands the same slot to the convs as w_amax.  Replaces rac_adam_step
+ * + rac_absmax_multi + rac_weight_frag_split_multi on these weights: one pass over p instead of four.
+ * Jobs in DEVICE memory; job j owns the workgroups [block_begin_j, block_begin_{j+1}), rac_weight_frag_blocks each. */
+typedef struct rac_adam_frag_job {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  const uint32_t* scale_slot;
+  uint32_t* amax_out;
+  uint16_t* parts_fwd; /* or NULL */
+  uint16_t* parts_t;   /* or NULL */
+  int64_t part_stride;
+  int32_t Cout, Cin, ksize, reserved;
+  int64_t block_begin;
+} rac_adam_frag_job;
+int rac_adam_frag_multi(const rac_adam_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, float lr, float beta1,
+                        float beta2, float eps, int32_t step, void* stream);
+/* bound[idx[j]] = bits(float(exact[idx[j]]) + margin); exact[idx[j]] = 0   (j < n; idx in device memory) */
+int rac_amax_bound(uint32_t* exact, uint32_t* bound, const int32_t* idx, int32_t n, float margin, void* stream);
+/* rac_adam_step over a list of float4 ranges [begin4, begin4 + n4) of the flat buffers (device table; range r owns the
+ * workgroups [block_begin_r, block_begin_{r+1}), ceil(n4 / 1024) each): everything the fused jobs do not cover. */
+typedef struct rac_adam_range {
+  int64_t begin4, n4, block_begin;
+} rac_adam_range;
+int rac_adam_ranges(float* p, const float* g, float* m, float* v, const rac_adam_range* ranges, int32_t n_ranges,
+                    int64_t total_blocks, float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

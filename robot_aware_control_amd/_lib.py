@@ -45,6 +45,18 @@ class FragJob(C.Structure):
                 ("ksize", i32), ("transposed", i32), ("block_begin", i64)]
 
 
+class AdamFragJob(C.Structure):
+    """struct rac_adam_frag_job (include/rac_hip.h)."""
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("scale_slot", vp), ("amax_out", vp), ("parts_fwd", vp),
+                ("parts_t", vp), ("part_stride", i64), ("Cout", i32), ("Cin", i32), ("ksize", i32), ("reserved", i32),
+                ("block_begin", i64)]
+
+
+class AdamRange(C.Structure):
+    """struct rac_adam_range (include/rac_hip.h)."""
+    _fields_ = [("begin4", i64), ("n4", i64), ("block_begin", i64)]
+
+
 class WgradArgs(C.Structure):
     """struct rac_wgrad_args (include/rac_hip.h)."""
     _fields_ = [
@@ -115,6 +127,9 @@ _SIGS = {
     "rac_cem_step_tail": [vp, vp, vp, vp, vp, vp, i32, f32, i32, vp, vp, i32, i32, vp],
     "rac_cem_robot_inputs": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
+    "rac_adam_frag_multi": [vp, i32, i64, f32, f32, f32, f32, i32, vp],
+    "rac_amax_bound": [vp, vp, vp, i32, f32, vp],
+    "rac_adam_ranges": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, vp],
     "rac_version": [],
     "rac_device_arch": [],
     "rac_last_error": [],

@@ -607,6 +607,32 @@ __global__ void adam_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v, long n
   if (blockIdx.x == 0 && threadIdx.x < tail) upd(pt[threadIdx.x], gt[threadIdx.x], mt[threadIdx.x], vt[threadIdx.x]);
 }
 
+// Adam over a list of [begin, begin + n) element ranges of the flat buffers (what rac_adam_frag_multi does not cover:
+// biases, BatchNorm / GroupNorm affines, the few conv weights off the split-precision pipe); job table in device memory,
+// a workgroup per 1024 float4.
+__global__ void adam_ranges_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v, const rac_adam_range* ranges, int n_ranges,
+                                   float b1, float b2, float eps, float step_size, float inv_sqrt_bc2) {
+  int lo = 0, hi = n_ranges - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (ranges[mid].block_begin <= (long)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const rac_adam_range r = ranges[lo];
+  const long first = r.begin4 + (blockIdx.x - r.block_begin) * 1024L, last = min(r.begin4 + r.n4, first + 1024L);
+  for (long i = first + threadIdx.x; i < last; i += blockDim.x) {
+    f32x4 P = p[i], G = g[i], Mv = m[i], V = v[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float mm = b1 * Mv[e] + (1.f - b1) * G[e];
+      const float vv = b2 * V[e] + (1.f - b2) * G[e] * G[e];
+      const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+      P[e] -= step_size * (mm / denom);
+      Mv[e] = mm, V[e] = vv;
+    }
+    p[i] = P, m[i] = Mv, v[i] = V;
+  }
+}
+
 }  // namespace rac
 
 using namespace rac;
@@ -900,6 +926,18 @@ int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
                      (const f32x4*)g, (f32x4*)m, (f32x4*)v, n4, p + n4 * 4, g + n4 * 4, m + n4 * 4, v + n4 * 4, tail,
                      beta1, beta2, eps, step_size, inv_sqrt_bc2);
   return check_launch("rac_adam_step");
+}
+
+int rac_adam_ranges(float* p, const float* g, float* m, float* v, const rac_adam_range* ranges, int32_t n_ranges,
+                    int64_t total_blocks, float lr, float beta1, float beta2, float eps, int32_t step, void* stream) {
+  RAC_REQUIRE(p && g && m && v && ranges && n_ranges > 0 && total_blocks >= n_ranges && total_blocks < 0x7FFFFFFFL && step >= 1,
+              "rac_adam_ranges: bad args");
+  RAC_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), "rac_adam_ranges: buffers must be 16-B aligned");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_ranges_kernel, dim3((unsigned)total_blocks), dim3(256), 0, ST(stream), (f32x4*)p, (const f32x4*)g,
+                     (f32x4*)m, (f32x4*)v, ranges, n_ranges, beta1, beta2, eps, (float)((double)lr / bc1),
+                     (float)(1.0 / sqrt(bc2)));
+  return check_launch("rac_adam_ranges");
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@
 //   wgrad16_kernel          weight gradient: both operands in their natural NHWC layout, transposed on the way out of
 //                           LDS by ds_read_b64_tr_b16; K walks pixel COLUMNS so that one staged input column serves
 //                           every horizontal tap and the border taps are skipped instead of masked.
+#include <math.h>
 #include <stdlib.h>
 
 #include "rac_common.h"
@@ -828,6 +829,102 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const rac_absmax_job*
 
 
 // ---------------------------------------------------------------------------------------------------------
+// Adam step AND the next step's operand parts in one pass over a conv weight (torch.optim.Adam.step(), trainer.py:461, +
+// rac_absmax + rac_weight_frag_split x 2): the separate passes read the 954 MB of weights three times after Adam wrote
+// them.  A workgroup owns two 32 x 32 (co, ci) cells of one tap, as weight_frag16_kernel does: its threads update 8
+// consecutive input channels each (p, g, m, v in, p, m, v out), write the forward fragment, and pass the new values
+// through LDS for the transposed, tap-flipped fragment of the data gradient's weight.  The parts need their scale
+// BEFORE the new maximum exists: the caller provides an upper bound of max |p_new| (old exact maximum + the largest
+// step Adam can take), whose exponent is the scale the convs then undo; the exact new maximum is folded into amax_out
+// for the next bound.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_frag_job* jobs, int n_jobs, float b1, float b2,
+                                                              float eps, float step_size, float inv_sqrt_bc2) {
+  __shared__ float tile[2][32][33];
+  __shared__ unsigned mx_sh[4];
+  const int j = job_of_block(jobs, n_jobs, blockIdx.x);
+  const rac_adam_frag_job q = jobs[j];
+  const int taps = q.ksize * q.ksize, cch = q.Cin >> 5;
+  const int half = threadIdx.x >> 7;
+  const long cell = (blockIdx.x - q.block_begin) * 2 + half;  // ((nt * cch + cc) * taps + tap)
+  const bool active = cell < (long)(q.Cout >> 5) * cch * taps;
+  const int tap = (int)(cell % taps);
+  const int cc = (int)((cell / taps) % cch);
+  const int nt = (int)(cell / ((long)taps * cch));
+  const int nb = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63;
+  const int rl = nb * 16 + (lane & 15), kl = 8 * (lane >> 4);  // row (co) and first column (ci) inside the cell
+  const float s = pow2f(scale_exp(*q.scale_slot));
+  unsigned mx = 0;
+  if (active) {
+    const long off = ((long)(nt * 32 + rl) * taps + tap) * q.Cin + cc * 32 + kl;
+    f32x4 P[2], G[2], M[2], V[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      P[h] = *reinterpret_cast<const f32x4*>(q.p + off + 4 * h);
+      G[h] = *reinterpret_cast<const f32x4*>(q.g + off + 4 * h);
+      M[h] = *reinterpret_cast<const f32x4*>(q.m + off + 4 * h);
+      V[h] = *reinterpret_cast<const f32x4*>(q.v + off + 4 * h);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {  // the arithmetic of adam_kernel (rac_pointwise.hip), operation for operation
+        const float gg = G[h][e];
+        const float mm = b1 * M[h][e] + (1.f - b1) * gg;
+        const float vv = b2 * V[h][e] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        const float pp = P[h][e] - step_size * (mm / denom);
+        M[h][e] = mm, V[h][e] = vv, P[h][e] = pp;
+        mx = max(mx, absbits(pp));
+        tile[half][rl][kl + 4 * h + e] = pp;
+      }
+      *reinterpret_cast<f32x4*>(q.p + off + 4 * h) = P[h];
+      *reinterpret_cast<f32x4*>(q.m + off + 4 * h) = M[h];
+      *reinterpret_cast<f32x4*>(q.v + off + 4 * h) = V[h];
+    }
+    if (q.parts_fwd) {
+      u32x4 parts[2];
+      split8h(__builtin_bit_cast(u32x4, P[0]), __builtin_bit_cast(u32x4, P[1]), s, parts);
+      const long o = (cell * 2 + nb) * 512 + lane * 8;
+      *reinterpret_cast<u32x4*>(q.parts_fwd + o) = parts[0];
+      *reinterpret_cast<u32x4*>(q.parts_fwd + q.part_stride + o) = parts[1];
+    }
+  }
+  __syncthreads();
+  if (active && q.parts_t) {
+    // transposed cell: rows = this cell's input channels, k = its output channels, tap flipped
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = tile[half][kl + e][rl];
+    u32x4 parts[2];
+    split8h(u32x4{__builtin_bit_cast(unsigned, v[0]), __builtin_bit_cast(unsigned, v[1]), __builtin_bit_cast(unsigned, v[2]),
+                  __builtin_bit_cast(unsigned, v[3])},
+            u32x4{__builtin_bit_cast(unsigned, v[4]), __builtin_bit_cast(unsigned, v[5]), __builtin_bit_cast(unsigned, v[6]),
+                  __builtin_bit_cast(unsigned, v[7])}, s, parts);
+    const long cell_t = ((long)cc * (q.Cout >> 5) + nt) * taps + (taps - 1 - tap);
+    const long o = (cell_t * 2 + nb) * 512 + lane * 8;
+    *reinterpret_cast<u32x4*>(q.parts_t + o) = parts[0];
+    *reinterpret_cast<u32x4*>(q.parts_t + q.part_stride + o) = parts[1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o));
+  if (lane == 0) mx_sh[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = max(max(mx_sh[0], mx_sh[1]), max(mx_sh[2], mx_sh[3]));
+    if (mx > __hip_atomic_load(q.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q.amax_out, mx);
+  }
+}
+
+// bound[i] = bits(exact[i] as float + margin); exact[i] = 0, for the listed slots: the scale of the parts the fused
+// Adam pass writes, and the zeroed accumulator of the maximum it measures
+__global__ void amax_bound_kernel(unsigned* exact, unsigned* bound, const int* idx, int n, float margin) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = idx[j];
+  bound[i] = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, exact[i]) + margin);
+  exact[i] = 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
 // Weight gradient   dw[co][ky][kx][ci] (+)= sum_p dy[p][co] * x[p + (ky - pad, kx - pad)][ci]
 // as a GEMM over pixels (M = co, N = ci per tap, K = pixels), both operands read in their natural NHWC layout:
 // no transposed or shifted copies exist anywhere.
@@ -1433,6 +1530,23 @@ extern "C" int rac_weight_frag_split_multi(const rac_frag_job* jobs, int32_t n_j
   hipLaunchKernelGGL(weight_frag16_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), jobs, n_jobs);
   return check_launch("rac_weight_frag_split_multi");
+}
+
+extern "C" int rac_adam_frag_multi(const rac_adam_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, float lr, float beta1,
+                                   float beta2, float eps, int32_t step, void* stream) {
+  RAC_REQUIRE(jobs && n_jobs > 0 && total_blocks >= n_jobs && total_blocks < 0x7FFFFFFFL && step >= 1,
+              "rac_adam_frag_multi: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_frag_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     jobs, n_jobs, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+  return check_launch("rac_adam_frag_multi");
+}
+
+extern "C" int rac_amax_bound(uint32_t* exact, uint32_t* bound, const int32_t* idx, int32_t n, float margin, void* stream) {
+  RAC_REQUIRE(exact && bound && idx && n > 0 && margin >= 0.f, "rac_amax_bound: bad args");
+  hipLaunchKernelGGL(amax_bound_kernel, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), exact, bound,
+                     idx, n, margin);
+  return check_launch("rac_amax_bound");
 }
 
 // image rows per tile of conv16_rows_kernel: R | H, R * W <= 128 and a multiple of 16 (0: none)

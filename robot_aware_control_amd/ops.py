@@ -27,7 +27,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AbsmaxJob, ConvArgs, FragJob, WgradArgs, call, ptr, stream_ptr
+from ._lib import AbsmaxJob, AdamFragJob, AdamRange, ConvArgs, FragJob, WgradArgs, call, ptr, stream_ptr
 
 FWD, DGRAD, WGRAD = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
@@ -412,7 +412,9 @@ def split_supported(H: int, W: int, k: int, Cin: int, Cout: int, a_split: int = 
 # are refreshed by three launches (zero the slots, rac_absmax_multi, rac_weight_frag_split_multi) instead of three per
 # weight and direction.  A weight that goes stale on its own (a new registration) takes the single-tensor calls.
 class _WeightParts:
-    __slots__ = ("ref", "idx", "slot", "device", "parts", "tag", "__weakref__")
+    # slot: what the convs read as the weight's maximum (exact after a refresh here; an upper bound after a fused
+    # optimiser step, fused_adam_step); exact_ok: the device's `exact` array holds the exact maximum of the CURRENT values
+    __slots__ = ("ref", "idx", "slot", "device", "parts", "tag", "exact_ok", "__weakref__")
 
 
 _WP_ENTRIES = {}  # id(weight) -> _WeightParts
@@ -424,7 +426,8 @@ def _wp_state(device):
     st = _WP_DEV.get(device)
     if st is None:
         st = _WP_DEV[device] = {"slots": torch.zeros(_WP_NSLOTS, device=device, dtype=torch.int32),
-                                "free": list(range(_WP_NSLOTS - 1, -1, -1)), "sig": None, "tables": None}
+                                "exact": torch.zeros(_WP_NSLOTS, device=device, dtype=torch.int32),
+                                "free": list(range(_WP_NSLOTS - 1, -1, -1)), "tables": {}, "adam_plan": None}
     return st
 
 
@@ -473,7 +476,7 @@ def _wp_refresh(device):
         return
     sp = stream_ptr()
     lib = _lib.load()
-    if len(stale) < n_live or len(stale) <= 2:  # new registrations: the single-tensor calls
+    if len(stale) <= 2:  # a new registration: the single-tensor calls
         for ent, w in stale:
             ent.slot.zero_()
             wm = weight_mem(w.detach())
@@ -482,11 +485,15 @@ def _wp_refresh(device):
             for transposed, parts in ent.parts.items():
                 call("rac_weight_frag_split", ptr(wm), ptr(ent.slot), ptr(parts), co, ci, k, 1 if transposed else 0,
                      wm.numel(), sp)
-            ent.tag = _wp_tag(w)
+            st["exact"][ent.idx:ent.idx + 1].copy_(ent.slot)
+            ent.tag, ent.exact_ok = _wp_tag(w), True
         return
     sig = tuple((w.data_ptr(), ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items())))
                 for ent, w in stale)
-    if st["sig"] != sig:  # job tables (device memory) for this set of weights
+    tables = st["tables"].get(sig)
+    if tables is None:  # job tables (device memory) for this set of weights
+        if len(st["tables"]) > 8:
+            st["tables"].clear()
         ajobs = (AbsmaxJob * len(stale))()
         nfrag = sum(len(ent.parts) for ent, _ in stale)
         fjobs = (FragJob * nfrag)()
@@ -501,14 +508,124 @@ def _wp_refresh(device):
                                    Cin=ci, ksize=k, transposed=1 if transposed else 0, block_begin=fb)
                 fb += lib.rac_weight_frag_blocks(co, ci, k)
                 j += 1
-        st["tables"] = (_wp_upload(ajobs, device), len(stale), ab, _wp_upload(fjobs, device), nfrag, fb)
-        st["sig"] = sig
-    ta, na, ab, tf, nf, fb = st["tables"]
-    st["slots"].zero_()  # every live slot is recomputed
+        idx = torch.tensor([ent.idx for ent, _ in stale], device=device, dtype=torch.long)
+        tables = st["tables"][sig] = (_wp_upload(ajobs, device), len(stale), ab, _wp_upload(fjobs, device), nfrag, fb, idx)
+    ta, na, ab, tf, nf, fb, idx = tables
+    st["slots"].index_fill_(0, idx, 0)  # the stale slots are recomputed (the others may hold bounds of a fused step)
     call("rac_absmax_multi", ptr(ta), na, ab, sp)
     call("rac_weight_frag_split_multi", ptr(tf), nf, fb, sp)
+    st["exact"].index_copy_(0, idx, st["slots"].index_select(0, idx))
     for ent, w in stale:
+        ent.tag, ent.exact_ok = _wp_tag(w), True
+
+
+# Fused optimiser step: for the conv weights that live in the model's flat parameter buffer and run on the split-precision
+# pipe, ONE pass does Adam and writes the next step's fp16 fragment parts (rac_adam_frag_multi) -- instead of Adam, then
+# a pass for the maxima, then one that re-reads every weight to split it (three reads of the 954 MB at g 512).  The
+# parts must be scaled before the new maximum is known: Adam moves an element by at most lr * adam_step_bound(), so
+# max |w| + that margin bounds the new maximum, and its exponent is the scale; the exact maximum comes out of the same
+# pass for the next step's bound.  Everything else in the flat buffer takes plain Adam over the complementary ranges.
+ADAM_FUSED = os.environ.get("RAC_ADAM_FUSED", "1") == "1"
+_ADAM_BOUNDS = {}
+
+
+def adam_step_bound(beta1: float, beta2: float):
+    """sup over t of |m_hat_t| / sqrt(v_hat_t) for ANY gradient history (Cauchy-Schwarz over the two exponential
+    averages): the largest multiple of lr an Adam step can move an element.  None when it is unbounded."""
+    key = (beta1, beta2)
+    if key not in _ADAM_BOUNDS:
+        r = beta1 * beta1 / beta2
+        if not (0.0 <= beta1 < 1.0 and 0.0 < beta2 < 1.0 and r < 1.0):
+            _ADAM_BOUNDS[key] = None
+        else:
+            best, series, b1t, b2t, rk = 0.0, 0.0, 1.0, 1.0, 1.0
+            for _ in range(200000):
+                series += rk
+                rk *= r
+                b1t *= beta1
+                b2t *= beta2
+                best = max(best, (1 - beta1) ** 2 / (1 - b1t) ** 2 * (1 - b2t) / (1 - beta2) * series)
+                if rk < 1e-18 and b1t < 1e-18 and b2t < 1e-9:
+                    break
+            _ADAM_BOUNDS[key] = best ** 0.5
+    return _ADAM_BOUNDS[key]
+
+
+def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
+    """One optimiser step over the flat buffers with the registered split-precision weights' parts refreshed in the
+    same pass.  False (nothing launched) when that is not possible yet -- a weight whose parts or maximum are not
+    current (first steps, new registrations), no registered weight inside `flat`, an unbounded Adam step: the caller
+    then takes rac_adam_step and the parts are refreshed lazily."""
+    global PARAM_EPOCH
+    if not ADAM_FUSED:
+        return False
+    bound = adam_step_bound(beta1, beta2)
+    if bound is None:
+        return False
+    dev = flat.device
+    st = _wp_state(dev)
+    base, nbytes = flat.data_ptr(), flat.numel() * 4
+    covered = []
+    for ent in _WP_ENTRIES.values():
+        if ent.device != dev:
+            continue
+        w = ent.ref()
+        if w is None or getattr(w, "_rac_pad_source", None) is not None:
+            continue
+        off = w.data_ptr() - base
+        co, ci, k, _ = w.shape
+        if not (0 <= off < nbytes and off % 16 == 0 and w.stride() == (k * k * ci, 1, k * ci, ci)):
+            continue
+        if ent.tag != _wp_tag(w) or not ent.exact_ok:
+            return False
+        covered.append((off // 4, ent, w))
+    if not covered:
+        return False
+    covered.sort(key=lambda c: c[0])
+    sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+           tuple((off, ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items()))) for off, ent, _ in covered))
+    plan = st["adam_plan"]
+    if plan is None or plan["sig"] != sig:
+        lib = _lib.load()
+        jobs = (AdamFragJob * len(covered))()
+        ranges, blocks, pos = [], 0, 0
+        for i, (off, ent, w) in enumerate(covered):
+            co, ci, k, _ = w.shape
+            n = w.numel()
+            assert off % 4 == 0 and n % 4 == 0 and off >= pos, "overlapping conv weights in the flat buffer"
+            if off > pos:
+                ranges.append((pos // 4, (off - pos) // 4))
+            pos = off + n
+            jobs[i] = AdamFragJob(p=base + 4 * off, g=grad.data_ptr() + 4 * off, m=m.data_ptr() + 4 * off,
+                                  v=v.data_ptr() + 4 * off, scale_slot=ptr(ent.slot),
+                                  amax_out=ptr(st["exact"][ent.idx:ent.idx + 1]), parts_fwd=ptr(ent.parts.get(False)),
+                                  parts_t=ptr(ent.parts.get(True)), part_stride=n, Cout=co, Cin=ci, ksize=k, reserved=0,
+                                  block_begin=blocks)
+            blocks += lib.rac_weight_frag_blocks(co, ci, k)
+        if pos < flat.numel():
+            ranges.append((pos // 4, (flat.numel() - pos + 3) // 4))
+        rjobs = (AdamRange * max(1, len(ranges)))()
+        rblocks = 0
+        for i, (b4, n4) in enumerate(ranges):
+            rjobs[i] = AdamRange(begin4=b4, n4=n4, block_begin=rblocks)
+            rblocks += _cdiv(n4, 1024)
+        assert flat.numel() % 4 == 0
+        plan = st["adam_plan"] = {
+            "sig": sig, "jobs": _wp_upload(jobs, dev), "n_jobs": len(covered), "blocks": blocks,
+            "ranges": _wp_upload(rjobs, dev), "n_ranges": len(ranges), "rblocks": rblocks,
+            "idx": torch.tensor([ent.idx for _, ent, _ in covered], device=dev, dtype=torch.int32)}
+    sp = stream_ptr()
+    call("rac_amax_bound", ptr(st["exact"]), ptr(st["slots"]), ptr(plan["idx"]), plan["n_jobs"],
+         float(lr) * bound * 1.01, sp)
+    call("rac_adam_frag_multi", ptr(plan["jobs"]), plan["n_jobs"], plan["blocks"], float(lr), float(beta1), float(beta2),
+         float(eps), int(step), sp)
+    if plan["n_ranges"]:
+        call("rac_adam_ranges", ptr(flat), ptr(grad), ptr(m), ptr(v), ptr(plan["ranges"]), plan["n_ranges"],
+             plan["rblocks"], float(lr), float(beta1), float(beta2), float(eps), int(step), sp)
+    PARAM_EPOCH += 1
+    for _, ent, w in covered:  # their parts and maxima already describe the new values
         ent.tag = _wp_tag(w)
+    return True
 
 
 def weight_parts(weight: torch.Tensor, transposed: bool = False):
@@ -525,7 +642,7 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
             raise _lib.RacError(f"split-precision weight {tuple(weight.shape)}: channel counts must be multiples of 32")
         ent = _WeightParts()
         ent.idx = st["free"].pop()
-        ent.device, ent.parts, ent.tag = weight.device, {}, None
+        ent.device, ent.parts, ent.tag, ent.exact_ok = weight.device, {}, None, False
         ent.slot = st["slots"][ent.idx:ent.idx + 1]
         ent.ref = weakref.ref(weight, functools.partial(_wp_drop, key, weight.device, ent.idx))
         _WP_ENTRIES[key] = ent

@@ -31,7 +31,11 @@ class FusedAdam(torch.optim.Optimizer):
         m, v = self._moments()
         g = self.param_groups[0]
         self._steps += 1
-        ops.PARAM_EPOCH += 1  # invalidates caches derived from the parameters (padded weight copies)
+        # one pass that also writes the next step's operand parts of the split-precision conv weights, when their parts
+        # and maxima are current (every step after the first); plain Adam over the whole buffer otherwise
+        if ops.fused_adam_step(flat, grad, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps):
+            return
+        ops.PARAM_EPOCH += 1  # invalidates caches derived from the parameters (padded weight copies, operand parts)
         _lib.call("rac_adam_step", flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(),
                   float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), self._steps,
                   _lib.stream_ptr())

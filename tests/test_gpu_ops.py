@@ -736,3 +736,59 @@ def test_amax_tag_does_not_survive_gradient_accumulation(dev):
     assert ops.amax_tag(t) is not None
     t.add_(1.0)
     assert ops.amax_tag(t) is None and int(ops.amax_for(t).item()) == int(t.abs().max().view(torch.int32).item())
+
+
+def test_fused_adam_step_writes_the_next_parts(dev):
+    """rac_adam_frag_multi + rac_adam_ranges against rac_adam_step + the separate refresh: the same p / m / v bits, the
+    fragment parts of the UPDATED weights under the bound's scale (bit-equal to rac_weight_frag_split run on them with
+    that slot), the exact new maxima kept for the next bound; taken only when every registered weight is current."""
+    from robot_aware_control_amd import _lib, ops
+    shapes = [(64, 96, 3), (128, 64, 5), (32, 32, 3)]
+    sizes = [co * ci * k * k for co, ci, k in shapes]
+    gaps = [8, 20, 12, 36]  # "biases" between and around the conv weights (multiples of 4 floats)
+    total = sum(sizes) + sum(gaps)
+    g0 = torch.Generator().manual_seed(5)
+    flat = (torch.randn(total, generator=g0) * 0.05).to(dev)
+    grad = (torch.randn(total, generator=g0) * 0.01).to(dev)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    ws, off = [], gaps[0]
+    for (co, ci, k), n, gap in zip(shapes, sizes, gaps[1:]):
+        ws.append(torch.as_strided(flat, (co, ci, k, k), (k * k * ci, 1, k * ci, ci), off))
+        off += n + gap
+    assert not ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 1)  # nothing registered yet
+    for w, both in zip(ws, (True, True, False)):
+        ops.weight_parts(w)
+        if both:
+            ops.weight_parts(w, transposed=True)
+    ref = [t.clone() for t in (flat, m, v)]
+    for step in (1, 2, 3):
+        lr = 1e-3
+        _lib.call("rac_adam_step", ref[0].data_ptr(), grad.data_ptr(), ref[1].data_ptr(), ref[2].data_ptr(), total, lr, 0.9,
+                  0.999, 1e-8, step, _lib.stream_ptr())
+        assert ops.fused_adam_step(flat, grad, m, v, lr, 0.9, 0.999, 1e-8, step)
+        assert torch.equal(flat, ref[0]) and torch.equal(m, ref[1]) and torch.equal(v, ref[2])
+        st = ops._wp_state(dev)
+        for w, both in zip(ws, (True, True, False)):
+            ent = ops._WP_ENTRIES[id(w)]
+            assert ent.tag == ops._wp_tag(w)  # no lazy refresh will follow
+            exact = st["exact"][ent.idx:ent.idx + 1]
+            assert int(exact.item()) == int(w.abs().max().view(torch.int32).item())
+            bound = ent.slot.view(torch.float32)
+            assert float(w.abs().max()) <= float(bound) <= float(w.abs().max()) + 10 * lr
+            co, ci, k, _ = w.shape
+            for transposed in ((False, True) if both else (False,)):
+                want = torch.empty_like(ent.parts[transposed])
+                _lib.call("rac_weight_frag_split", w.data_ptr(), ent.slot.data_ptr(), want.data_ptr(), co, ci, k,
+                          1 if transposed else 0, w.numel(), _lib.stream_ptr())
+                assert torch.equal(ent.parts[transposed], want), (tuple(w.shape), transposed)
+            # and the conv that consumes them is right
+            x = to_map(rnd(91, 2, ci, 8, 8), dev)
+            got = ops.conv_forward_split(x, None, w, None)
+            refc = F.conv2d(from_map(x).double(), w.detach().cpu().double(), None, 1, k // 2)
+            assert relerr(from_map(got), refc) < 2e-6
+        grad.mul_(1.7)
+    # a weight changed behind the parts' back (load_state_dict ...): the fused step declines, the lazy refresh repairs
+    ws[0].mul_(2.0)
+    assert not ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
+    ops.weight_parts(ws[0])
+    assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
