@@ -48,6 +48,18 @@ __device__ __forceinline__ double wave_sum_d(double v) {
   return v;
 }
 
+// One Adam update (torch.optim.Adam semantics, reference trainer.py:109-110,461), shared by every kernel that applies it
+// (adam_kernel, adam_ranges_kernel, adam_frag_multi_kernel) with floating-point contraction OFF: the same bits whichever
+// kernel updates an element.  step_size = lr / (1 - beta1^t), inv_sqrt_bc2 = 1 / sqrt(1 - beta2^t).
+__device__ __forceinline__ void adam_update(float& p, float g, float& m, float& v, float b1, float b2, float eps,
+                                            float step_size, float inv_sqrt_bc2) {
+#pragma clang fp contract(off)
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + ((1.f - b2) * g) * g;
+  const float denom = sqrtf(v) * inv_sqrt_bc2 + eps;
+  p = p - step_size * (m / denom);
+}
+
 // max |v| bookkeeping for the split-precision convs (include/rac_hip.h, rac_absmax): a kernel that produces a
 // tensor folds the bit pattern of its max |v| into a device slot -- wave reduce, then at most one atomic per wave and
 // only if it can raise the slot.  Every lane of the wave must call amax_commit.

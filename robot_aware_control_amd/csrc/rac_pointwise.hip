@@ -587,10 +587,7 @@ __global__ void adam_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v, long n
                             float* mt, float* vt, int tail, float b1, float b2, float eps, float step_size,
                             float inv_sqrt_bc2) {
   auto upd = [&](float& pp, float gg, float& mm, float& vv) {
-    mm = b1 * mm + (1.f - b1) * gg;
-    vv = b2 * vv + (1.f - b2) * gg * gg;
-    float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-    pp -= step_size * (mm / denom);
+    adam_update(pp, gg, mm, vv, b1, b2, eps, step_size, inv_sqrt_bc2);
   };
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
     f32x4 P = p[i], G = g[i], Mv = m[i], V = v[i];
@@ -623,11 +620,9 @@ __global__ void adam_ranges_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v,
     f32x4 P = p[i], G = g[i], Mv = m[i], V = v[i];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const float mm = b1 * Mv[e] + (1.f - b1) * G[e];
-      const float vv = b2 * V[e] + (1.f - b2) * G[e] * G[e];
-      const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-      P[e] -= step_size * (mm / denom);
-      Mv[e] = mm, V[e] = vv;
+      float pe = P[e], me = Mv[e], ve = V[e];
+      adam_update(pe, G[e], me, ve, b1, b2, eps, step_size, inv_sqrt_bc2);
+      P[e] = pe, Mv[e] = me, V[e] = ve;
     }
     p[i] = P, m[i] = Mv, v[i] = V;
   }

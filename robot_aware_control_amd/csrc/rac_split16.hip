@@ -865,12 +865,9 @@ __global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_fra
       M[h] = *reinterpret_cast<const f32x4*>(q.m + off + 4 * h);
       V[h] = *reinterpret_cast<const f32x4*>(q.v + off + 4 * h);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {  // the arithmetic of adam_kernel (rac_pointwise.hip), operation for operation
-        const float gg = G[h][e];
-        const float mm = b1 * M[h][e] + (1.f - b1) * gg;
-        const float vv = b2 * V[h][e] + (1.f - b2) * gg * gg;
-        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
-        const float pp = P[h][e] - step_size * (mm / denom);
+      for (int e = 0; e < 4; ++e) {
+        float pp = P[h][e], mm = M[h][e], vv = V[h][e];
+        adam_update(pp, G[h][e], mm, vv, b1, b2, eps, step_size, inv_sqrt_bc2);  // the same bits as adam_kernel
         M[h][e] = mm, V[h][e] = vv, P[h][e] = pp;
         mx = max(mx, absbits(pp));
         tile[half][rl][kl + 4 * h + e] = pp;

@@ -752,11 +752,15 @@ def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
     dy = dy if dy.is_contiguous() else dy.contiguous()
     pw, wslot = weight_parts(weight, transposed=True)
     split = plan_split_k(M, Cin, k * k * _cdiv(Cout, 32), tile128_only=True)
+    dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
+    s0 = amax_slot(dy.device)  # the kernel that writes dx leaves max |dx| for the conv that consumes the gradient
+    if split == 1 and not C1:  # one K range, one destination: the conv writes dx itself (no slab, no combine pass)
+        _split_launch(dy, None, amax_for(dy), None, pw, wslot, dx0, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout,
+                      out_amax=s0)
+        return tag_amax(dx0, s0), None
     slabs = torch.empty((split, M * Cin), device=dy.device, dtype=torch.float32)
     _split_launch(dy, None, amax_for(dy), None, pw, wslot, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=Cin, C0=Cout,
                   split_k=split, slab_stride=M * Cin)
-    dx0 = torch.empty((B, H, W, C0), device=dy.device, dtype=torch.float32)
-    s0 = amax_slot(dy.device)  # the combine leaves max |dx| for the conv that consumes the gradient
     if C1:
         dx1 = torch.empty((B, H, W, C1), device=dy.device, dtype=torch.float32)
         s1 = amax_slot(dy.device)
