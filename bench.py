@@ -110,7 +110,7 @@ def pmc_traffic(tag, kernel_substr, workgroups):
     """HBM-side bytes per launch of the dominant kernel from the newest committed PMC profile
     (profiles/*_pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r02*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")))
     if not files:
         return None, None
     try:
