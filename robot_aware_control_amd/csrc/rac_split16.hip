@@ -720,6 +720,223 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// PERSISTENT form of the unrolled 3x3 rows kernel for the narrow layers (64 / 32 output columns per workgroup: the
+// 64-channel 64x64 layers and the 4-channel output head).  Their K is 18-36 steps per tile, so a tile's life is mostly
+// fixed costs: the first chunk's HBM round trip with nothing to overlap it, the epilogue's stores, a fresh workgroup.
+// Here a workgroup walks tiles bx, bx + gridDim.x, ... : while the LAST chunk of a tile is multiplied, the first chunk of
+// the NEXT tile is already requested (and the weight ring wraps to the next tile's first two taps: same weights), so the
+// epilogue's stores run under those loads and the next tile starts from registers.  Same arithmetic, same order of sums:
+// bit-equal to conv16_rows_kernel<NV, WM, NT, 3, true>.
+// ---------------------------------------------------------------------------------------------------------
+template <int NV, int WM, int NT>
+__global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) {
+  constexpr int WN = 4 / WM;
+  constexpr int MB = 8 / WM;
+  constexpr int NB = 2 * NT;
+  constexpr int BNW = WN * NT * 32;
+  constexpr int TM = 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15;
+  const int by = blockIdx.y;
+  const int wn = wid % WN, wm = wid / WN;
+  const int nmb = TM >> 4;
+  const int n0 = by * BNW;
+  const int kc_begin = 0, kc_end = p.nchunks;  // (never K-split: the short-K layers)
+  const int kw = scale_exp(*p.w_amax);
+  const int halo = p.W;
+  const int nrows = TM + 2 * halo;
+  const int cplane = (nrows + 16) * 16;
+  const int pplane = 4 * cplane;
+  const int abuf = 2 * pplane;
+  {
+    const int pl = tid >> 4, r = tid & 15;
+    *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * abuf + ((pl >> 2) & 1) * pplane + (pl & 3) * cplane +
+                              (nrows + r) * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  // tile-independent staging roles
+  int s_off[NV], s_row[NV], s_grp[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int v = tid + 256 * i;
+    const int g = v / nrows, row = v - g * nrows;
+    s_grp[i] = g;
+    s_row[i] = row;
+    s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
+  }
+  unsigned amask[MB];
+#pragma unroll
+  for (int t = 0; t < MB; ++t) {
+    const int r = (wm * MB + t) * 16 + lr;
+    const int x = r % p.W;
+    unsigned mk = 0;
+    for (int kx = 0; kx < 3; ++kx) mk |= ((unsigned)(x + kx - 1) < (unsigned)p.W) ? (1u << kx) : 0u;
+    amask[t] = mk;
+  }
+  const int lq = lane >> 4;
+  const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;
+  const int zrow = lq * cplane + nrows * 16;
+  const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
+  const unsigned w_pstride = (unsigned)(p.w_ps * 2);
+  unsigned b_off[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int ntile = (n0 >> 5) + wn * NT + j;
+    b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.w_nchunks * 2048u : 0u) + (unsigned)lane * 16u;
+  }
+  auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
+    const int so = kc * 2048;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+          rb[(j * 2 + part) * 2 + nb] = __builtin_bit_cast(
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), so, 0));
+  };
+  // per-tile state: the tile being multiplied (cur) and the one whose first chunk is in flight (nxt)
+  struct TileState {
+    int m0, ka;
+    bool ok[NV];
+    int pix[NV];
+  };
+  auto setup = [&](int bx, TileState& t) {
+    t.m0 = bx * TM;
+    const int img = p.per_image ? t.m0 / p.HW : 0;
+    unsigned am = p.a_amax0[img];
+    if (p.a_amax1) am = max(am, p.a_amax1[img]);
+    t.ka = scale_exp(am);
+    const int y_tile = (t.m0 % p.HW) / p.W;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = s_row[i];
+      const int y = y_tile - 1 + row / p.W;
+      t.ok[i] = (s_grp[i] < 4) & ((unsigned)y < (unsigned)p.H) & (t.m0 - halo + row < p.M);
+      t.pix[i] = t.m0 - halo + row;
+      if (p.a0_up && t.ok[i]) {
+        const int im = t.pix[i] / p.HW, x = row % p.W;
+        t.pix[i] = (im * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      }
+    }
+  };
+  u32x4 ra[2 * NV];
+  auto issue_a = [&](int cc, const TileState& t) {
+    const int c0 = cc * SBK;
+    const bool first = c0 < p.a_split;
+    const int Cs = first ? p.a_split : p.Cin - p.a_split;
+    const int cl = first ? c0 : c0 - p.a_split;
+    const bool up = first && p.a0_up;
+    const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1,
+                                    (unsigned)((long)(up ? p.P >> 2 : p.P) * Cs * 4));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const unsigned oa = (unsigned)((up ? t.pix[i] : t.m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      ra[2 * i] = load16(a_rsrc, t.ok[i] ? oa : OOB);
+      ra[2 * i + 1] = load16(a_rsrc, t.ok[i] ? oa + 16u : OOB);
+    }
+  };
+  auto store_a = [&](int buf, float sa) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      if (s_off[i] < 0) continue;
+      u32x4 q[2];
+      split8h(ra[2 * i], ra[2 * i + 1], sa, q);
+#pragma unroll
+      for (int part = 0; part < 2; ++part)
+        *reinterpret_cast<u32x4*>(lds_raw + buf * abuf + part * pplane + s_off[i]) = q[part];
+    }
+  };
+  float pre[NB][3];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n0 + wn * NT * 32 + nb * 16 + lr;
+    const int nc = n < p.n_store ? n : 0;
+    pre[nb][0] = p.bias ? p.bias[nc] : 0.f;
+    pre[nb][1] = p.scale ? p.scale[nc] : 1.f;
+    pre[nb][2] = p.scale ? p.shift[nc] : 0.f;
+  }
+  const int n_tiles = (p.M + TM - 1) / TM;
+  const int c_end = kc_end / 9;
+  TileState cur_t, nxt_t;
+  int bx = blockIdx.x;
+  if (bx >= n_tiles) return;
+  setup(bx, cur_t);
+  u32x4 bs[3][4 * NT];
+  issue_a(0, cur_t);
+  load_b(bs[0], kc_begin);
+  load_b(bs[1], min(kc_begin + 1, kc_end - 1));
+  int cur = 0;
+  for (;;) {
+    const int next_bx = bx + gridDim.x;
+    const bool has_next = next_bx < n_tiles;
+    store_a(cur, pow2f(cur_t.ka));  // the first chunk of this tile: requested while the previous tile was finishing
+    __syncthreads();
+    if (has_next) setup(next_bx, nxt_t);
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int cc = 0; cc < c_end; ++cc) {
+      const bool more = cc + 1 < c_end;
+      if (more)
+        issue_a(cc + 1, cur_t);
+      else if (has_next)
+        issue_a(0, nxt_t);
+      const int kc0 = cc * 9;
+      const int bufo = cur * abuf;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap % 3;
+        // the ring wraps to taps 0 and 1 of chunk 0 behind the last chunk: the next tile multiplies the same weights
+        int knext = kc0 + tap + 2;
+        knext = knext >= kc_end ? knext - kc_end : knext;
+        load_b(bs[(tap + 2) % 3], knext);
+        const int drow = (ky - 1) * p.W + (kx - 1);
+        const int shift = drow * 16 + bufo + abase;
+        const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;
+        f16x8 fb[NB][2];
+#pragma unroll
+        for (int j2 = 0; j2 < NT; ++j2)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+              fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[tap % 3][(j2 * 2 + part) * 2 + nb]);
+        f16x8 fa[MB][2];
+#pragma unroll
+        for (int t = 0; t < MB; ++t) {
+          const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+        }
+#pragma unroll
+        for (int t = 0; t < MB; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
+      }
+      if (more) {
+        store_a(cur ^ 1, pow2f(cur_t.ka));
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+    const int img = p.per_image ? cur_t.m0 / p.HW : 0;
+    conv16_epilogue(p, acc, cur_t.m0, wm * MB, nmb, n0 + wn * NT * 32, 0, pow2f(-cur_t.ka), pow2f(-kw), pre, nullptr,
+                    p.out_amax ? p.out_amax + img : nullptr);
+    if (!has_next) break;
+    // the next tile's first chunk goes to the buffer nobody reads any more (the last chunk sits in `cur`)
+    cur ^= 1;
+    cur_t = nxt_t;
+    bx = next_bx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // max |x| of one or two fp32 arrays as a bit pattern (non-negative floats order like unsigned integers):
 // *amax = max(*amax, bits(max |x|)).  The slot must hold 0 (or an earlier maximum) on entry.
 // ---------------------------------------------------------------------------------------------------------
@@ -1650,8 +1867,33 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
     static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
     rows_fn fn = fns[width][nv - 2];
-    if (a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast)))
-      fn = fast_fns[width][nv - 2];
+    const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast));
+    if (fast) fn = fast_fns[width][nv - 2];
+    // narrow layers (64 / 32 columns), unsplit K, many more tiles than the chip holds: persistent workgroups that walk
+    // the tiles and request the next tile's first chunk under the current tile's last one
+    static const rows_fn persist_fns[2][3] = {
+        {conv16_rows_persist_kernel<2, 2, 1>, conv16_rows_persist_kernel<3, 2, 1>, conv16_rows_persist_kernel<4, 2, 1>},
+        {conv16_rows_persist_kernel<2, 4, 1>, conv16_rows_persist_kernel<3, 4, 1>, conv16_rows_persist_kernel<4, 4, 1>}};
+    static const char* nopersist = getenv("RAC_ROWS_PERSIST");
+    static const int persist_wgs = [] { const char* e = getenv("RAC_ROWS_PERSIST_WGS"); return e ? atoi(e) : 512; }();
+    if (fast && width >= 1 && p.split_k == 1 && (int)grid.x >= 4 * persist_wgs && !(nopersist && atoi(nopersist) == 0)) {
+      static bool persist_attr = false;
+      if (!persist_attr) {
+        for (int i = 0; i < 6; ++i) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(persist_fns[i / 3][i % 3]),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * (256 + 16) * 16);
+          if (e != hipSuccess) {
+            set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return RAC_ELAUNCH;
+          }
+        }
+        persist_attr = true;
+      }
+      p.xcd_group = 0;
+      hipLaunchKernelGGL(persist_fns[width - 1][nv - 2], dim3(persist_wgs, grid.y, 1), dim3(256), lds_rows,
+                         reinterpret_cast<hipStream_t>(stream), p);
+      return check_launch("rac_conv2d_fwd_split(image rows, persistent)");
+    }
     hipLaunchKernelGGL(fn, grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(image rows)");
   }

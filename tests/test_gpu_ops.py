@@ -515,13 +515,16 @@ def test_weight_frag_split(dev, shape):
 
 
 @pytest.mark.parametrize("B,H,W,C0,C1,Cout,k", [(5, 8, 8, 64, 64, 256, 5), (3, 6, 8, 128, 0, 128, 3), (3, 16, 16, 64, 64, 128, 3),
-                                                  (2, 64, 64, 64, 0, 64, 3), (4, 32, 32, 128, 0, 32, 3)])
+                                                  (2, 64, 64, 64, 0, 64, 3), (4, 32, 32, 128, 0, 32, 3),
+                                                  (80, 64, 64, 64, 0, 64, 3), (72, 64, 64, 32, 32, 32, 3)])
 def test_per_image_scales_make_a_conv_batch_invariant(dev, B, H, W, C0, C1, Cout, k):
     """`per_image` (the frozen model): every image is scaled by its own max |x|, K is never split -> an image's output is
     the same bits alone, in any batch and at any position in it, even next to images 1e4 times larger; accuracy as the
     per-tensor form.  Producers leave one maximum per image (conv epilogue, tilecat, rac_absmax_rows)."""
     from robot_aware_control_amd import ops
-    mags = torch.tensor([1.0, 3e-4, 2e3, 0.07, 11.0])[:B].view(B, 1, 1, 1)
+    # (the two large batches are >= 2048 tiles of 128 pixels: the PERSISTENT rows kernel, whose sub-batches below take the
+    # one-tile-per-workgroup kernel -- bit-equal)
+    mags = torch.tensor([1.0, 3e-4, 2e3, 0.07, 11.0]).repeat((B + 4) // 5)[:B].view(B, 1, 1, 1)
     x0 = to_map(rnd(61, B, C0, H, W) * mags, dev)
     x1 = to_map(rnd(62, B, C1, H, W) * mags, dev) if C1 else None
     wt = cl_weight(rnd(63, Cout, C0 + C1, k, k) * 0.05).to(dev)
