@@ -8,9 +8,11 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 nopk="-Xclang -target-feature -Xclang -packed-fp32-ops"; [ "$RAC_PACKED" = "1" ] && nopk=""
 obj=/tmp/rac_variant_$name; mkdir -p "$obj" "$root/robot_aware_control_amd/variants"
+# RAC_PACKED_FILES="rac_frame rac_split16": packed fp32 ops in those translation units only (bisecting the miscompute)
 for f in rac_igemm rac_split16 rac_pointwise rac_frame; do
+  fl=$nopk; case " $RAC_PACKED_FILES " in *" $f "*) fl="";; esac
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I"$root/include" -Wall -Wno-unused-function \
-    $nopk "$@" \
+    $fl "$@" \
     -c "$root/robot_aware_control_amd/csrc/$f.hip" -o "$obj/$f.o" &
 done
 wait

@@ -22,7 +22,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = ("conv16_tile_kernel", "conv16_rows_kernel", "wgrad16_kernel", "wgrad16_allky_kernel")
+KERNELS = ("conv16_tile_kernel", "conv16_rows_kernel", "conv16_rows_persist_kernel", "wgrad16_kernel", "wgrad16_allky_kernel")
 
 
 def short(name):

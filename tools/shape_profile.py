@@ -13,7 +13,7 @@ import re
 import sys
 from collections import OrderedDict, defaultdict
 
-FAMILIES = [("conv16", re.compile(r"conv16_(tile|rows)_kernel")), ("wgrad16", re.compile(r"wgrad16_(allky_)?kernel")),
+FAMILIES = [("conv16", re.compile(r"conv16_(tile|rows|rows_persist)_kernel")), ("wgrad16", re.compile(r"wgrad16_(allky_)?kernel")),
             ("igemm", re.compile(r"igemm_\w*kernel"))]
 
 
