@@ -436,10 +436,33 @@ class SVGConvModel(nn.Module):
         flat = lambda t: None if t is None else t.reshape((T * B,) + tuple(t.shape[2:]))
         h_all, skips = self._encode(flat(images), flat(masks), flat(heatmaps), flat(zero_masks), 2, T)
         h_steps = h_all.view((T, B) + tuple(h_all.shape[1:])).unbind(0)
+        # the prior's and the posterior's input convs see only data and the encoder output (the posterior encodes the
+        # CURRENT frame: dynamics.py:619), all known before the recurrence starts: ONE launch each over the T*B latents
+        # instead of T (M = 5120 instead of 5 x 1024 at cfg2: no K split, no combine, a fifth of the launches, forward
+        # and backward); only the frame predictor's input conv waits for z_t
+        cf = self._config
+        cat = lambda seq: torch.cat([v.contiguous() for v in seq], 0)
+        a_all = cat(actions)
+        r_all = rn_all = None
+        if cf.model_use_robot_state:
+            if cf.model_use_future_robot_state:
+                r_all, rn_all = cat([r[0] for r in robots]), cat([r[1] for r in robots])
+            else:
+                r_all = cat(robots)
+        prior_all = self._embed(self.prior_input_conv, [v for v in (a_all, r_all, rn_all) if v is not None], h_all, None)
+        if cf.model_use_robot_state:
+            post_all = self._embed(self.posterior_input_conv, [cat(next_robots)], h_all, None)
+        else:
+            q = self.posterior_input_conv
+            post_all = ops.ConvBias.apply(h_all, None, q.weight, q.bias, ACT_NONE, not torch.is_grad_enabled())
+        # (a step's slice inherits the whole tensor's maximum: a valid bound, and no reduction pass per step)
+        steps_of = lambda t_: [ops.retag(s_, ops.amax_tag(t_)) for s_ in t_.view((T, B) + tuple(t_.shape[1:])).unbind(0)]
+        prior_steps, post_steps = steps_of(prior_all), steps_of(post_all)
         h_preds, mus, logvars, mu_ps, logvar_ps = [], [], [], [], []
         for t in range(T):
             h_pred, mu, logvar, mu_p, logvar_p = self._recur(h_steps[t], robots[t], actions[t], True, next_robots[t],
-                                                             False, False)
+                                                             False, False, prior_in=prior_steps[t],
+                                                             post_in=post_steps[t])
             h_preds.append(h_pred)
             mus.append(mu)
             logvars.append(logvar)
@@ -476,8 +499,19 @@ class SVGConvModel(nn.Module):
         x_in = ops.PackInput.apply(image, None if zero_mask is None else zero_mask.contiguous(), mask_planes, pad_to)
         return self.encoder(x_in, n_updates, groups)
 
-    def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean):
-        """The stepped part of `forward`: prior / posterior / frame predictor on one time step's latent."""
+    def _embed(self, conv, vs, h, z):
+        """conv(cat[tile(vs), h, z]) (dynamics.py:591-607,634-640); the frozen model's conv reads h in place (no
+        concatenated tensor)."""
+        frozen = not torch.is_grad_enabled()  # no tape: the input convs may take the split-precision pipe
+        if frozen and not self.training and ops.embed_frozen_ok(vs, h, z, conv.weight):
+            return ops.embed_frozen(vs, h, z, conv.weight, conv.bias)
+        vs3 = list(vs) + [None] * (3 - len(vs))
+        return ops.ConvBias.apply(ops.TileCat.apply(vs3[0], vs3[1], vs3[2], h, z, frozen), None, conv.weight,
+                                  conv.bias, ACT_NONE, frozen)
+
+    def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean, prior_in=None, post_in=None):
+        """The stepped part of `forward`: prior / posterior / frame predictor on one time step's latent.
+        `prior_in` / `post_in`: the two input convs' outputs when the caller ran them for all time steps at once."""
         cf = self._config
         a = action.contiguous()
         r = r_next = None
@@ -487,31 +521,23 @@ class SVGConvModel(nn.Module):
                 r, r_next = r.contiguous(), r_next.contiguous()
             else:
                 r = robot.contiguous()
-        p = self.prior_input_conv
-        frozen = not torch.is_grad_enabled()  # no tape: the input convs may take the split-precision pipe
-
-        def embed(conv, vs, z):
-            """conv(cat[tile(vs), h, z]); the frozen model's conv reads h in place (no concatenated tensor)."""
-            if frozen and not self.training and ops.embed_frozen_ok(vs, h, z, conv.weight):
-                return ops.embed_frozen(vs, h, z, conv.weight, conv.bias)
-            vs3 = list(vs) + [None] * (3 - len(vs))
-            return ops.ConvBias.apply(ops.TileCat.apply(vs3[0], vs3[1], vs3[2], h, z, frozen), None, conv.weight,
-                                      conv.bias, ACT_NONE, frozen)
-
-        prior_in = embed(p, [v for v in (a, r, r_next) if v is not None], None)
+        frozen = not torch.is_grad_enabled()
+        if prior_in is None:
+            prior_in = self._embed(self.prior_input_conv, [v for v in (a, r, r_next) if v is not None], h, None)
         z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean)
         z = mu_p if sample_mean else z_p
         mu = logvar = None
         if posterior:
             q = self.posterior_input_conv
-            if cf.model_use_robot_state:
-                post_in = embed(q, [next_robot.contiguous()], None)
-            else:
-                post_in = ops.ConvBias.apply(h, None, q.weight, q.bias, ACT_NONE, frozen)
+            if post_in is None:
+                if cf.model_use_robot_state:
+                    post_in = self._embed(q, [next_robot.contiguous()], h, None)
+                else:
+                    post_in = ops.ConvBias.apply(h, None, q.weight, q.bias, ACT_NONE, frozen)
             z_t, mu, logvar = self.posterior(post_in, self._eps)
             if not force_use_prior:
                 z = z_t
         f = self.frame_pred_input_conv
-        frame_in = embed(f, [v for v in (a, r, r_next) if v is not None], z)
+        frame_in = self._embed(f, [v for v in (a, r, r_next) if v is not None], h, z)
         h_pred = self.frame_predictor(frame_in)
         return h_pred, mu, logvar, mu_p, logvar_p
