@@ -234,8 +234,20 @@ class _GaussianConvLSTM(_ConvLSTM):
         self.logvar_net = _Conv(g, z, 3)
         self._head = None  # (weight, bias) views over both heads, adjacent in the flat buffer (SVGConvModel._flatten)
 
-    def forward(self, x, eps_fn, need_z=True):
+    def forward(self, x, eps_fn, need_z=True, defer_head=False):
+        """`defer_head`: only step the ConvLSTM and draw (and drop) this step's noise in the reference's order; returns
+        (None, h, None) -- the caller applies `heads` to the hidden states of all time steps at once."""
         h = super().forward(x)
+        if defer_head:
+            if need_z:
+                eps_fn(h[..., :self.mu_net.weight.shape[0]])  # the draw z = eps * sigma + mu would have consumed
+            return None, h, None
+        mu, logvar = self.heads(h)
+        z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
+        return z, mu, logvar
+
+    def heads(self, h):
+        """mu, logvar = mu_net(h), logvar_net(h) (lstm.py:273-274)."""
         head = self._head
         if head is not None and ops.gauss_head_ok(h.shape, head[0]):
             for t in head:  # the views follow the parameters they alias
@@ -246,8 +258,7 @@ class _GaussianConvLSTM(_ConvLSTM):
             frozen = not torch.is_grad_enabled()
             mu = ops.ConvBias.apply(h, None, self.mu_net.weight, self.mu_net.bias, ACT_NONE, frozen)
             logvar = ops.ConvBias.apply(h, None, self.logvar_net.weight, self.logvar_net.bias, ACT_NONE, frozen)
-        z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
-        return z, mu, logvar
+        return mu, logvar
 
 
 class SVGConvModel(nn.Module):
@@ -460,14 +471,18 @@ class SVGConvModel(nn.Module):
         prior_steps, post_steps = steps_of(prior_all), steps_of(post_all)
         h_preds, mus, logvars, mu_ps, logvar_ps = [], [], [], [], []
         for t in range(T):
-            h_pred, mu, logvar, mu_p, logvar_p = self._recur(h_steps[t], robots[t], actions[t], True, next_robots[t],
-                                                             False, False, prior_in=prior_steps[t],
-                                                             post_in=post_steps[t])
+            # the prior's z is never used on this path (the posterior's drives the frame predictor): its mu / logvar heads
+            # only feed the KL term, so they too run once over all steps' hidden states, after the loop
+            h_pred, mu, logvar, h_prior, _ = self._recur(h_steps[t], robots[t], actions[t], True, next_robots[t],
+                                                         False, False, prior_in=prior_steps[t], post_in=post_steps[t],
+                                                         defer_prior_head=True)
             h_preds.append(h_pred)
             mus.append(mu)
             logvars.append(logvar)
-            mu_ps.append(mu_p)
-            logvar_ps.append(logvar_p)
+            mu_ps.append(h_prior)
+        mu_p_all, logvar_p_all = self.prior.heads(torch.cat(mu_ps, 0))
+        mu_ps = list(mu_p_all.view((T, B) + tuple(mu_p_all.shape[1:])).unbind(0))
+        logvar_ps = list(logvar_p_all.view((T, B) + tuple(logvar_p_all.shape[1:])).unbind(0))
         x4 = self.decoder(torch.cat(h_preds, 0), skips, T)
         return x4, mus, logvars, mu_ps, logvar_ps
 
@@ -509,9 +524,11 @@ class SVGConvModel(nn.Module):
         return ops.ConvBias.apply(ops.TileCat.apply(vs3[0], vs3[1], vs3[2], h, z, frozen), None, conv.weight,
                                   conv.bias, ACT_NONE, frozen)
 
-    def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean, prior_in=None, post_in=None):
+    def _recur(self, h, robot, action, posterior, next_robot, force_use_prior, sample_mean, prior_in=None, post_in=None,
+               defer_prior_head=False):
         """The stepped part of `forward`: prior / posterior / frame predictor on one time step's latent.
-        `prior_in` / `post_in`: the two input convs' outputs when the caller ran them for all time steps at once."""
+        `prior_in` / `post_in`: the two input convs' outputs when the caller ran them for all time steps at once;
+        `defer_prior_head` (posterior given, its z used): mu_p comes back as the prior's hidden state, logvar_p as None."""
         cf = self._config
         a = action.contiguous()
         r = r_next = None
@@ -524,7 +541,8 @@ class SVGConvModel(nn.Module):
         frozen = not torch.is_grad_enabled()
         if prior_in is None:
             prior_in = self._embed(self.prior_input_conv, [v for v in (a, r, r_next) if v is not None], h, None)
-        z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean)
+        defer = defer_prior_head and posterior and not force_use_prior
+        z_p, mu_p, logvar_p = self.prior(prior_in, self._eps, need_z=not sample_mean, defer_head=defer)
         z = mu_p if sample_mean else z_p
         mu = logvar = None
         if posterior:
