@@ -356,7 +356,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     // weights two steps ahead in three register sets.  (Measured alternatives, M = 1024 / 64 000 gate GEMM: A fragments
     // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; skipping
     // the MFMAs of row blocks that are all padding for a tap (10 % of a 5x5 conv on 8x8 maps) through three step
-    // variants: spills, 188 / 228 TF; this form 437 / 477.)
+    // variants: spills, 188 / 228 TF; this form 437 / 477.  Round 3: s_setprio 1 / 3 around the MFMA block: 491 / 490 TF
+    // against 492 at M = 64 000, 435-446 either way at M = 1024 -- nothing.)
     u32x4 b0[4 * NT], b1[4 * NT], b2[4 * NT];
     issue_a(cc);
     load_b(b0, kc_begin);
