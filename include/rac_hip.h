@@ -324,6 +324,13 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
                         const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax,
                         int32_t amax_per_image, int32_t B, int32_t H, int32_t W, int32_t Cout, void* stream);
 /* amax_per_image: out_amax is an array of B zeroed slots, one per image */
+/* The output head, ConvTranspose2d(64 -> 4, 3, 1, 1) + bias + Sigmoid (vgg_64.py:218-220), forward, as exact-fp32 FMAs
+ * (a GEMM with N = 4 wastes the matrix pipe):
+ *   y[b][p][c] = sigmoid(bias[c] + sum_{ky, kx, ci} x[b][p - (ky - 1, kx - 1)][ci] * w_taps[ky][kx][ci][c])
+ * x NHWC [B][H][W][64], y NHWC [B][H][W][4]; w_taps = the (64, 4, 3, 3) ConvTranspose parameter re-ordered to
+ * [3][3][64][4].  H % 8 == 0, W % 32 == 0.  A fixed order of sums per pixel: the result does not depend on the batch. */
+int rac_head_fwd(const float* x, const float* w_taps, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
+                 void* stream);
 /* parts[i][w][ky][kx][t] = sum over the pixels of workgroup i's 16 x 16 tiles of wide[p][w] * thin[p + (ky - 1, kx - 1)][t]:
  * the weight gradient of a 3x3 conv between a 64-channel NHWC tensor and a thin one (Ct <= 8 channels, row stride
  * thin_stride >= Ct: the packed frame carries pad channels), as n_parts partial sums of 64 * 9 * Ct floats each that

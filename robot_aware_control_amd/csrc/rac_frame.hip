@@ -117,6 +117,63 @@ __global__ __launch_bounds__(256) void first_layer_kernel(const float* img, cons
   if (amax) amax_commit_block(mx, per_image ? amax + b : amax);
 }
 
+// Output head: ConvTranspose2d(64 -> 4, 3, 1, 1) + bias + Sigmoid (vgg_64.py:218-220) as exact-fp32 FMAs.
+//   y[p][c] = sigmoid(bias[c] + sum_{ky, kx, ci} x[p - (ky - 1, kx - 1)][ci] * w[ky][kx][ci][c])
+// On the matrix pipe this layer is a GEMM with N = 4: the 32-column tile of conv16_rows_kernel spends 7/8 of its MFMAs
+// on padding and a whole tile's staging (halo, fp32 -> fp16 parts, barriers) on 18 K steps: 0.86-1.06 ms per 4 M pixels
+// (0.02 of the pipe), against an HBM floor of 0.17 ms (1.05 GB in) and 0.27 ms of plain VALU time for its 9.4 G FMAs.
+// Here: a workgroup owns an 8 x 32 pixel tile, one thread per pixel, 4 accumulators; the haloed input tile goes through
+// LDS in two 32-channel halves ([pixel][36 floats]: a 144-byte pixel stride spreads the 8 lanes of a ds_read_b128 pass
+// over all banks), every LDS vector feeds 16 FMAs, and the weights never touch LDS or VGPRs -- they are wave-uniform, so
+// the compiler fetches them with scalar loads and the FMAs take them as SGPR operands.  LDS traffic 9 x the tile
+// (2.3 KB per pixel, 9.4 GB per launch at 4 M pixels: ~0.16 ms), VALU 2304 FMAs per pixel: VALU-bound at ~0.3 ms.
+// Exact fp32 (no operand split), a fixed order of sums per pixel: batch-invariant like the rest of the frozen path.
+__global__ __launch_bounds__(256) void head_direct_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int H,
+                                                          int W) {
+  constexpr int TR = 8, TC = 32, PR = TR + 2, PC = TC + 2, CS = 36;
+  __shared__ __attribute__((aligned(16))) float xs[PR * PC * CS];
+  const int tid = threadIdx.x;
+  const int py = tid >> 5, px = tid & 31;
+  const int tiles_x = W / TC;
+  const int b = blockIdx.y, ty0 = (blockIdx.x / tiles_x) * TR, tx0 = (blockIdx.x % tiles_x) * TC;
+  const float* xb = x + (long)b * H * W * 64;
+  float acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = bias[c];
+  for (int half = 0; half < 2; ++half) {
+    if (half) __syncthreads();
+    for (int i = tid; i < PR * PC * 8; i += 256) {
+      const int pix = i >> 3, q = i & 7;
+      const int row = pix / PC, col = pix - row * PC;
+      const int gy = ty0 + row - 1, gx = tx0 + col - 1;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+        v = *reinterpret_cast<const f32x4*>(xb + ((long)gy * W + gx) * 64 + half * 32 + q * 4);
+      *reinterpret_cast<f32x4*>(xs + pix * CS + q * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const float* xp = xs + ((py + 2 - ky) * PC + (px + 2 - kx)) * CS;
+      const float* wp = wt + (tap * 64 + half * 32) * 4;  // wave-uniform: scalar loads
+#pragma unroll
+      for (int c4 = 0; c4 < 8; ++c4) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + c4 * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += xv[j] * wp[(c4 * 4 + j) * 4 + c];
+      }
+    }
+  }
+  f32x4 out;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[c] = sigmoid_acc(acc[c]);
+  *reinterpret_cast<f32x4*>(y + (((long)b * H + ty0 + py) * W + tx0 + px) * 4) = out;
+}
+
 // Weight gradient of a 3x3 conv between a wide (64-channel) and a thin (<= 8-channel) NHWC tensor:
 //   out[w][tap][t] += sum_p wide[p][w] * thin[p + tap - (1, 1)][t]
 // = the first encoder layer's dW (wide = dy, thin = the packed frame: vgg_64.py:8-18 backward) and the output head's
@@ -504,6 +561,15 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
   hipLaunchKernelGGL(fns[Cm], grid, dim3(256), 0, ST(stream), img, zmask, mask, w, scale, shift, act, out, out_amax,
                      amax_per_image ? 1 : 0, H, W);
   return check_launch("rac_first_layer_fwd");
+}
+
+int rac_head_fwd(const float* x, const float* w_taps, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
+                 void* stream) {
+  RAC_REQUIRE(x && w_taps && bias && y && B > 0 && H > 0 && W > 0, "rac_head_fwd: bad args");
+  RAC_REQUIRE(H % 8 == 0 && W % 32 == 0 && aligned16(x) && aligned16(y) && aligned16(w_taps),
+              "rac_head_fwd: H % 8 == 0, W % 32 == 0, 16-byte aligned buffers");
+  hipLaunchKernelGGL(head_direct_kernel, dim3((H / 8) * (W / 32), B), dim3(256), 0, ST(stream), x, w_taps, bias, y, H, W);
+  return check_launch("rac_head_fwd");
 }
 
 int rac_thin_wgrad(const float* wide, const float* thin, int32_t thin_stride, int32_t Ct, float* parts, int32_t n_parts,

@@ -313,6 +313,7 @@ def _flush_bias_grads():
 # accumulation.  RAC_SPLIT_GEMM=0 keeps every conv on the exact-fp32 MFMA path (rac_conv2d).
 SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = SPLIT_GEMM
+HEAD_DIRECT = os.environ.get("RAC_HEAD_DIRECT", "1") == "1"  # the 64 -> 4 output head as FMAs (rac_head_fwd)
 # narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "64"))
@@ -1103,7 +1104,12 @@ class ConvTHead(torch.autograd.Function):
         assert Ci == Ciw
         weight_mem(weight)
         y = torch.empty((B, H, W, Cow), device=x.device, dtype=torch.float32)
-        if SPLIT_GEMM and Cow <= 32 and split_supported(H, W, k, Ciw, 32):
+        if HEAD_DIRECT and x.is_cuda and (Ciw, Cow, k) == (64, 4, 3) and H % 8 == 0 and W % 32 == 0:
+            # exact-fp32 FMAs, weights as scalar operands (rac_head_fwd): N = 4 is no shape for the matrix pipe
+            wt = _derived(weight, "_rac_head_taps", lambda: weight.detach().permute(2, 3, 0, 1).contiguous())
+            x = x if x.is_contiguous() else x.contiguous()
+            call("rac_head_fwd", ptr(x), ptr(wt), ptr(bias), ptr(y), B, H, W, stream_ptr())
+        elif SPLIT_GEMM and Cow <= 32 and split_supported(H, W, k, Ciw, 32):
             # the transposed-conv forward IS a data gradient: forward conv with the (Cow, Ciw) tap-flipped weight, its
             # Cow rows zero-padded to one 32-column tile; only the Cow real columns are computed into y
             pw, wslot = weight_parts(padded_weight(weight, 32), transposed=True)

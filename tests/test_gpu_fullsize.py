@@ -100,6 +100,26 @@ def test_train_step_cfg5_shard(dev):
     print(f"cfg5 shard: {n} of {total} selections differ (max |pre|/rms {worst:.1e}); worst gradient error {worst_grad:.1e}")
 
 
+def test_train_step_cfg5_per_gpu_size(dev):
+    """BASELINE configs[4] exactly as one GPU of the 8 sees it and as `bench.py --cfg5` times it: 128x128 frames, 8
+    samples, n_past 1 + n_future 10 (a 10-step BPTT window on 16x16 latent maps), g 512 / z 64, robot-aware flags.
+    Losses <= 1e-4; every parameter's gradient <= 1e-4 norm-wise with the selections agreed."""
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=8, n_past=1, n_future=10, lr=1e-4, image_height=128, image_width=128,
+                  **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=27, randomize_bn_stats=False)
+    data = syn.synth_video(seed=28, T=11, B=8, H=128, W=128)
+    eps = syn.synth_eps(seed=29, steps=10, B=8, z=64, h=16, w=16)
+    tr = make_trainer(cfg, sd, dev)
+    tr.optimizer.step = lambda: None
+    ts = orc.TrainState.create(cfg, sd)
+    got, ref, flips = forced_step(tr, ts, data, eps, 8)
+    for k in ref:
+        np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, err_msg=k)
+    n, total, worst = check_flips(flips)
+    worst_grad = check_grads(tr, ts)
+    print(f"cfg5 per-GPU size: {n} of {total} selections differ (max |pre|/rms {worst:.1e}); worst gradient error {worst_grad:.1e}")
+
+
 def test_train_step_group_norm_g256_forced(dev):
     """`--lstm_group_norm True` at the width of the authors' deployed checkpoints (g 256 / z 64,
     evaluate_checkpoint.py:40-46): NormConvLSTMCell -- separate ih / hh gate convs, GroupNorm(16) on both and on the cell
