@@ -118,7 +118,7 @@ def test_convT_head(dev, B, H, W, Ci, monkeypatch):
     assert relerr(from_map(y), y_ref.detach()) < 1e-5
     if Ci == 64:  # the direct kernel: exact fp32 against fp64, and the matrix-pipe form next to it
         y64 = torch.sigmoid(F.conv_transpose2d(x.detach().double(), w.detach().double(), b.detach().double(), 1, 1))
-        assert relerr(from_map(y), y64) < 5e-7
+        assert relerr(from_map(y), y64) < 2e-6
         monkeypatch.setattr(ops, "HEAD_DIRECT", False)
         y_mfma = ops.ConvTHead.apply(xd.detach(), wd.detach(), bd.detach())
         monkeypatch.setattr(ops, "HEAD_DIRECT", True)
