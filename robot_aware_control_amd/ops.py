@@ -134,7 +134,19 @@ def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> in
     cap = max(1, nchunks // 8)  # keep >= 8 chunks per split: the pipeline prologue/epilogue must amortise
     if tile128_only:  # the split-precision kernel has one tile shape
         t128 = _cdiv(M, 128) * _cdiv(N, 128)
-        return 1 if t128 >= 384 else max(1, min(8, _cdiv(512, t128), cap))
+        if t128 >= 384:
+            return 1
+        # 512 workgroups run at a time (2 per CU): the split whose LAST round is fullest, a little cheaper the smaller it
+        # is (each split is one more slab to write and combine).  Measured on the M = 5120 / 20 480 vgg shapes: 160 tiles
+        # x 3 = 480 workgroups 78 us against 88 (x 4 = 640: a quarter-full second round) and 97 (x 2); 320 tiles x 3 = 960
+        # 89 us against 98 (x 1: half the slots idle) and 96 (x 4); the gate GEMMs keep 128 x 4 and 64 x 8 = 512.
+        best, best_eff = 1, -1.0
+        for s in range(1, min(8, cap) + 1):
+            rounds = t128 * s / 512.0
+            eff = (rounds / -(-rounds // 1) if rounds > 1 else rounds) * (1.0 - 0.03 * (s - 1))
+            if eff > best_eff + 1e-9:
+                best, best_eff = s, eff
+        return best
     if N <= 32:
         tiles = _cdiv(M, 128)
         return 1 if tiles >= 384 else max(1, min(8, _cdiv(512, tiles), cap))
