@@ -115,10 +115,12 @@ constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
 // Written without per-element branches: a taken branch costs more than the arithmetic it would skip.
 // `ia_rows` (LDS, per-image scales): 1 / scale of every tile row instead of the one `ia`.  mxb[mb] = max |v| of the
 // lane's values in 16-row block mb (the caller folds them into one slot, or into one slot per image).
+// `ym_hw` (0: off): the tile kernel's y-major row order -- tile row 16 y + 8 i + x holds pixel (y, x) of the tile's image
+// i (W = 8, two images of ym_hw pixels per tile): block mb is image row mb of BOTH images.
 template <int SIG, int MBLK, int NBLK>
 __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0,
                                                      int nmb, int ncol0, float ia, float iw, const float (*pre)[3],
-                                                     const float* ia_rows, unsigned (&mxb)[MBLK]) {
+                                                     const float* ia_rows, unsigned (&mxb)[MBLK], int ym_hw = 0) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int NS = p.n_store;
   const float slope = p.act == RAC_ACT_LEAKY02 ? 0.2f : 1.f;
@@ -145,7 +147,8 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
       if (mb0 + mb >= nmb) continue;  // wave-uniform: past the tile's rows
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + (mb0 + mb) * 16 + 4 * lq + r;
+        const int rl = 4 * lq + r;
+        const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : m0 + (mb0 + mb) * 16 + rl;
         const bool ok = nok & (m < p.M);
         float v = acc[mb][nb][r] * iav[mb][r] * iw + bias;  // two exact steps: ia * iw alone may underflow
         const float vs = ok ? v : 0.f;
@@ -180,7 +183,8 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
 template <int MBLK, int NBLK>
 __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&acc)[MBLK][NBLK], int m0, int mb0, int nmb,
                                                 int ncol0, int bz, float ia, float iw, const float (*pre)[3] = nullptr,
-                                                const float* ia_rows = nullptr, unsigned* out_amax = nullptr) {
+                                                const float* ia_rows = nullptr, unsigned* out_amax = nullptr,
+                                                int ym_hw = 0) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
   const int NS = p.n_store;
   if (p.split_k > 1) {  // raw partial sums: the ConvLSTM cell kernel / rac_slab_reduce adds the slabs
@@ -193,7 +197,8 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
         if (mb0 + mb >= nmb) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = m0 + (mb0 + mb) * 16 + 4 * lq + r;
+          const int rl = 4 * lq + r;
+          const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : m0 + (mb0 + mb) * 16 + rl;
           if ((n < NS) & (m < p.M)) dst[(long)m * NS + n] = acc[mb][nb][r] * ia * iw;
         }
       }
@@ -202,10 +207,19 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
   }
   unsigned mxb[MBLK];
   if (p.act == RAC_ACT_SIGMOID)
-    conv16_epilogue_body<1>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb);
+    conv16_epilogue_body<1>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb, ym_hw);
   else
-    conv16_epilogue_body<0>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb);
+    conv16_epilogue_body<0>(p, acc, m0, mb0, nmb, ncol0, ia, iw, pre, ia_rows, mxb, ym_hw);
   if (!out_amax) return;
+  if (ia_rows && ym_hw) {  // y-major tile, one slot per image: lanes with lq < 2 hold image 0's rows, the others image 1's
+    unsigned mx = 0;
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb) mx = max(mx, mxb[mb]);
+    const int img0 = m0 / ym_hw;
+    amax_commit(lq < 2 ? mx : 0u, out_amax + img0);
+    if (m0 + ym_hw < p.M) amax_commit(lq >= 2 ? mx : 0u, out_amax + img0 + 1);
+    return;
+  }
   if (!ia_rows) {  // one slot for everything this wave wrote
     unsigned mx = 0;
 #pragma unroll
@@ -232,7 +246,12 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
 // WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
 // columns (half the LDS fragment reads and tap-shift selects per MFMA, twice the weight loads per wave).
 // FULL: the tile is 128 rows (8x8 / 4x8 / ... maps): no per-block liveness tests inside the loop.
-template <int WM, bool FULL>
+// YM: y-major tile rows (W = 8, two images per tile): LDS / accumulator row 16 y + 8 i + x = pixel (y, x) of image i, so a
+// 16-row block is ONE image row of both images and a vertical tap that leaves the image leaves it for the whole block:
+// the block's fragment reads and MFMAs are skipped -- 15 % of a 5x5 conv's products on 8-row maps (image rows 0, 1, 6, 7
+// lose 2, 1, 1, 2 of their 5 kernel rows), 8 % of a 3x3 conv's -- instead of multiplying zero rows.  A tap's shift
+// stays one wave-uniform offset (16 rows per image row); the epilogue maps rows back to the tensor's (image, y, x) order.
+template <int WM, bool FULL, bool YM = false>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;   // waves along the columns
   constexpr int RB = 8 / WM;   // 16-row blocks per wave
@@ -260,13 +279,15 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
+  // the LDS row of the staged pixel: its tile row, or (YM) 16 y + 8 image + x
+  const int lrow = (YM && srow < TM) ? ((srow % p.HW) >> 3) * 16 + (srow / p.HW) * 8 + (srow & 7) : srow;
   __shared__ float ia_sh[128];  // per-image scales: 1 / scale of every tile row's image
   unsigned am;
   if (p.per_image) {  // the scale of the image this thread's staged row belongs to
     const int img = min((m0 + srow) / p.HW, p.B - 1);
     am = p.a_amax0[img];
     if (p.a_amax1) am = max(am, p.a_amax1[img]);
-    ia_sh[srow] = pow2f(-scale_exp(am));
+    ia_sh[lrow] = pow2f(-scale_exp(am));
   } else {
     am = *p.a_amax0;
     if (p.a_amax1) am = max(am, *p.a_amax1);
@@ -287,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     const int r = (wm * RB + t) * 16 + lr;
     const int im = r / p.HW;
     const int q = r - im * p.HW;
-    const int y = q / p.W, x = q - y * p.W;
+    // (YM: block t is image row wm * RB + t, the lane's pixel is x = lr & 7 of it)
+    const int y = YM ? wm * RB + t : q / p.W, x = YM ? (lr & 7) : q - (q / p.W) * p.W;
     unsigned mk = 0;
     for (int tp = 0; tp < p.taps; ++tp) {
       const int yy = y + tp / p.ks - p.pad, xx = x + tp % p.ks - p.pad;
@@ -337,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       split8h(ra[2 * i], ra[2 * i + 1], sa, q);
 #pragma unroll
       for (int part = 0; part < 2; ++part)
-        *reinterpret_cast<u32x4*>(lds_raw + buf * T16_ABUF + part * T16_PP + (sch + 2 * i) * T16_CP + srow * 16) = q[part];
+        *reinterpret_cast<u32x4*>(lds_raw + buf * T16_ABUF + part * T16_PP + (sch + 2 * i) * T16_CP + lrow * 16) = q[part];
     }
   };
 
@@ -370,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
-      const int drow = (ky - p.pad) * p.W + (kx - p.pad);
+      const int drow = (ky - p.pad) * (YM ? 16 : p.W) + (kx - p.pad);
       const int shift = drow * 16 + cur * T16_ABUF + abase;
       // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
       // would have used, so that the read group stays conflict-free
@@ -391,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
           if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
+          if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;  // the tap leaves the image: no work
           const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
 #pragma unroll
           for (int part = 0; part < 2; ++part)
@@ -401,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             if (!FULL && wm * RB + 4 * h + t >= nmb) continue;
+            if (YM && (unsigned)(wm * RB + 4 * h + t + ky - p.pad) >= (unsigned)p.H) continue;
             acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
           }
       }
@@ -432,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 
   if (p.per_image) __syncthreads();  // ia_sh (a workgroup with an empty K range has not passed a barrier yet)
   conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), nullptr,
-                  p.per_image ? ia_sh : nullptr, p.out_amax);
+                  p.per_image ? ia_sh : nullptr, p.out_amax, YM ? p.HW : 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1907,10 +1931,12 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
   constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
   // waves 2 x 2 (template argument 2); the 1 x 4 arrangement of the same kernel measured 10 % slower
-  if (p.tile_m == 128)
-    hipLaunchKernelGGL((conv16_tile_kernel<2, true>), grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
-  else
-    hipLaunchKernelGGL((conv16_tile_kernel<2, false>), grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
+  static const char* noym = getenv("RAC_TILE_YMAJOR");
+  const bool ym = a->W == 8 && p.tile_m == 2 * p.HW && !(noym && atoi(noym) == 0);  // 8x8 / 6x8 maps: skip vertical padding
+  typedef void (*tile_fn)(Conv16P);
+  const tile_fn fn = p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true> : (tile_fn)conv16_tile_kernel<2, true>)
+                                     : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
 }
 
