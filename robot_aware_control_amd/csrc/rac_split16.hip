@@ -440,6 +440,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       ky = last_tap ? 0 : (kx == 0 ? ky + 1 : ky);
     };
 
+    // Round 3, timing builds at M = 64 000 / 1024 (wrong results, what each stream costs): this loop 508 / 433 TF; the
+    // weight operands loaded once 585 / 497 (+15 %); no fragment reads from LDS 617 / 513 (+21 %); 15 % of the MFMAs
+    // skipped (YM) +3..5 %: no single stream bounds it -- issue slots and the latencies of both operand paths share it.
     for (int kc = kc_begin; kc < kc_end; kc += 3) {
       load_b(b2, kc + 2);
       step(b0, kc);
