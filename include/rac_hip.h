@@ -152,6 +152,17 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
  * rows zero-padded to the next multiple of 32; only Cout columns are computed into the output (row stride Cout). */
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
                          int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
+/* The FROZEN model's ConvLSTM cell in one launch (lstm.py:129-149 without a tape): the gate conv of
+ * rac_conv2d_fwd_split with the cell arithmetic in its epilogue,
+ *   (i, f, o, g) = conv([a0 | a1]) + bias;  c = sig(f) c_prev + sig(i) tanh(g);  h = sig(o) tanh(c),
+ * so the [M][4g] gate tensor is never written.  a->w: parts of the gate weight with its 4g ROWS GATE-INTERLEAVED in groups
+ * of 16 channels -- row 64 (c / 16) + 16 gate + c % 16 holds gate `gate` (0 i, 1 f, 2 o, 3 g) of channel c; a->bias: the
+ * gate bias in the ORIGINAL order [4][g]; a->Cout = 4g (% 64 == 0), split_k 1, a map that fits a tile (H*W <= 128);
+ * a->out0 unused.  c_prev / h_out / c_out: [M][g].  Transcendentals to ~1e-7 absolute (v_exp_f32 with an FMA-recovered
+ * argument error), not libm's: results agree with rac_lstm_cell_fwd to that level, not to the bit. */
+int rac_convlstm_cell_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
+                                int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, const float* c_prev,
+                                float* h_out, float* c_out, void* stream);
 /* w_cin (0 = a->Cin): input channels the weight parts were built with.  a->Cin < w_cin runs the conv over the first
  * a->Cin input channels only (a channel prefix is a prefix of every tile's weight stream): the ConvLSTM cells' first
  * step, whose hidden state is all zeros, skips the hidden half of K (and of the data gradient's N, through a->Cout). */

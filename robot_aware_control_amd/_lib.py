@@ -81,6 +81,7 @@ _SIGS = {
     "rac_weight_frag_split_multi": [vp, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp],
+    "rac_convlstm_cell_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
     "rac_split_steps": [C.POINTER(vp), C.POINTER(vp), i32, i64, C.POINTER(vp), i32, vp],
     "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],

@@ -100,6 +100,11 @@ struct Conv16P {
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
   int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
   int a0_up;      // rows kernel: a0 is the half-resolution tensor, read at (y / 2, x / 2) (nearest 2x upsampling)
+  // frozen ConvLSTM cell in the epilogue (tile kernel only): the weight rows are gate-interleaved in groups of 16 channels
+  // (column 64 (c / 16) + 16 gate + c % 16), so a lane holds the four gates of one channel; out0 is not written
+  const float* lstm_c_prev;
+  float *lstm_h, *lstm_c;
+  int lstm_g;
   int per_image;  // a_amax0 / a_amax1 / out_amax are arrays of B slots, one per image: every image is scaled by its OWN
                   // maximum, so its result cannot depend on what else is in the batch (the frozen model's rollouts)
 };
@@ -241,6 +246,49 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
     mx = max(mx, mxb[mb]);
   }
   if (cur >= 0) amax_commit(mx, out_amax + cur);
+}
+
+// e^x to ~1e-7 relative for |x| < 80 in 6 instructions: v_exp_f32 on x log2(e) with the product's rounding error (an
+// FMA recovers it exactly) and log2(e)'s own carried into a first-order correction.  libm's expf / tanhf cost an order of
+// magnitude more -- enough to lose 2 % of a planner iteration when the cell sat in the GEMM epilogue (round 2).
+__device__ __forceinline__ float exp_fast(float x) {
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.92596299112661746e-8f;
+  const float t = x * L2E_HI;
+  const float e = __builtin_fmaf(x, L2E_HI, -t) + x * L2E_LO;
+  return __builtin_amdgcn_exp2f(t) * __builtin_fmaf(e, 0.693147182464599609375f, 1.0f);
+}
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+// 1 - 2 / (1 + e^2x): absolute error ~1e-7 everywhere (what a gate activation needs: it multiplies O(1) states)
+__device__ __forceinline__ float tanh_fast(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + exp_fast(2.0f * x)); }
+
+// ConvLSTM cell of the FROZEN model in the gate conv's epilogue (lstm.py:136-149): the 4g-wide gate tensor (524 MB per
+// planner step at 1000 candidates) is never written and read back, and the separate cell launch disappears.  The wave's
+// four 16-column blocks are the i, f, o, g gates of 16 channels (gate-interleaved weight rows).
+template <int MBLK>
+__device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32x4 (&acc)[MBLK][4], int m0, int mb0, int nmb,
+                                                     int ncol0, float ia, float iw, const float* ia_rows, int ym_hw) {
+  const int lane = threadIdx.x & 63, lr = lane & 15, lq = lane >> 4;
+  const int g = p.lstm_g;
+  const int c = (ncol0 >> 6) * 16 + lr;
+  if (c >= g) return;
+  const float bi = p.bias[c], bf = p.bias[g + c], bo = p.bias[2 * g + c], bg = p.bias[3 * g + c];
+#pragma unroll
+  for (int mb = 0; mb < MBLK; ++mb) {
+    if (mb0 + mb >= nmb) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = 4 * lq + r;
+      const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : m0 + (mb0 + mb) * 16 + rl;
+      if (m >= p.M) continue;
+      const float s = ia_rows ? ia_rows[(mb0 + mb) * 16 + rl] : ia;
+      const float gi = sigmoid_fast(acc[mb][0][r] * s * iw + bi), gf = sigmoid_fast(acc[mb][1][r] * s * iw + bf);
+      const float go = sigmoid_fast(acc[mb][2][r] * s * iw + bo), gg = tanh_fast(acc[mb][3][r] * s * iw + bg);
+      const long i = (long)m * g + c;
+      const float cn = gf * p.lstm_c_prev[i] + gi * gg;
+      p.lstm_c[i] = cn;
+      p.lstm_h[i] = go * tanh_fast(cn);
+    }
+  }
 }
 
 // WM = waves along the rows: 1 -> waves 1 x 4, each all 128 rows x 32 columns; 2 -> waves 2 x 2, each 64 rows x 64
@@ -458,6 +506,13 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   }
 
   if (p.per_image) __syncthreads();  // ia_sh (a workgroup with an empty K range has not passed a barrier yet)
+  if constexpr (WM == 2) {
+    if (p.lstm_h) {
+      conv16_lstm_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, pow2f(-ka), pow2f(-kw),
+                           p.per_image ? ia_sh : nullptr, YM ? p.HW : 0);
+      return;
+    }
+  }
   conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), nullptr,
                   p.per_image ? ia_sh : nullptr, p.out_amax, YM ? p.HW : 0);
 }
@@ -1807,11 +1862,12 @@ extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, i
   return tm && (tm + 2 * (ksize / 2) * W) * 4 <= 1024;
 }
 
-extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
-                                    int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax,
-                                    void* stream) {
+static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1, int64_t w_part_stride,
+                         int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax, const float* lstm_c_prev, float* lstm_h,
+                         float* lstm_c, void* stream) {
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
-  RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && a->out0 && a_amax0 && w_amax,
+  RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && (a->out0 || lstm_h) && a_amax0 &&
+                  w_amax,
               "rac_conv2d_fwd_split: bad args");
   const int a_split = (a->a1 && a->a_split > 0 && a->a_split < a->Cin) ? a->a_split : a->Cin;
   const int n_rows = (a->Cout + 31) / 32 * 32;  // weight rows: Cout zero-padded to whole 32-column tiles
@@ -1839,6 +1895,9 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
   p.per_image = a->amax_per_image ? 1 : 0;
   RAC_REQUIRE(!p.per_image || (p.split_k == 1 && (p.HW > 128 || p.HW % 16 == 0)),
               "rac_conv2d_fwd_split: amax_per_image needs split_k 1 and H*W a multiple of 16");
+  p.lstm_c_prev = lstm_c_prev, p.lstm_h = lstm_h, p.lstm_c = lstm_c, p.lstm_g = a->Cout / 4;
+  RAC_REQUIRE(!lstm_h || (lstm_c_prev && lstm_c && a->bias && p.split_k == 1 && p.HW <= 128 && a->Cout % 64 == 0),
+              "rac_convlstm_cell_fwd_split: needs c_prev / h / c / bias, split_k 1, a map that fits a tile, 4g % 64 == 0");
   RAC_REQUIRE(!p.a0_up || (p.HW > 128 && a->H % 2 == 0 && a->W % 2 == 0),
               "rac_conv2d_fwd_split: a0_up needs even H, W and a map larger than a 128-pixel tile");
   RAC_REQUIRE(aligned16(a->a0) && aligned16(a->w) && (!a->a1 || aligned16(a->a1)), "rac_conv2d_fwd_split: alignment");
@@ -1941,6 +2000,19 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
                                      : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
+}
+
+extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
+                                    int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax,
+                                    void* stream) {
+  return conv16_launch(a, a_amax0, a_amax1, w_part_stride, w_cin, w_amax, out_amax, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int rac_convlstm_cell_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
+                                           int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, const float* c_prev,
+                                           float* h_out, float* c_out, void* stream) {
+  RAC_REQUIRE(c_prev && h_out && c_out, "rac_convlstm_cell_fwd_split: null state pointer");
+  return conv16_launch(a, a_amax0, a_amax1, w_part_stride, w_cin, w_amax, nullptr, c_prev, h_out, c_out, stream);
 }
 
 extern "C" int rac_split_steps(const float* const* xs, uint16_t* const* parts, int32_t T, int64_t n,

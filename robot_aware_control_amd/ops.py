@@ -753,6 +753,60 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     return tag_amax(out, slot)
 
 
+# The frozen model's ConvLSTM cell in ONE launch: gate conv + cell arithmetic in its epilogue (rac_convlstm_cell_fwd_split)
+FUSED_CELL = os.environ.get("RAC_FUSED_CELL", "1") == "1"
+
+
+def fused_cell_ok(x, weight) -> bool:
+    B, H, W, g = x.shape
+    return (FUSED_CELL and SPLIT_GEMM and H * W <= 128 and (H * W) % 16 == 0 and g % 16 == 0
+            and tuple(weight.shape[:2]) == (4 * g, 2 * g) and split_supported(H, W, weight.shape[2], 2 * g, 4 * g, g))
+
+
+def convlstm_cell_frozen(x, h_prev, c_prev, weight, bias):
+    """(h, c) of a ConvLSTM cell without a tape (lstm.py:129-149): the gate conv over [x | h_prev] with per-image operand
+    scales and the cell arithmetic in its epilogue, against a cached copy of the gate weight whose rows are
+    gate-interleaved in groups of 16 channels (a lane of the matrix-pipe tile then holds i, f, o, g of one channel).  The
+    [B, H, W, 4g] gate tensor is never written."""
+    B, H, W, g = x.shape
+    k = weight.shape[2]
+
+    def build():
+        w = weight.detach()
+        wp = w.reshape(4, g // 16, 16, 2 * g, k, k).permute(1, 0, 2, 3, 4, 5).reshape(4 * g, 2 * g, k, k)
+        return wp.contiguous(memory_format=torch.channels_last)
+    w_perm = _derived(weight, "_rac_gate_interleaved", build)
+    x = x if x.is_contiguous() else x.contiguous()
+    x1, w_cin = h_prev, 0
+    if is_zero(h_prev):  # first step: the hidden half of K is skipped (a channel prefix of the same parts)
+        x1, w_cin = None, 2 * g
+    elif not x1.is_contiguous():
+        x1 = x1.contiguous()
+    Cin = g if x1 is None else 2 * g
+    a0 = amax_for(x, True)
+    a1 = amax_for(x1, True) if x1 is not None else None
+    pw, wslot = weight_parts(w_perm)
+    c_prev = c_prev if c_prev.is_contiguous() else c_prev.contiguous()
+    h, c = torch.empty_like(x), torch.empty_like(x)
+    args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=4 * g, act=ACT_NONE, split_k=1, accumulate=0, a_split=g,
+                    o_split=0, slab_stride=0, a0=ptr(x), a1=ptr(x1), w=ptr(pw), out0=None, out1=None, bias=ptr(bias),
+                    scale=None, shift=None, stats=None, stats_rows=0, a0_up=0, amax_per_image=1)
+    prof = PROFILE
+    timed = prof is not None and prof["match"] == (FWD, k, Cin, 4 * g)
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    if SHAPE_LOG is not None:
+        _log_shape("conv16", FWD, k, B * H * W, 4 * g, Cin * k * k, 2500.0 / 3)
+    call("rac_convlstm_cell_fwd_split", C.byref(args), ptr(a0), ptr(a1), pw.shape[1], w_cin, ptr(wslot), ptr(c_prev),
+         ptr(h), ptr(c), stream_ptr())
+    if timed:
+        e1.record()
+        prof["events"].append((e0, e1, B * H * W))
+        prof["split"] = True
+    return h, c
+
+
 def conv_dgrad_split(dy, weight, C0: int, C1: int = 0, need1: bool = True):
     """Data gradient on the split-precision pipe: forward conv of dy with the transposed, tap-flipped weight.
     `need1` False: only the first C0 input channels' gradient is computed (returns (dx0, None))."""
@@ -1376,6 +1430,8 @@ class LstmCell(torch.autograd.Function):
         need_bwd = grad_mode and any(ctx.needs_input_grad)
         ctx.split = SPLIT_GEMM and split_supported(H, W, weight.shape[2], 2 * g, 4 * g, g)
         frozen = not grad_mode  # no tape: scales per image, K never split (batch-invariant rollouts)
+        if frozen and fused_cell_ok(x, weight):
+            return convlstm_cell_frozen(x, h_prev, c_prev, weight, bias)
         if ctx.split and frozen and not per_image_ok(H, W):
             ctx.split = False
         if ctx.split:

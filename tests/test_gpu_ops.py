@@ -805,3 +805,40 @@ def test_fused_adam_step_writes_the_next_parts(dev):
     assert not ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
     ops.weight_parts(ws[0])
     assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
+
+
+@pytest.mark.parametrize("B,H,W,g,k", [(5, 8, 8, 64, 5), (3, 6, 8, 128, 3), (2, 8, 8, 512, 5)])
+def test_frozen_cell_in_the_gate_conv_epilogue(dev, B, H, W, g, k, monkeypatch):
+    """rac_convlstm_cell_fwd_split (the frozen model's ConvLSTM cell in one launch, gate-interleaved weight rows) against
+    the two-launch form (gate conv slabs + rac_lstm_cell_fwd): same pre-activations to the bit, transcendentals to ~1e-7
+    absolute; against fp64; zero initial state (hidden half of K skipped); batch-invariant to the bit."""
+    from robot_aware_control_amd import ops
+    x = to_map(rnd(81, B, g, H, W), dev)
+    hp = ops.tag_amax(to_map(torch.tanh(rnd(82, B, g, H, W)), dev), ops.amax_one(dev))
+    cp = to_map(rnd(83, B, g, H, W), dev)
+    wt = cl_weight(rnd(84, 4 * g, 2 * g, k, k) * (1.0 / np.sqrt(2 * g * k * k))).to(dev)
+    bias = rnd(85, 4 * g, scale=0.1).to(dev)
+    assert ops.fused_cell_ok(x, wt)
+    with torch.no_grad():
+        h1, c1 = ops.LstmCell.apply(x, hp, cp, wt, bias, False)
+        monkeypatch.setattr(ops, "FUSED_CELL", False)
+        h0, c0 = ops.LstmCell.apply(x, hp, cp, wt, bias, False)
+        monkeypatch.setattr(ops, "FUSED_CELL", True)
+    assert float((h1 - h0).abs().max()) < 6e-7 and float((c1 - c0).abs().max()) < 6e-7 * max(1.0, float(c0.abs().max()))
+    gates = F.conv2d(torch.cat([from_map(x), from_map(hp)], 1).double(), wt.cpu().double(), bias.cpu().double(), 1, k // 2)
+    i, f, o, gg = gates.chunk(4, 1)
+    c_ref = torch.sigmoid(f) * from_map(cp).double() + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    assert relerr(from_map(c1), c_ref) < 2e-6 and relerr(from_map(h1), h_ref) < 2e-6
+    with torch.no_grad():
+        sub = ops.LstmCell.apply(x[B - 1:].contiguous(), ops.tag_amax(hp[B - 1:].contiguous(), ops.amax_one(dev)),
+                                 cp[B - 1:].contiguous(), wt, bias, False)
+        assert torch.equal(sub[0], h1[B - 1:]) and torch.equal(sub[1], c1[B - 1:])
+        z0 = torch.zeros_like(x)
+        z0._rac_zero = True
+        ops.tag_amax(z0, ops.amax_one(dev))
+        hz, cz = ops.LstmCell.apply(x, z0, z0, wt, bias, False)
+    gz = F.conv2d(torch.cat([from_map(x), torch.zeros_like(from_map(x))], 1).double(), wt.cpu().double(), bias.cpu().double(), 1, k // 2)
+    i, f, o, gg = gz.chunk(4, 1)
+    cz_ref = torch.sigmoid(i) * torch.tanh(gg)
+    assert relerr(from_map(cz), cz_ref) < 2e-6 and relerr(from_map(hz), torch.sigmoid(o) * torch.tanh(cz_ref)) < 2e-6
