@@ -427,7 +427,11 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; skipping
     // the MFMAs of row blocks that are all padding for a tap (10 % of a 5x5 conv on 8x8 maps) through three step
     // variants: spills, 188 / 228 TF; this form 437 / 477.  Round 3: s_setprio 1 / 3 around the MFMA block: 491 / 490 TF
-    // against 492 at M = 64 000, 435-446 either way at M = 1024 -- nothing.)
+    // against 492 at M = 64 000, 435-446 either way at M = 1024 -- nothing.  Rotating the A fragments through the step in
+    // halves (blocks 2, 3 and then the NEXT tap's blocks 0, 1 requested under the MFMAs of the other half; no registers
+    // added, reads unconditional so that the compiler's lgkmcnt waits stay exact -- behind the YM branches or an EXEC
+    // mask it waits for every read in flight): 479 against 490 TF at M = 64 000, 441 against 455 at M = 1024, 3x3 -4 %:
+    // the other wave of the SIMD already covers a wave's LDS round trip; what is short is issue slots.)
     u32x4 b0[4 * NT], b1[4 * NT], b2[4 * NT];
     issue_a(cc);
     load_b(b0, kc_begin);
