@@ -267,7 +267,8 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
     flags = dict(RA, reward_type="dontcare") if ra else dict(model_use_mask=False, model_use_future_mask=False,
                                                              model_use_robot_state=False, reconstruction_loss="l1")
     cf = namespace(dev, candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
-                   lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic", **flags)
+                   lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic",
+                   cem_shared_start=not args.no_cem_shared_start, **flags)
     model = SVGConvModel(cf)
     model.load_state_dict(syn.synth_state_dict(model, seed=12))
     if exact_of is not None and exact_of["check"] is not None:
@@ -458,6 +459,8 @@ def main():
     ap.add_argument("--exact-steps", type=int, default=5, help="timed train steps of the exact-fp32 comparison run")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-fp32 comparison runs")
     ap.add_argument("--no-cem-ra", action="store_true", help="skip the robot-aware planner workload")
+    ap.add_argument("--no-cem-shared-start", action="store_true",
+                    help="planner step 0: run the encoder on every candidate's copy of the start frame (as the reference does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--h48", action="store_true",
                     help="train workload on 48x64 frames, the reference's default --image_height (not the headline)")
@@ -545,7 +548,11 @@ def main():
                    "config": {"workload": "CEM rollouts, BASELINE configs[2]: 1000 candidates/GPU x horizon 15 "
                                           "(14 model steps), frozen g512/z64 model, 64x64, dense image cost",
                               "candidates": cem["candidates"], "candidates_batch_size": cem["candidates_batch_size"],
-                              "parallelism": f"candidate-shard{world}"},
+                              "parallelism": f"candidate-shard{world}",
+                              # step 0 of a rollout sees the same start frame for every candidate: its encoder pass runs
+                              # once (same bits; 1.4 % of the algorithmic FLOPs, which stay in the numerator as the
+                              # shared second encoder pass of training does).  --no-cem-shared-start: per candidate
+                              "shared_start_frame": not args.no_cem_shared_start},
                    "achieved_tflops_per_gpu": cem["tflops_per_gpu"],
                    "frac_of_split_peak": cem["tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
                    "gate_gemm": gate, "get_action": cem["get_action"]}

@@ -105,6 +105,7 @@ _COMPAT = [("stoch", B, False), ("multiview", B, False)]
 # MI355X additions (not in the reference)
 _NATIVE = [("ddp_bucket_mb", I, 64), ("cem_shard", B, True),
            ("cem_exact_elites", I, 0),  # re-roll the M best candidates of an atlas pass with exactly rendered masks
+           ("cem_shared_start", B, True),  # planner step 0: encode the (shared) start frame once, not per candidate
            ("plot", B, False)]          # write the per-epoch generation GIFs of PredictionTrainer.plot
 
 

@@ -422,10 +422,20 @@ class SVGConvModel(nn.Module):
                 None if logvar is None else v(logvar), v(mu_p), v(logvar_p))
 
     def forward_maps(self, image, mask, robot, heatmap, action, posterior: bool, next_robot=None, skip=None,
-                     force_use_prior=False, sample_mean=False, zero_mask=None):
+                     force_use_prior=False, sample_mean=False, zero_mask=None, shared_frame=False):
         """`forward` on NHWC maps (no layout conversion of the results).  `zero_mask` fuses
-        zero_robot_region(mask, image) (src/utils/image.py:5-19) into the input packing."""
-        h, curr_skip = self._encode(image, mask, heatmap, zero_mask, 2 if posterior else 1, 1)
+        zero_robot_region(mask, image) (src/utils/image.py:5-19) into the input packing.
+        `shared_frame` (frozen model): every sample's frame / mask / heatmap is the same one (a planner's first step,
+        trajectory_sampler.py:131-137): the encoder runs on one image and its maps are copied to the batch -- the same
+        bits, since every image is scaled by its own maximum."""
+        if shared_frame and not self.training and not torch.is_grad_enabled() and image.shape[0] > 1:
+            n = image.shape[0]
+            one = lambda t: None if t is None else t[:1]
+            h, curr_skip = self._encode(one(image), one(mask), one(heatmap), one(zero_mask), 1, 1)
+            h = ops.broadcast_images(h, n)
+            curr_skip = [ops.broadcast_images(s, n) for s in curr_skip]
+        else:
+            h, curr_skip = self._encode(image, mask, heatmap, zero_mask, 2 if posterior else 1, 1)
         if self._config.last_frame_skip or skip is None:
             skip = curr_skip
         h_pred, mu, logvar, mu_p, logvar_p = self._recur(h, robot, action, posterior, next_robot, force_use_prior,

@@ -409,6 +409,19 @@ def amax_for(t: torch.Tensor, per_image: bool = False) -> torch.Tensor:
     return slot
 
 
+def broadcast_images(t: torch.Tensor, n: int) -> torch.Tensor:
+    """A one-image map as n identical images, its per-image maximum carried along (the planner's first step: every
+    candidate starts from the same frame, so the encoder runs once -- an image's result does not depend on its batch)."""
+    out = t.expand(n, *t.shape[1:]).contiguous()
+    slot = amax_tag(t)
+    if slot is not None:
+        if getattr(slot, "_rac_bound1", False):
+            tag_amax(out, amax_one(t.device, n))
+        elif slot.numel() == 1:
+            tag_amax(out, slot.expand(n).contiguous())
+    return out
+
+
 _SPLIT_OK = {}
 
 

@@ -181,6 +181,12 @@ class TrajectorySampler(object):
             curr = start_img.expand(n, -1, -1, -1).contiguous()
             if dontcare_in:
                 curr = ops.ZeroRegion.apply(curr, masks[0, s:e].contiguous())
+            # step 0: every candidate sees the start frame (and the start mask, row 0 of the robot model's answer --
+            # checked, one readback per batch): the encoder runs on one image.  A future mask is the candidate's own.
+            shared0 = (getattr(cfg, "cem_shared_start", True) and not cfg.model_use_future_mask
+                       and not getattr(cfg, "model_use_heatmap", False))
+            if shared0 and (cfg.model_use_mask or dontcare_in):
+                shared0 = bool((masks[0, s:e] == masks[0, s:s + 1]).all())
             for t in range(T):
                 ac = actions_dev[s:e, t].contiguous()
                 mask = masks[t, s:e] if cfg.model_use_mask else None
@@ -189,7 +195,9 @@ class TrajectorySampler(object):
                     mask = torch.cat([mask, masks[t + 1, s:e]], 1)
                 if cfg.model_use_future_robot_state:
                     state = (state, states[t + 1, s:e])
-                x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean)[0]
+                shared = t == 0 and shared0
+                x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean,
+                                        shared_frame=shared)[0]
                 gi = t if t < len(goal_imgs) else -1
                 add = (not cfg.sparse_cost) or t == T - 1
                 nxt = torch.empty_like(curr)

@@ -424,6 +424,37 @@ def test_cem_rollouts_48x64_vs_oracle(dev, ra):
     assert err < 1e-5, err
 
 
+@pytest.mark.parametrize("kind", ["vanilla", "mask_common", "mask_differs"])
+def test_cem_shared_start_frame_is_the_same_bits(dev, kind):
+    """Planner step 0 encodes the shared start frame once (`cem_shared_start`) and copies the maps to the candidates:
+    the same sum_cost bits as encoding it per candidate (an image's result does not depend on its batch); with a
+    robot-model answer whose row-0 masks differ between candidates the planner notices and encodes them all."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    ra = kind != "vanilla"
+    flags = dict(FLAGSETS["vanilla"]) if not ra else dict(model_use_mask=True, model_use_future_mask=False,
+                                                          model_use_robot_state=True, reconstruction_loss="dontcare_l1")
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=2, candidates_batch_size=7, sample_mean=True,
+                  reward_type="dontcare" if ra else "dense", topk=3, **flags)
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=6, N=9, T=3, with_robot=ra, goal_blend=0.15)
+    if kind == "mask_common":
+        prob["masks"][0] = prob["masks"][0, :1]
+    model = build_model(cfg, sd, dev)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    out = {}
+    for shared in (False, True):
+        sampler = TrajectorySampler(ns_for(cfg, dev, cem_shared_start=shared), model,
+                                    robot_model=FakeRobotModel(prob["states"], prob["masks"]) if ra else None)
+        out[shared] = sampler.generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+    assert np.array_equal(out[False], out[True])
+    ref = orc.cem_rollouts(sd, cfg, prob["actions"], prob["start_img"], prob["goal_imgs"], prob["goal_masks"],
+                           prob.get("states"), prob.get("masks"))
+    err = float(np.abs(out[True] - ref["sum_cost"]).max() / np.abs(ref["sum_cost"]).max())
+    assert err < 1e-5, err
+
+
 SWEEP = [
     dict(model_use_mask=True, model_use_future_mask=False, model_use_robot_state=True, model_use_future_robot_state=True,
          reconstruction_loss="dontcare_mse", robot_pixel_weight=0.3),
