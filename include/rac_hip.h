@@ -342,6 +342,13 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
  * [3][3][64][4].  H % 8 == 0, W % 32 == 0.  A fixed order of sums per pixel: the result does not depend on the batch. */
 int rac_head_fwd(const float* x, const float* w_taps, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
                  void* stream);
+/* The same head on the split-precision matrix pipe, as a tap-stacked 1 x 1 conv Z[tap][q][c] = sum_ci w[tap][ci][c] x[q][ci]
+ * (M = 36 rows: weights = the MFMA's A operand, 16 pixels = B, loaded straight from HBM and split in registers) followed by
+ * the shifted sum y[p] = sigmoid(bias + sum_tap Z[tap][p + d_tap]) through LDS: every input element is read, converted and
+ * multiplied once.  x_amax = the rac_absmax slot of x (amax_per_image: B slots, one per image -- the frozen model); the
+ * weight's scale is found in the kernel.  H % 16 == 0, W % 16 == 0. */
+int rac_head_fwd_split(const float* x, const uint32_t* x_amax, int32_t amax_per_image, const float* w_taps,
+                       const float* bias, float* y, int32_t B, int32_t H, int32_t W, void* stream);
 /* parts[i][w][ky][kx][t] = sum over the pixels of workgroup i's 16 x 16 tiles of wide[p][w] * thin[p + (ky - 1, kx - 1)][t]:
  * the weight gradient of a 3x3 conv between a 64-channel NHWC tensor and a thin one (Ct <= 8 channels, row stride
  * thin_stride >= Ct: the packed frame carries pad channels), as n_parts partial sums of 64 * 9 * Ct floats each that

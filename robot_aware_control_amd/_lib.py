@@ -116,6 +116,7 @@ _SIGS = {
     "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],
     "rac_first_layer_fwd": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_head_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "rac_head_fwd_split": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "rac_thin_wgrad": [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp],
     "rac_unpack_grad": [vp, i32, vp, vp, i32, i32, vp],
     "rac_zero_region": [vp, vp, vp, i32, i32, vp],

@@ -522,6 +522,120 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The 64 -> 4 output head (ConvTranspose2d(64, 4, 3, 1, 1) + bias + Sigmoid, vgg_64.py:218-220) on the matrix pipe as a
+// TAP-STACKED 1 x 1 conv followed by a shifted sum:
+//     y[p][c] = sigmoid(bias[c] + sum_tap Z[tap][p + d_tap][c]),    Z[tap][q][c] = sum_ci w[tap][ci][c] x[q][ci].
+// Z is one GEMM with M = 9 taps x 4 channels = 36 rows (3 blocks of 16), K = 64, N = the pixels of a tile's halo: the
+// weights are the MFMA's A operand (48 VGPRs for both parts, for the life of the workgroup), 16 pixels the B operand,
+// loaded STRAIGHT from HBM as the lane's 8 consecutive channels and split in registers -- every input element is read,
+// converted and multiplied once (the conv form reads and multiplies it nine times: 36 KB of LDS fragment reads per 16
+// pixels, here none).  A result block is [tap-channel][pixel]: the lane of k-group q holds the float4 Z[4 j + q][pixel]
+// [0..3], stored to LDS with one 16-byte write; after a barrier every output pixel sums its nine float4s in a fixed order
+// (fp32, the same for every batch).  Per 16 x 16 pixel tile (18 x 18 halo = 21 blocks of 16): 378 MFMAs, 1.3 k VALU
+// instructions per SIMD for the split, 47 KB + 37 KB of LDS traffic -- all far below the tile's 83 KB from HBM / L2:
+// memory-bound (1.05 GB per 4 M pixels plus the halos' L2 hits).  Measured at 4 M pixels: this form 285 us (3.7 TB/s of
+// input; floor 0.17-0.19 ms); the 3 x 3 conv form on the matrix pipe (weights 144 VGPRs, halo tile split into LDS once,
+// read by nine taps) with specialised producer / consumer waves 361, without 459; exact-fp32 FMAs (rac_head_fwd) 515;
+// the rows kernel's 32-column tile 845.
+constexpr int H16_T = 16, H16_P = H16_T + 2, H16_NPX = H16_P * H16_P, H16_NBLK = (H16_NPX + 15) / 16, H16_ZS = H16_NBLK * 16;
+__global__ __launch_bounds__(256, 2) void head16_kernel(const float* __restrict__ x, const unsigned* __restrict__ a_amax,
+                                                        int per_image, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ y, int H, int W,
+                                                        int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float zs[9 * H16_ZS * 4];  // Z[tap][halo pixel][4]
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float m = 0.f;
+  for (int i = tid; i < 9 * 64 * 4; i += 256) m = fmaxf(m, fabsf(wt[i]));
+#pragma unroll
+  for (int off = 32; off; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (lane == 0) red[wid] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const int kw = scale_exp(__builtin_bit_cast(unsigned, m));
+  const float sw = pow2f(kw);
+  // A fragments: row lr of block j = (tap 4 j + lr / 4, channel lr % 4); k = 32 s + 8 lq + i
+  f16x8 fw[3][2][2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int tap = 4 * j + (lr >> 2), co = lr & 3;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = tap < 9 ? wt[(tap * 64 + s * 32 + lq * 8 + i) * 4 + co] * sw : 0.f;
+        const _Float16 a = (_Float16)v;
+        fw[j][s][0][i] = a;
+        fw[j][s][1][i] = (_Float16)(v - (float)a);
+      }
+  }
+  const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias);
+  const int tiles_x = W >> 4, tiles_img = (H >> 4) * tiles_x;
+  constexpr int NB = (H16_NBLK + 3) / 4;  // blocks per wave: wid, wid + 4, ...
+
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / tiles_img, ti = tile - b * tiles_img;
+    const int ty0 = (ti / tiles_x) << 4, tx0 = (ti % tiles_x) << 4;
+    const int ka = scale_exp(a_amax[per_image ? b : 0]);
+    const float sa = pow2f(ka), inv = pow2f(-ka) * pow2f(-kw);
+    const rsrc_t r = make_rsrc(x + (long)b * H * W * 64, (unsigned)((long)H * W * 64 * 4));
+    // [buffer][step s, half]: the lane's 8 channels of both K steps, one block ahead (two ahead costs the third wave per
+    // SIMD: 309 against 285 us; an XCD-contiguous tile order changes nothing: the halos' second readers hit the MALL)
+    u32x4 v[2][4];
+    auto issue = [&](u32x4(&d)[4], int blk) {
+      const int hp = blk * 16 + lr;
+      const int row = hp / H16_P, col = hp - row * H16_P;
+      const int gy = ty0 + row - 1, gx = tx0 + col - 1;
+      const bool ok = (hp < H16_NPX) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+      const unsigned off = ok ? (unsigned)(((gy * W + gx) * 64 + lq * 8) * 4) : OOB;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        d[2 * s] = load16(r, ok ? off + s * 128u : OOB);
+        d[2 * s + 1] = load16(r, ok ? off + s * 128u + 16u : OOB);
+      }
+    };
+    issue(v[0], wid);
+    __syncthreads();  // the previous tile's sums have read zs
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      const int blk = wid + 4 * n;
+      if (blk >= H16_NBLK) break;
+      if (blk + 4 < H16_NBLK) issue(v[(n + 1) & 1], blk + 4);
+      f16x8 fx[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        u32x4 q[2];
+        split8h(v[n & 1][2 * s], v[n & 1][2 * s + 1], sa, q);
+        fx[s][0] = __builtin_bit_cast(f16x8, q[0]);
+        fx[s][1] = __builtin_bit_cast(f16x8, q[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) acc = mma3(fw[j][s], fx[s], acc);
+        const int tap = 4 * j + lq;  // acc[r] = Z[tap][pixel lr][channel r]
+        if (tap < 9) *reinterpret_cast<f32x4*>(zs + ((tap * H16_ZS) + blk * 16 + lr) * 4) = acc * inv;
+      }
+    }
+    __syncthreads();
+    {
+      const int py = tid >> 4, px = tid & 15;
+      f32x4 o = b4;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        o += *reinterpret_cast<const f32x4*>(zs + (tap * H16_ZS + (py + 2 - ky) * H16_P + px + 2 - kx) * 4);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) o[c] = sigmoid_acc(o[c]);
+      *reinterpret_cast<f32x4*>(y + (((long)b * H + ty0 + py) * W + tx0 + px) * 4) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The same for maps LARGER than a tile (the 16x16 / 32x32 / 64x64 vgg maps, the 16x16 ConvLSTM maps of a 128x128
 // model, the 12x16 maps of 48x64 frames): a tile = R whole image rows (R | H, R * W <= 128 and a multiple of 16);
 // its pixels plus `pad` image rows above and below (the halo; zeros outside the image) are staged per channel chunk
@@ -2017,6 +2131,20 @@ extern "C" int rac_convlstm_cell_fwd_split(const rac_conv_args* a, const uint32_
                                            float* h_out, float* c_out, void* stream) {
   RAC_REQUIRE(c_prev && h_out && c_out, "rac_convlstm_cell_fwd_split: null state pointer");
   return conv16_launch(a, a_amax0, a_amax1, w_part_stride, w_cin, w_amax, nullptr, c_prev, h_out, c_out, stream);
+}
+
+extern "C" int rac_head_fwd_split(const float* x, const uint32_t* x_amax, int32_t amax_per_image, const float* w_taps,
+                                  const float* bias, float* y, int32_t B, int32_t H, int32_t W, void* stream) {
+  RAC_REQUIRE(x && x_amax && w_taps && bias && y && B > 0 && H > 0 && W > 0, "rac_head_fwd_split: bad args");
+  RAC_REQUIRE(H % 16 == 0 && W % 16 == 0 && aligned16(x) && aligned16(y) && aligned16(bias),
+              "rac_head_fwd_split: H % 16 == 0, W % 16 == 0, 16-byte aligned buffers");
+  RAC_REQUIRE((long)H * W * 64 * 4 < (1L << 32), "rac_head_fwd_split: image too large for one buffer descriptor");
+  const long n_tiles = (long)B * (H / 16) * (W / 16);
+  RAC_REQUIRE(n_tiles < (1L << 31), "rac_head_fwd_split: too many tiles");
+  const int grid = (int)(n_tiles < 768 ? n_tiles : 768);  // persistent: the weight fragments are built once per workgroup
+  hipLaunchKernelGGL(head16_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, x_amax,
+                     amax_per_image, w_taps, bias, y, H, W, (int)n_tiles);
+  return check_launch("rac_head_fwd_split");
 }
 
 extern "C" int rac_split_steps(const float* const* xs, uint16_t* const* parts, int32_t T, int64_t n,

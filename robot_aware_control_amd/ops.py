@@ -326,6 +326,7 @@ def _flush_bias_grads():
 SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = SPLIT_GEMM
 HEAD_DIRECT = os.environ.get("RAC_HEAD_DIRECT", "1") == "1"  # the 64 -> 4 output head as FMAs (rac_head_fwd)
+HEAD_MFMA = os.environ.get("RAC_HEAD_MFMA", "1") == "1"  # ... on the matrix pipe, roles swapped (rac_head_fwd_split)
 # narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
 SPLIT_MIN_COUT_TRAIN = int(os.environ.get("RAC_SPLIT_MIN_COUT_TRAIN", "64"))
@@ -1183,7 +1184,14 @@ class ConvTHead(torch.autograd.Function):
         assert Ci == Ciw
         weight_mem(weight)
         y = torch.empty((B, H, W, Cow), device=x.device, dtype=torch.float32)
-        if HEAD_DIRECT and x.is_cuda and (Ciw, Cow, k) == (64, 4, 3) and H % 8 == 0 and W % 32 == 0:
+        if HEAD_MFMA and SPLIT_GEMM and x.is_cuda and (Ciw, Cow, k) == (64, 4, 3) and H % 16 == 0 and W % 16 == 0:
+            # the matrix pipe: tap-stacked 1 x 1 conv (weights = A operand, 16 pixels = B) + shifted sum
+            wt = _derived(weight, "_rac_head_taps", lambda: weight.detach().permute(2, 3, 0, 1).contiguous())
+            x = x if x.is_contiguous() else x.contiguous()
+            per_image = frozen and per_image_ok(H, W)
+            call("rac_head_fwd_split", ptr(x), ptr(amax_for(x, per_image)), 1 if per_image else 0, ptr(wt), ptr(bias),
+                 ptr(y), B, H, W, stream_ptr())
+        elif HEAD_DIRECT and x.is_cuda and (Ciw, Cow, k) == (64, 4, 3) and H % 8 == 0 and W % 32 == 0:
             # exact-fp32 FMAs, weights as scalar operands (rac_head_fwd): N = 4 is no shape for the matrix pipe
             wt = _derived(weight, "_rac_head_taps", lambda: weight.detach().permute(2, 3, 0, 1).contiguous())
             x = x if x.is_contiguous() else x.contiguous()

@@ -102,8 +102,9 @@ def test_conv_mfma_layout_asymmetric(dev):
 
 @pytest.mark.parametrize("B,H,W,Ci", [(2, 64, 64, 64), (1, 48, 64, 64), (1, 128, 128, 32), (2, 32, 32, 64)])
 def test_convT_head(dev, B, H, W, Ci, monkeypatch):
-    """ConvTranspose2d + bias + Sigmoid head.  64 -> 4 channels on H % 8 = W % 32 = 0 maps: the exact-fp32 FMA kernel
-    (rac_head_fwd, weights as scalar operands); otherwise the narrow 32-column form of the rows kernel (4 real columns)."""
+    """ConvTranspose2d + bias + Sigmoid head.  64 -> 4 channels on H % 8 = W % 16 = 0 maps: the matrix pipe with the
+    roles swapped (rac_head_fwd_split); RAC_HEAD_MFMA=0 or the exact-fp32 mode: the FMA kernel (rac_head_fwd, weights as
+    scalar operands); otherwise the narrow 32-column form of the rows kernel (4 real columns)."""
     from robot_aware_control_amd import ops
     x = rnd(1, B, Ci, H, W).requires_grad_(True)
     w = (rnd(2, Ci, 4, 3, 3) * 0.05).requires_grad_(True)
@@ -116,15 +117,22 @@ def test_convT_head(dev, B, H, W, Ci, monkeypatch):
     bd = b.detach().to(dev).requires_grad_(True)
     y = ops.ConvTHead.apply(xd, wd, bd)
     assert relerr(from_map(y), y_ref.detach()) < 1e-5
-    if Ci == 64:  # the direct kernel: exact fp32 against fp64, and the matrix-pipe form next to it
+    if Ci == 64:  # the three forms against fp64
         y64 = torch.sigmoid(F.conv_transpose2d(x.detach().double(), w.detach().double(), b.detach().double(), 1, 1))
         assert relerr(from_map(y), y64) < 2e-6
+        monkeypatch.setattr(ops, "HEAD_MFMA", False)
+        y_fma = ops.ConvTHead.apply(xd.detach(), wd.detach(), bd.detach())
         monkeypatch.setattr(ops, "HEAD_DIRECT", False)
-        y_mfma = ops.ConvTHead.apply(xd.detach(), wd.detach(), bd.detach())
+        y_rows = ops.ConvTHead.apply(xd.detach(), wd.detach(), bd.detach())
         monkeypatch.setattr(ops, "HEAD_DIRECT", True)
-        assert relerr(from_map(y_mfma), y64) < 2e-6 and relerr(from_map(y.detach()), from_map(y_mfma).double()) < 2e-6
-        # per-pixel arithmetic only: an image's output is the same bits alone and in a batch
-        assert torch.equal(ops.ConvTHead.apply(xd.detach()[B - 1:].contiguous(), wd.detach(), bd.detach()), y.detach()[B - 1:])
+        monkeypatch.setattr(ops, "HEAD_MFMA", True)
+        assert relerr(from_map(y_fma), y64) < 2e-6 and relerr(from_map(y_rows), y64) < 2e-6
+        assert relerr(from_map(y.detach()), from_map(y_fma).double()) < 2e-6
+        # the frozen model's form (one scale per image): an image's output is the same bits alone and in a batch
+        with torch.no_grad():
+            yf = ops.ConvTHead.apply(xd.detach(), wd.detach(), bd.detach(), True)
+            y1 = ops.ConvTHead.apply(xd.detach()[B - 1:].contiguous(), wd.detach(), bd.detach(), True)
+        assert torch.equal(y1, yf[B - 1:]) and relerr(from_map(yf), y64) < 2e-6
     y.backward(to_map(gy, dev))
     assert relerr(from_map(xd.grad), x.grad) < 2e-5
     assert relerr(wd.grad.cpu(), w.grad) < 3e-5
