@@ -335,6 +335,13 @@ int rac_first_layer_fwd(const float* img, const float* zmask, const float* mask,
                         const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax,
                         int32_t amax_per_image, int32_t B, int32_t H, int32_t W, int32_t Cout, void* stream);
 /* amax_per_image: out_amax is an array of B zeroed slots, one per image */
+/* The same layer on the split-precision matrix pipe (same arguments): the weights are the MFMA's A operand (M = 64
+ * channels), 16 pixels the B operand gathered from the halo planes; every pixel is scaled by the maximum of its own
+ * 9 x (3 + Cm) inputs and every channel by the maximum of its own weights (a column of B and a row of A may each carry
+ * their own power of two), so no operand maxima are needed and an image's result depends on nothing but the image. */
+int rac_first_layer_fwd_split(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
+                              const float* scale, const float* shift, int32_t act, float* out, uint32_t* out_amax,
+                              int32_t amax_per_image, int32_t B, int32_t H, int32_t W, int32_t Cout, void* stream);
 /* The output head, ConvTranspose2d(64 -> 4, 3, 1, 1) + bias + Sigmoid (vgg_64.py:218-220), forward, as exact-fp32 FMAs
  * (a GEMM with N = 4 wastes the matrix pipe):
  *   y[b][p][c] = sigmoid(bias[c] + sum_{ky, kx, ci} x[b][p - (ky - 1, kx - 1)][ci] * w_taps[ky][kx][ci][c])

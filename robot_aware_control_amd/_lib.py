@@ -115,6 +115,7 @@ _SIGS = {
     "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
     "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],
     "rac_first_layer_fwd": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
+    "rac_first_layer_fwd_split": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_head_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
     "rac_head_fwd_split": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "rac_thin_wgrad": [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp],

@@ -636,6 +636,166 @@ __global__ __launch_bounds__(256, 2) void head16_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// First encoder layer of the frozen model on the matrix pipe, straight from the NCHW planes (vgg_64.py:8-18 on
+// dynamics.py:578-582's input): out[b][y][x][co] = act(scale[co] conv3x3([img * (zmask == 0) | mask])[co] + shift[co]).
+// K = 9 taps x CIN (27..72) is one to three MFMA steps; with the roles swapped -- the weights the A operand (M = 64 output
+// channels, 4 blocks: 32 VGPRs per step for the life of the workgroup), 16 pixels of an image row the B operand, gathered
+// from the tile's halo planes in LDS -- a result block is [channel][pixel]: a lane stores 4 consecutive channels of its
+// pixel with one 16-byte store and the four lanes of a pixel write 64 contiguous bytes.
+// Operand scales need no tensor maxima here: a COLUMN of B (a pixel's 9 x CIN inputs) and a ROW of A (a channel's
+// weights) may each carry their own power of two (C[m][n] is scaled by both, exactly), so every pixel is scaled by the
+// maximum of its own inputs and every channel by the maximum of its own weights, found with two lane exchanges: better
+// conditioned than one scale per image, and an image's result cannot depend on anything but the image.
+// Per 16 pixels: 12 KS MFMAs and ~150 VALU instructions against 4 KB of output: bound by the 1.05 GB write per 4 M pixels.
+// (The exact-fp32 FMA form, rac_first_layer_fwd: 1728 CIN / 3 FMAs per pixel, VALU-bound, 0.53 ms there.)
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void first16_kernel(const float* __restrict__ img, const float* __restrict__ zmask,
+                                                         const float* __restrict__ mask, const float* __restrict__ w,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int act, float* __restrict__ out, unsigned* amax, int per_image,
+                                                         int H, int W, int n_tiles) {
+  constexpr int KK = 9 * CIN, KS = (KK + 31) / 32, TP = 18, TPW = 20, PL = TP * TPW;
+  __shared__ float in_sh[CIN * PL];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, lq = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A fragments: row lr of block j = channel 16 j + lr, k = 32 s + 8 lq + i = (tap, ci) flattened as in w[co][tap][ci]
+  f16x8 fw[4][KS][2];
+  float osc[4][4], osh[4][4];  // the epilogue's per-channel scale (x 2^-k of the channel's weight scale) and shift
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float* wr = w + (long)(16 * j + lr) * KK;
+    float wv[KS][8], mx = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 32 * s + 8 * lq + i;
+        wv[s][i] = k < KK ? wr[k] : 0.f;
+        mx = fmaxf(mx, fabsf(wv[s][i]));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const int kw = scale_exp(__builtin_bit_cast(unsigned, mx));
+    const float sw = pow2f(kw);
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float v = wv[s][i] * sw;
+        const _Float16 a = (_Float16)v;
+        fw[j][s][0][i] = a;
+        fw[j][s][1][i] = (_Float16)(v - (float)a);
+      }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {  // this lane's result rows are channels 16 j + 4 lq + r: their scale sits in lane 4 lq + r
+      const int kwr = __shfl(kw, 4 * lq + r);
+      const int co = 16 * j + 4 * lq + r;
+      osc[j][r] = (scale ? scale[co] : 1.f) * pow2f(-kwr);
+      osh[j][r] = scale ? shift[co] : 0.f;
+    }
+  }
+  // B gather: the lane's k values of step s as offsets into the halo planes, relative to its pixel
+  int goff[KS][8];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = min(32 * s + 8 * lq + i, KK - 1), tap = k / CIN, ci = k - tap * CIN;
+      goff[s][i] = ci * PL + (tap / 3) * TPW + tap % 3;
+    }
+  const float slope = act == RAC_ACT_LEAKY02 ? 0.2f : 1.f;
+  const int tiles_x = W >> 4, tiles_img = (H >> 4) * tiles_x;
+  const long HW = (long)H * W;
+
+  // the halo planes of a tile: CIN x 18 x 18 values, NST per thread, requested one tile ahead (a tile's life is otherwise
+  // mostly the round trips of these small loads)
+  constexpr int NST = (CIN * TP * TP + 255) / 256;
+  float pv[NST];
+  auto fetch = [&](int tile) {
+    const int b = tile / tiles_img, ti = tile - b * tiles_img;
+    const int ty0 = (ti / tiles_x) << 4, tx0 = (ti % tiles_x) << 4;
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int i = tid + 256 * it;
+      const int ci = i / (TP * TP), q = i - ci * TP * TP;
+      const int qy = q / TP, qx = q - qy * TP;
+      const int yy = ty0 + qy - 1, xx = tx0 + qx - 1;
+      const bool ok = (i < CIN * TP * TP) & ((unsigned)yy < (unsigned)H) & ((unsigned)xx < (unsigned)W);
+      const long pix = ok ? (long)yy * W + xx : 0;
+      const float* src = ci < 3 ? img + ((long)b * 3 + (ok ? ci : 0)) * HW + pix
+                                : mask + ((long)b * (CIN - 3) + (ok ? ci - 3 : 0)) * HW + pix;
+      float v = ok ? *src : 0.f;
+      if (zmask) {
+        const float z = zmask[(long)b * HW + pix];
+        if (ok & (ci < 3) & (z != 0.f)) v = v * 0.f;
+      }
+      pv[it] = v;
+    }
+  };
+  if ((int)blockIdx.x < n_tiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int b = tile / tiles_img, ti = tile - b * tiles_img;
+    const int ty0 = (ti / tiles_x) << 4, tx0 = (ti % tiles_x) << 4;
+    __syncthreads();  // the previous tile's gathers
+#pragma unroll
+    for (int it = 0; it < NST; ++it) {
+      const int i = tid + 256 * it;
+      if (i >= CIN * TP * TP) break;
+      const int ci = i / (TP * TP), q = i - ci * TP * TP;
+      in_sh[ci * PL + (q / TP) * TPW + q % TP] = pv[it];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < n_tiles) fetch(tile + gridDim.x);
+    unsigned mxo = 0;
+#pragma unroll 1
+    for (int n = 0; n < 4; ++n) {
+      const int py = 4 * wid + n;  // the block = image row py of the tile, pixel lr
+      const float* base = in_sh + py * TPW + lr;
+      float xv[KS][8], mx = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float t = base[goff[s][i]];
+          xv[s][i] = (32 * s + 8 * lq + i < KK) ? t : 0.f;
+          mx = fmaxf(mx, fabsf(xv[s][i]));
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16));
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const int ka = scale_exp(__builtin_bit_cast(unsigned, mx));
+      const float sa = pow2f(ka), ia = pow2f(-ka);
+      f16x8 fx[KS][2];
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float v = xv[s][i] * sa;
+          const _Float16 a = (_Float16)v;
+          fx[s][0][i] = a;
+          fx[s][1][i] = (_Float16)(v - (float)a);
+        }
+      float* op = out + (((long)b * H + ty0 + py) * W + tx0 + lr) * 64 + 4 * lq;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = mma3(fw[j][s], fx[s], acc);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = fmaf(acc[r] * ia, osc[j][r], osh[j][r]);
+          v = v > 0.f ? v : slope * v;
+          mxo = max(mxo, absbits(v));
+          o[r] = v;
+        }
+        *reinterpret_cast<f32x4*>(op + 16 * j) = o;
+      }
+    }
+    if (amax) amax_commit_block(mxo, per_image ? amax + b : amax);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The same for maps LARGER than a tile (the 16x16 / 32x32 / 64x64 vgg maps, the 16x16 ConvLSTM maps of a 128x128
 // model, the 12x16 maps of 48x64 frames): a tile = R whole image rows (R | H, R * W <= 128 and a multiple of 16);
 // its pixels plus `pad` image rows above and below (the halo; zeros outside the image) are staged per channel chunk
@@ -2131,6 +2291,27 @@ extern "C" int rac_convlstm_cell_fwd_split(const rac_conv_args* a, const uint32_
                                            float* h_out, float* c_out, void* stream) {
   RAC_REQUIRE(c_prev && h_out && c_out, "rac_convlstm_cell_fwd_split: null state pointer");
   return conv16_launch(a, a_amax0, a_amax1, w_part_stride, w_cin, w_amax, nullptr, c_prev, h_out, c_out, stream);
+}
+
+extern "C" int rac_first_layer_fwd_split(const float* img, const float* zmask, const float* mask, int32_t Cm, const float* w,
+                                         const float* scale, const float* shift, int32_t act, float* out,
+                                         uint32_t* out_amax, int32_t amax_per_image, int32_t B, int32_t H, int32_t W,
+                                         int32_t Cout, void* stream) {
+  RAC_REQUIRE(img && w && out && B > 0 && H > 0 && W > 0 && Cm >= 0 && Cm <= 5 && (Cm == 0 || mask),
+              "rac_first_layer_fwd_split: bad args (3 image planes + at most 5 mask / heatmap planes)");
+  RAC_REQUIRE(Cout == 64 && H % 16 == 0 && W % 16 == 0 && (scale == nullptr) == (shift == nullptr) && aligned16(out) &&
+                  (act == RAC_ACT_NONE || act == RAC_ACT_LEAKY02),
+              "rac_first_layer_fwd_split: Cout 64, H and W multiples of 16, act none / leaky");
+  const long n_tiles = (long)B * (H / 16) * (W / 16);
+  RAC_REQUIRE(n_tiles < (1L << 31), "rac_first_layer_fwd_split: too many tiles");
+  const int grid = (int)(n_tiles < 1024 ? n_tiles : 1024);  // persistent: the weight fragments are built once per workgroup
+  typedef void (*fn_t)(const float*, const float*, const float*, const float*, const float*, const float*, int, float*,
+                       unsigned*, int, int, int, int);
+  static const fn_t fns[6] = {first16_kernel<3>, first16_kernel<4>, first16_kernel<5>,
+                              first16_kernel<6>, first16_kernel<7>, first16_kernel<8>};
+  hipLaunchKernelGGL(fns[Cm], dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), img, zmask, mask, w, scale,
+                     shift, act, out, out_amax, amax_per_image ? 1 : 0, H, W, (int)n_tiles);
+  return check_launch("rac_first_layer_fwd_split");
 }
 
 extern "C" int rac_head_fwd_split(const float* x, const uint32_t* x_amax, int32_t amax_per_image, const float* w_taps,

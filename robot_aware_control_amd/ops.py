@@ -326,6 +326,7 @@ def _flush_bias_grads():
 SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = SPLIT_GEMM
 HEAD_DIRECT = os.environ.get("RAC_HEAD_DIRECT", "1") == "1"  # the 64 -> 4 output head as FMAs (rac_head_fwd)
+FIRST_MFMA = os.environ.get("RAC_FIRST_MFMA", "1") == "1"  # the frozen model's first encoder layer on the matrix pipe
 HEAD_MFMA = os.environ.get("RAC_HEAD_MFMA", "1") == "1"  # ... on the matrix pipe, roles swapped (rac_head_fwd_split)
 # narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
@@ -1656,7 +1657,9 @@ def first_layer_frozen(img, zero_mask, mask, weight, scale, shift) -> torch.Tens
     Cm = mask.shape[1] if mask is not None else 0
     out = torch.empty((B, H, W, 64), device=img.device, dtype=torch.float32)
     slot = amax_slot(img.device, B)  # one maximum per image: the frozen model's scales are per image
-    call("rac_first_layer_fwd", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(weight_mem(weight.detach())), ptr(scale),
+    # the matrix pipe (per-pixel / per-channel operand scales), or exact-fp32 FMAs (RAC_FIRST_MFMA=0)
+    call("rac_first_layer_fwd_split" if FIRST_MFMA else "rac_first_layer_fwd", ptr(img), ptr(zero_mask), ptr(mask), Cm,
+         ptr(weight_mem(weight.detach())), ptr(scale),
          ptr(shift), ACT_LEAKY, ptr(out), ptr(slot), 1, B, H, W, 64, stream_ptr())
     return tag_amax(out, slot)
 

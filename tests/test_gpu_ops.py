@@ -209,11 +209,15 @@ def test_lstm_cell(dev, g, k, B):
     assert relerr(bd.grad.cpu(), b.grad) < 5e-5
 
 
-@pytest.mark.parametrize("B,H,W,Cm,zero", [(3, 64, 64, 2, True), (2, 48, 64, 1, True), (2, 32, 16, 0, False), (1, 16, 16, 4, True)])
-def test_first_layer_from_planes(dev, B, H, W, Cm, zero):
+@pytest.mark.parametrize("mfma", [True, False], ids=["matrix_pipe", "fma"])
+@pytest.mark.parametrize("B,H,W,Cm,zero", [(3, 64, 64, 2, True), (2, 48, 64, 1, True), (2, 32, 16, 0, False), (1, 16, 16, 4, True),
+                                           (2, 32, 32, 5, False)])
+def test_first_layer_from_planes(dev, B, H, W, Cm, zero, mfma, monkeypatch):
     """Frozen model's first encoder layer straight from the NCHW planes: zero_robot_region + mask concat + conv3x3 +
-    folded BatchNorm + LeakyReLU(0.2) in one kernel, and the max |out| it leaves for the next conv."""
+    folded BatchNorm + LeakyReLU(0.2) in one kernel, and the max |out| it leaves for the next conv -- on the matrix
+    pipe (rac_first_layer_fwd_split: every pixel / channel scaled by its own maximum) and as exact-fp32 FMAs."""
     from robot_aware_control_amd import ops
+    monkeypatch.setattr(ops, "FIRST_MFMA", mfma)
     img = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(3))
     mask = (rnd(2, B, Cm, H, W) > 0.3).float() if Cm else None
     zm = (rnd(4, B, 1, H, W) > 0.5).float() if zero else None
@@ -230,6 +234,10 @@ def test_first_layer_from_planes(dev, B, H, W, Cm, zero):
     assert relerr(from_map(out), ref) < 2e-6
     # one maximum per image (the frozen model scales every image on its own)
     assert torch.equal(ops.amax_tag(out).cpu(), out.abs().amax((1, 2, 3)).view(torch.int32).cpu())
+    # an image's result is the same bits alone and in the batch
+    one = ops.first_layer_frozen(img[B - 1:].to(dev), None if zm is None else zm[B - 1:].to(dev),
+                                 None if mask is None else mask[B - 1:].to(dev), wd, scale.to(dev), shift.to(dev))
+    assert torch.equal(one, out[B - 1:])
 
 
 @pytest.mark.parametrize("B,h,w,C0,C1,Cout", [(2, 8, 8, 64, 64, 64), (3, 32, 32, 64, 64, 64), (2, 16, 16, 128, 128, 128),
