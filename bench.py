@@ -139,7 +139,11 @@ def kernel_roofline(k):
     peak = SPLIT_PEAK_TFLOPS if k["split"] else F32_MFMA_PEAK_TFLOPS
     return {"arith": ("fp16x2-split operands (22 bits, power-of-two tensor scales), 3 fp16 MFMA products per fp32 "
                       "product, fp32 accumulate" if k["split"] else "exact fp32 MFMA"),
-            "peak": peak, "frac": k["tflops"] / peak}
+            "peak": peak, "frac": k["tflops"] / peak,
+            # what a kernel of nothing but these MFMAs (register-resident operands) sustains under the chip's power cap:
+            # 1939 TFLOP/s of fp16 products = 0.776 of nominal (profiles/r03_mfma_power.md); informational, `frac` is the contract's
+            **({"sustained_mfma_peak": round(SPLIT_PEAK_TFLOPS * 0.776, 1),
+                "frac_of_sustained": k["tflops"] / (SPLIT_PEAK_TFLOPS * 0.776)} if k["split"] else {})}
 
 
 def phase_breakdown(events, steps):
