@@ -23,6 +23,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "rac_common.h"
 
 namespace rac {
@@ -564,7 +566,9 @@ __global__ __launch_bounds__(256, 2) void head16_kernel(const float* __restrict_
     for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        const float v = tap < 9 ? wt[(tap * 64 + s * 32 + lq * 8 + i) * 4 + co] * sw : 0.f;
+        // (clamped address + select: a load behind a branch is waited for on the spot, 24 round trips in a row)
+        const float t = wt[(min(tap, 8) * 64 + s * 32 + lq * 8 + i) * 4 + co];
+        const float v = tap < 9 ? t * sw : 0.f;
         const _Float16 a = (_Float16)v;
         fw[j][s][0][i] = a;
         fw[j][s][1][i] = (_Float16)(v - (float)a);
@@ -670,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void first16_kernel(const float* __restrict
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int k = 32 * s + 8 * lq + i;
-        wv[s][i] = k < KK ? wr[k] : 0.f;
+        const float t = wr[min(k, KK - 1)];  // (clamped address + select: no load behind a branch)
+        wv[s][i] = k < KK ? t : 0.f;
         mx = fmaxf(mx, fabsf(wv[s][i]));
       }
     mx = fmaxf(mx, __shfl_xor(mx, 16));
@@ -817,6 +822,9 @@ __global__ __launch_bounds__(256, 2) void first16_kernel(const float* __restrict
 // HBM round trip alone is 4-6 us of a 22 us tile) and issues 3.4 other VALU instructions per MFMA (staging with its
 // 2x halo, tap addressing, the epilogue), which share the SIMD's issue port with the MFMAs.  Dropping the fragment
 // reads, the weight loads or the MFMAs themselves from the loop changes the kernel time by 5-10 % each.
+#ifndef RAC_ROWS_PIN
+#define RAC_ROWS_PIN 1
+#endif
 template <int NV, int WM, int NT, int D, bool FAST = false>
 __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;
@@ -955,14 +963,21 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     static_assert(D == 3, "the 9 taps of a chunk walk a ring of 3 weight register sets");
     const int c_begin = kc_begin / 9, c_end = kc_end / 9;
     if (c_begin < c_end) {
-      u32x4 bs[3][4 * NT];
+      // weight register sets: 128-column workgroups (NT = 2: 32 VGPRs per set) keep TWO and request one tap ahead -- with
+      // three the kernel needs more than 256 VGPRs, and the scheduler, to stay inside, sank every request to just before the
+      // MFMAs that read it: each tap then waited out an L2 round trip (seen in the ISA: s_waitcnt vmcnt(7) straight after
+      // eight loads).  Nine taps are odd, so with two sets the set of a tap alternates between chunks: the chunk body exists
+      // for both parities.  The narrower forms keep three sets, two taps ahead.
+      constexpr int R = NT == 2 ? 2 : 3, AHEAD = R - 1;
+      u32x4 bs[R][4 * NT];
       issue_a(c_begin);
-      load_b(bs[0], kc_begin);
-      load_b(bs[1], min(kc_begin + 1, kc_end - 1));
+#pragma unroll
+      for (int j = 0; j < AHEAD; ++j) load_b(bs[j], min(kc_begin + j, kc_end - 1));
       store_a(0);
       __syncthreads();
       int cur = 0;
-      for (int cc = c_begin; cc < c_end; ++cc) {
+      auto chunk = [&](auto par, int cc) {
+        constexpr int P = decltype(par)::value;
         const bool more = cc + 1 < c_end;
         if (more) issue_a(cc + 1);
         const int kc0 = cc * 9;
@@ -970,7 +985,11 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap % 3;
-          load_b(bs[(tap + 2) % 3], min(kc0 + tap + 2, kc_end - 1));
+          load_b(bs[(tap + AHEAD + P) % R], min(kc0 + tap + AHEAD, kc_end - 1));
+#if RAC_ROWS_PIN
+          // pin the requests here: in this one large basic block the scheduler otherwise moves them towards their use
+          __builtin_amdgcn_sched_barrier(0);
+#endif
           const int drow = (ky - 1) * p.W + (kx - 1);
           const int shift = drow * 16 + bufo + abase;
           const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
@@ -981,7 +1000,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
               for (int part = 0; part < 2; ++part)
-                fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[tap % 3][(j2 * 2 + part) * 2 + nb]);
+                fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[(tap + P) % R][(j2 * 2 + part) * 2 + nb]);
           f16x8 fa[MB][2];
 #pragma unroll
           for (int t = 0; t < MB; ++t) {
@@ -1001,6 +1020,14 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           __syncthreads();
           cur ^= 1;
         }
+      };
+      if constexpr (R == 2) {
+        for (int cc = c_begin; cc < c_end; cc += 2) {
+          chunk(std::integral_constant<int, 0>{}, cc);
+          if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
+        }
+      } else {
+        for (int cc = c_begin; cc < c_end; ++cc) chunk(std::integral_constant<int, 0>{}, cc);
       }
     }
   } else
@@ -1256,6 +1283,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
         int knext = kc0 + tap + 2;
         knext = knext >= kc_end ? knext - kc_end : knext;
         load_b(bs[(tap + 2) % 3], knext);
+#if RAC_ROWS_PIN
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         const int drow = (ky - 1) * p.W + (kx - 1);
         const int shift = drow * 16 + bufo + abase;
         const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;
