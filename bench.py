@@ -535,6 +535,9 @@ def main():
                            "avg_launch_ms": k["avg_ms"], "launches": k["launches"],
                            "step_achieved": train["step_tflops_per_gpu"], "step_peak": SPLIT_PEAK_TFLOPS,
                            "step_frac": train["step_tflops_per_gpu"] / SPLIT_PEAK_TFLOPS}
+        for key in ("sustained_mfma_peak", "frac_of_sustained"):  # informational (profiles/r03_mfma_power.md)
+            if key in kr:
+                out["roofline"][key] = kr[key]
         if not (args.h48 or args.cfg5 or args.group_norm):
             out["roofline"]["kernel"] = ("conv16_tile_kernel: FWD 5x5 ConvLSTM gate conv as GEMM (M=%d, N=2048, K=25600)"
                                          % (train["cf"].batch_size * 64))
