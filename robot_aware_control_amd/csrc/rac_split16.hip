@@ -987,7 +987,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           const int ky = tap / 3, kx = tap % 3;
           load_b(bs[(tap + AHEAD + P) % R], min(kc0 + tap + AHEAD, kc_end - 1));
 #if RAC_ROWS_PIN
-          // pin the requests here: in this one large basic block the scheduler otherwise moves them towards their use
+          // pin the requests here: in this one large basic block the scheduler otherwise moves them towards their use.
+          // (Also pinning a tap's fragment reads before its MFMAs, or rotating them through the tap in halves as
+          // conv16_rows_persist_kernel does: +4 % on the 64-column form, nothing on the 128-column one -- not done.)
           __builtin_amdgcn_sched_barrier(0);
 #endif
           const int drow = (ky - 1) * p.W + (kx - 1);
@@ -1257,11 +1259,29 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   load_b(bs[0], kc_begin);
   load_b(bs[1], min(kc_begin + 1, kc_end - 1));
   int cur = 0;
+  // A fragments rotate through the tap in halves: the second half's reads are issued before the first half's MFMAs, the NEXT
+  // tap's first half before the second half's MFMAs, pinned with scheduling barriers.  (Left alone, the scheduler issued
+  // every read right in front of the MFMAs that need it -- s_waitcnt lgkmcnt(0) after each: an LDS round trip per fragment
+  // under 3-6 MFMAs.  -7 % here; in conv16_rows_kernel the same rotation measured +4 % on the 64-column form.)
+  constexpr int HB = MB / 2;
+  f16x8 fa[MB][2];
+  auto read_frag = [&](int t, int tap, int bufo) {
+    const int ky = tap / 3, kx = tap % 3;
+    const int drow = (ky - 1) * p.W + (kx - 1);
+    const int shift = drow * 16 + bufo + abase;
+    const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;
+    const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+      fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+  };
   for (;;) {
     const int next_bx = bx + gridDim.x;
     const bool has_next = next_bx < n_tiles;
     store_a(cur, pow2f(cur_t.ka));  // the first chunk of this tile: requested while the previous tile was finishing
     __syncthreads();
+#pragma unroll
+    for (int t = 0; t < HB; ++t) read_frag(t, 0, cur * abuf);
     if (has_next) setup(next_bx, nxt_t);
     f32x4 acc[MB][NB];
 #pragma unroll
@@ -1275,20 +1295,13 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
       else if (has_next)
         issue_a(0, nxt_t);
       const int kc0 = cc * 9;
-      const int bufo = cur * abuf;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap % 3;
         // the ring wraps to taps 0 and 1 of chunk 0 behind the last chunk: the next tile multiplies the same weights
         int knext = kc0 + tap + 2;
         knext = knext >= kc_end ? knext - kc_end : knext;
         load_b(bs[(tap + 2) % 3], knext);
-#if RAC_ROWS_PIN
         __builtin_amdgcn_sched_barrier(0);
-#endif
-        const int drow = (ky - 1) * p.W + (kx - 1);
-        const int shift = drow * 16 + bufo + abase;
-        const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;
         f16x8 fb[NB][2];
 #pragma unroll
         for (int j2 = 0; j2 < NT; ++j2)
@@ -1297,23 +1310,28 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
 #pragma unroll
             for (int part = 0; part < 2; ++part)
               fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[tap % 3][(j2 * 2 + part) * 2 + nb]);
-        f16x8 fa[MB][2];
 #pragma unroll
-        for (int t = 0; t < MB; ++t) {
-          const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+        for (int t = HB; t < MB; ++t) read_frag(t, tap, cur * abuf);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int part = 0; part < 2; ++part)
-            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
-        }
-#pragma unroll
-        for (int t = 0; t < MB; ++t)
+        for (int t = 0; t < HB; ++t)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
-      }
-      if (more) {
-        store_a(cur ^ 1, pow2f(cur_t.ka));
-        __syncthreads();
-        cur ^= 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 8 && more) {
+          store_a(cur ^ 1, pow2f(cur_t.ka));
+          __syncthreads();
+          cur ^= 1;
+        }
+        if (tap < 8 || more) {
+#pragma unroll
+          for (int t = 0; t < HB; ++t) read_frag(t, (tap + 1) % 9, cur * abuf);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = HB; t < MB; ++t)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
       }
     }
     const int img = p.per_image ? cur_t.m0 / p.HW : 0;
