@@ -115,6 +115,11 @@ struct Conv16P {
 // The 16 lanes of a ds_read_b128 group touch 16 distinct rows mod 16 = 16 distinct bank slots; a tap shift is one
 // wave-uniform byte offset.
 constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
+// The y-major form (W = 8, two images per tile) pads every image-row segment to 16 slots -- LDS row 32 y + 16 i + 4 + x,
+// slots 0..3 and 12..15 zeros: a horizontal tap that leaves the image reads the padding, so a fragment address is the
+// lane's constant + one wave-uniform tap offset + an immediate per block: no per-lane validity mask, compare and select
+// (12 of the ~38 VALU instructions per 48 MFMAs).  256 rows per plane, 32 KB per buffer.
+constexpr int T16Y_CP = 256 * 16, T16Y_PP = 4 * T16Y_CP, T16Y_ABUF = 2 * T16Y_PP;
 
 // Epilogue of both kernels: undo the two operand scales, then as rac_conv2d FWD (bias, fp64 BatchNorm statistics of the
 // biased value, folded eval-BatchNorm scale / shift, activation, max |v|) -- or the raw partial sums of a K split.
@@ -328,9 +333,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const int m0 = bx * TM, n0 = by * SBN;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
+  constexpr int CP = YM ? T16Y_CP : T16_CP, PP = 4 * CP, ABUF = 2 * PP;
   const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
-  // the LDS row of the staged pixel: its tile row, or (YM) 16 y + 8 image + x
+  // the accumulator row of the staged pixel: its tile row, or (YM) 16 y + 8 image + x ...
   const int lrow = (YM && srow < TM) ? ((srow % p.HW) >> 3) * 16 + (srow / p.HW) * 8 + (srow & 7) : srow;
+  // ... and its LDS row: the same, or (YM) 32 y + 16 image + 4 + x (padded segments)
+  const int srow_lds = YM ? ((srow % p.HW) >> 3) * 32 + (srow / p.HW) * 16 + 4 + (srow & 7) : srow;
   __shared__ float ia_sh[128];  // per-image scales: 1 / scale of every tile row's image
   unsigned am;
   if (p.per_image) {  // the scale of the image this thread's staged row belongs to
@@ -344,8 +352,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   }
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
   const float sa = pow2f(ka);
-  // zero rows 128..143 of every chunk plane of both buffers: 2 * 2 * 4 * 16 = 256 vectors
-  {
+  if constexpr (YM) {  // everything: the padding slots (and the rows of a short tile) are never written again
+#pragma unroll
+    for (int i = 0; i < 2 * ABUF / (256 * 16); ++i)
+      *reinterpret_cast<u32x4*>(lds_raw + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();  // (the staging below writes some of the same slots from other threads)
+  } else {  // zero rows 128..143 of every chunk plane of both buffers: 2 * 2 * 4 * 16 = 256 vectors
     const int pl = tid >> 4, r = tid & 15;  // plane index (buffer, part, chunk), row
     *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * T16_ABUF + ((pl >> 2) & 1) * T16_PP + (pl & 3) * T16_CP +
                               (128 + r) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -367,8 +379,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
     amask[t] = mk;
   }
-  const int abase = lq * T16_CP + (wm * RB * 16 + lr) * 16;  // block t adds t * 256
-  const int zrow = lq * T16_CP + 128 * 16;
+  // fragment base of the lane: block t adds t * 256 -- (YM) image row wm * RB + t: t * 512
+  const int abase = YM ? lq * CP + (wm * RB * 32 + 16 * (lr >> 3) + 4 + (lr & 7)) * 16 : lq * CP + (wm * RB * 16 + lr) * 16;
+  const int zrow = lq * CP + 128 * 16;
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
   unsigned b_off[NT];
@@ -409,7 +422,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       split8h(ra[2 * i], ra[2 * i + 1], sa, q);
 #pragma unroll
       for (int part = 0; part < 2; ++part)
-        *reinterpret_cast<u32x4*>(lds_raw + buf * T16_ABUF + part * T16_PP + (sch + 2 * i) * T16_CP + lrow * 16) = q[part];
+        if (!YM || srow < TM)  // (YM: a row past the tile has no slot of its own)
+          *reinterpret_cast<u32x4*>(lds_raw + buf * ABUF + part * PP + (sch + 2 * i) * CP + srow_lds * 16) = q[part];
     }
   };
 
@@ -446,11 +460,11 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
-      const int drow = (ky - p.pad) * (YM ? 16 : p.W) + (kx - p.pad);
-      const int shift = drow * 16 + cur * T16_ABUF + abase;
+      const int drow = (ky - p.pad) * (YM ? 32 : p.W) + (kx - p.pad);
+      const int shift = drow * 16 + cur * ABUF + abase;
       // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
-      // would have used, so that the read group stays conflict-free
-      const int zr = zrow + cur * T16_ABUF + ((lr + drow) & 15) * 16;
+      // would have used, so that the read group stays conflict-free  (YM: the segments' own padding)
+      const int zr = zrow + cur * ABUF + ((lr + drow) & 15) * 16;
       const unsigned bit = 1u << tap;
       f16x8 fb[NB][2];
 #pragma unroll
@@ -468,10 +482,10 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
           const int mb = 4 * h + t;
           if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
           if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;  // the tap leaves the image: no work
-          const int ao = (amask[mb] & bit) ? shift + mb * 256 : zr;
+          const int ao = YM ? shift + mb * 512 : ((amask[mb] & bit) ? shift + mb * 256 : zr);
 #pragma unroll
           for (int part = 0; part < 2; ++part)
-            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * T16_PP));
+            fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * PP));
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -2317,13 +2331,28 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
   dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
   p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
-  constexpr size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
+  size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
   // waves 2 x 2 (template argument 2); the 1 x 4 arrangement of the same kernel measured 10 % slower
   static const char* noym = getenv("RAC_TILE_YMAJOR");
   const bool ym = a->W == 8 && p.tile_m == 2 * p.HW && !(noym && atoi(noym) == 0);  // 8x8 / 6x8 maps: skip vertical padding
   typedef void (*tile_fn)(Conv16P);
   const tile_fn fn = p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true> : (tile_fn)conv16_tile_kernel<2, true>)
                                      : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>);
+  if (ym) {
+    lds_tile = 2 * T16Y_ABUF;  // 65,536 B (+ 512 B static): two workgroups per CU
+    static bool ym_attr = false;
+    if (!ym_attr) {
+      for (tile_fn f : {(tile_fn)conv16_tile_kernel<2, true, true>, (tile_fn)conv16_tile_kernel<2, false, true>}) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           2 * T16Y_ABUF);
+        if (e != hipSuccess) {
+          set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+          return RAC_ELAUNCH;
+        }
+      }
+      ym_attr = true;
+    }
+  }
   hipLaunchKernelGGL(fn, grid, dim3(256), lds_tile, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_fwd_split(whole images)");
 }
