@@ -873,10 +873,17 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const float sa = pow2f(ka);
   const int halo = p.pad * p.W;
   const int nrows = TM + 2 * halo;       // staged pixel rows (a multiple of 16)
-  const int cplane = (nrows + 16) * 16;  // one 8-channel group: staged rows + 16 zero rows
+  // FAST (3 x 3): every staged image row sits in W + 2 LDS rows, a zero row either side, so a horizontal tap that leaves
+  // the image reads zeros by address: no per-lane validity mask / compare / select per (tap, block) -- as the tile
+  // kernel's padded segments.  Otherwise: the staged rows + 16 zero rows that the select points at.
+  const int WP = p.W + 2;
+  const int cplane = FAST ? (nrows / p.W) * WP * 16 : (nrows + 16) * 16;  // one 8-channel group
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;           // one buffer
-  {  // zero rows of both buffers: 2 buffers x 2 parts x 4 groups x 16 rows = 256 vectors
+  if constexpr (FAST) {
+    for (int o = tid * 16; o < 2 * abuf; o += 4096) *reinterpret_cast<u32x4*>(lds_raw + o) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();  // (the staging below writes some of the same rows from other threads)
+  } else {  // zero rows of both buffers: 2 buffers x 2 parts x 4 groups x 16 rows = 256 vectors
     const int pl = tid >> 4, r = tid & 15;
     *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * abuf + ((pl >> 2) & 1) * pplane + (pl & 3) * cplane +
                               (nrows + r) * 16) = u32x4{0u, 0u, 0u, 0u};
@@ -891,7 +898,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     const int g = v / nrows, row = v - g * nrows;
     s_grp[i] = g;
     s_row[i] = row;
-    s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
+    s_off[i] = g < 4 ? g * cplane + (FAST ? (row / p.W) * WP + 1 + row % p.W : row) * 16 : -1;
     const int y = y_tile - p.pad + row / p.W;
     s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
     s_pix[i] = m0 - halo + row;
@@ -911,6 +918,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   }
   const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;  // block t adds t * 256
   const int zrow = lq * cplane + nrows * 16;
+  int ablk[MB];  // FAST: block t's fragment base in the padded rows (a 16-pixel block lies inside one image row)
+#pragma unroll
+  for (int t = 0; t < MB; ++t) {
+    const int r0 = (wm * MB + t) * 16;
+    ablk[t] = lq * cplane + ((1 + r0 / p.W) * WP + 1 + r0 % p.W + lr) * 16;
+  }
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
   unsigned b_off[NT];
@@ -1006,9 +1019,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           // conv16_rows_persist_kernel does: +4 % on the 64-column form, nothing on the 128-column one -- not done.)
           __builtin_amdgcn_sched_barrier(0);
 #endif
-          const int drow = (ky - 1) * p.W + (kx - 1);
-          const int shift = drow * 16 + bufo + abase;
-          const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
+          const int shift = ((ky - 1) * WP + (kx - 1)) * 16 + bufo;  // wave-uniform: the tap in the padded rows
           f16x8 fb[NB][2];
 #pragma unroll
           for (int j2 = 0; j2 < NT; ++j2)
@@ -1020,8 +1031,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           f16x8 fa[MB][2];
 #pragma unroll
           for (int t = 0; t < MB; ++t) {
-            // the centre column needs no x test
-            const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+            const int ao = ablk[t] + shift;
 #pragma unroll
             for (int part = 0; part < 2; ++part)
               fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
@@ -1152,14 +1162,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   const int kw = scale_exp(*p.w_amax);
   const int halo = p.W;
   const int nrows = TM + 2 * halo;
-  const int cplane = (nrows + 16) * 16;
+  const int WP = p.W + 2;  // padded rows, as conv16_rows_kernel's unrolled form: a zero LDS row either side of an image row
+  const int cplane = (nrows / p.W) * WP * 16;
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;
-  {
-    const int pl = tid >> 4, r = tid & 15;
-    *reinterpret_cast<u32x4*>(lds_raw + (pl >> 3) * abuf + ((pl >> 2) & 1) * pplane + (pl & 3) * cplane +
-                              (nrows + r) * 16) = u32x4{0u, 0u, 0u, 0u};
-  }
+  for (int o = tid * 16; o < 2 * abuf; o += 4096) *reinterpret_cast<u32x4*>(lds_raw + o) = u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
   // tile-independent staging roles
   int s_off[NV], s_row[NV], s_grp[NV];
 #pragma unroll
@@ -1168,20 +1176,15 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
     const int g = v / nrows, row = v - g * nrows;
     s_grp[i] = g;
     s_row[i] = row;
-    s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
-  }
-  unsigned amask[MB];
-#pragma unroll
-  for (int t = 0; t < MB; ++t) {
-    const int r = (wm * MB + t) * 16 + lr;
-    const int x = r % p.W;
-    unsigned mk = 0;
-    for (int kx = 0; kx < 3; ++kx) mk |= ((unsigned)(x + kx - 1) < (unsigned)p.W) ? (1u << kx) : 0u;
-    amask[t] = mk;
+    s_off[i] = g < 4 ? g * cplane + ((row / p.W) * WP + 1 + row % p.W) * 16 : -1;
   }
   const int lq = lane >> 4;
-  const int abase = lq * cplane + (halo + wm * MB * 16 + lr) * 16;
-  const int zrow = lq * cplane + nrows * 16;
+  int ablk[MB];
+#pragma unroll
+  for (int t = 0; t < MB; ++t) {
+    const int r0 = (wm * MB + t) * 16;
+    ablk[t] = lq * cplane + ((1 + r0 / p.W) * WP + 1 + r0 % p.W + lr) * 16;
+  }
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
   unsigned b_off[NT];
@@ -1281,10 +1284,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   f16x8 fa[MB][2];
   auto read_frag = [&](int t, int tap, int bufo) {
     const int ky = tap / 3, kx = tap % 3;
-    const int drow = (ky - 1) * p.W + (kx - 1);
-    const int shift = drow * 16 + bufo + abase;
-    const int zr = zrow + bufo + ((lr + halo + drow) & 15) * 16;
-    const int ao = (kx == 1 || (amask[t] & (1u << kx))) ? shift + t * 256 : zr;
+    const int ao = ablk[t] + ((ky - 1) * WP + (kx - 1)) * 16 + bufo;
 #pragma unroll
     for (int part = 0; part < 2; ++part)
       fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
@@ -2295,7 +2295,10 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
     rows_fn fn = fns[width][nv - 2];
     const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast));
-    if (fast) fn = fast_fns[width][nv - 2];
+    if (fast) {
+      fn = fast_fns[width][nv - 2];
+      lds_rows = (size_t)2 * 2 * 4 * (nrows / a->W) * (a->W + 2) * 16;  // padded rows: W + 2 LDS rows per image row
+    }
     // narrow layers (64 / 32 columns), unsplit K, many more tiles than the chip holds: persistent workgroups that walk
     // the tiles and request the next tile's first chunk under the current tile's last one
     static const rows_fn persist_fns[2][3] = {
