@@ -306,6 +306,9 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 // the block's fragment reads and MFMAs are skipped -- 15 % of a 5x5 conv's products on 8-row maps (image rows 0, 1, 6, 7
 // lose 2, 1, 1, 2 of their 5 kernel rows), 8 % of a 3x3 conv's -- instead of multiplying zero rows.  A tap's shift
 // stays one wave-uniform offset (16 rows per image row); the epilogue maps rows back to the tensor's (image, y, x) order.
+#ifndef RAC_TILE_READ_ALL
+#define RAC_TILE_READ_ALL 0
+#endif
 template <int WM, bool FULL, bool YM = false>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;   // waves along the columns
@@ -481,7 +484,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
           if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
+#if !RAC_TILE_READ_ALL  // (reading dead blocks too -- straight-line LDS traffic, exact waits -- measured +0 % on 5x5, +1 % on 3x3)
           if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;  // the tap leaves the image: no work
+#endif
           const int ao = YM ? shift + mb * 512 : ((amask[mb] & bit) ? shift + mb * 256 : zr);
 #pragma unroll
           for (int part = 0; part < 2; ++part)
