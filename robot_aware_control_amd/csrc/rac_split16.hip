@@ -115,11 +115,15 @@ struct Conv16P {
 // The 16 lanes of a ds_read_b128 group touch 16 distinct rows mod 16 = 16 distinct bank slots; a tap shift is one
 // wave-uniform byte offset.
 constexpr int T16_CP = 144 * 16, T16_PP = 4 * T16_CP, T16_ABUF = 2 * T16_PP;
-// The y-major form (W = 8, two images per tile) pads every image-row segment to 16 slots -- LDS row 32 y + 16 i + 4 + x,
-// slots 0..3 and 12..15 zeros: a horizontal tap that leaves the image reads the padding, so a fragment address is the
-// lane's constant + one wave-uniform tap offset + an immediate per block: no per-lane validity mask, compare and select
-// (12 of the ~38 VALU instructions per 48 MFMAs).  256 rows per plane, 32 KB per buffer.
-constexpr int T16Y_CP = 256 * 16, T16Y_PP = 4 * T16Y_CP, T16Y_ABUF = 2 * T16Y_PP;
+// The y-major form (W = 8, two images per tile) keeps zero slots beside every image-row segment -- image row y of image i
+// sits in LDS rows 36 y + (2 | 26) + x, two zero rows either side of each segment: a horizontal tap that leaves the
+// image reads the padding, so a fragment address is the lane's constant + one wave-uniform tap offset + an immediate per
+// block: no per-lane validity mask, compare and select (12 of the ~38 VALU instructions per 48 MFMAs).  The second
+// image's segment starts 24 rows after the first's (= 8 mod 16): the 16 lanes of a read group still touch 16 distinct
+// 16-byte slots mod 256 B (a 16-row pitch put both segments on the same slots: 2-way bank conflicts on every read,
+// SQ_LDS_BANK_CONFLICT = half of the active LDS cycles).  288 rows per plane, 36 KB per buffer.
+constexpr int T16Y_PITCH = 36, T16Y_S0 = 2, T16Y_S1 = 26;
+constexpr int T16Y_CP = 8 * T16Y_PITCH * 16, T16Y_PP = 4 * T16Y_CP, T16Y_ABUF = 2 * T16Y_PP;
 
 // Epilogue of both kernels: undo the two operand scales, then as rac_conv2d FWD (bias, fp64 BatchNorm statistics of the
 // biased value, folded eval-BatchNorm scale / shift, activation, max |v|) -- or the raw partial sums of a K split.
@@ -341,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   // the accumulator row of the staged pixel: its tile row, or (YM) 16 y + 8 image + x ...
   const int lrow = (YM && srow < TM) ? ((srow % p.HW) >> 3) * 16 + (srow / p.HW) * 8 + (srow & 7) : srow;
   // ... and its LDS row: the same, or (YM) 32 y + 16 image + 4 + x (padded segments)
-  const int srow_lds = YM ? ((srow % p.HW) >> 3) * 32 + (srow / p.HW) * 16 + 4 + (srow & 7) : srow;
+  const int srow_lds = YM ? ((srow % p.HW) >> 3) * T16Y_PITCH + (srow / p.HW ? T16Y_S1 : T16Y_S0) + (srow & 7) : srow;
   __shared__ float ia_sh[128];  // per-image scales: 1 / scale of every tile row's image
   unsigned am;
   if (p.per_image) {  // the scale of the image this thread's staged row belongs to
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const float sa = pow2f(ka);
   if constexpr (YM) {  // everything: the padding slots (and the rows of a short tile) are never written again
 #pragma unroll
-    for (int i = 0; i < 2 * ABUF / (256 * 16); ++i)
+    for (int i = 0; i < 2 * ABUF / (256 * 16); ++i)  // (2 * ABUF = 18 * 4096)
       *reinterpret_cast<u32x4*>(lds_raw + (i * 256 + tid) * 16) = u32x4{0u, 0u, 0u, 0u};
     __syncthreads();  // (the staging below writes some of the same slots from other threads)
   } else {  // zero rows 128..143 of every chunk plane of both buffers: 2 * 2 * 4 * 16 = 256 vectors
@@ -382,8 +386,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     }
     amask[t] = mk;
   }
-  // fragment base of the lane: block t adds t * 256 -- (YM) image row wm * RB + t: t * 512
-  const int abase = YM ? lq * CP + (wm * RB * 32 + 16 * (lr >> 3) + 4 + (lr & 7)) * 16 : lq * CP + (wm * RB * 16 + lr) * 16;
+  // fragment base of the lane: block t adds t * 256 -- (YM) image row wm * RB + t: t * 16 T16Y_PITCH
+  const int abase = YM ? lq * CP + (wm * RB * T16Y_PITCH + (lr >> 3 ? T16Y_S1 : T16Y_S0) + (lr & 7)) * 16
+                       : lq * CP + (wm * RB * 16 + lr) * 16;
   const int zrow = lq * CP + 128 * 16;
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
       const bool more = kc + 1 < kc_end;
       if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
       fresh = false;
-      const int drow = (ky - p.pad) * (YM ? 32 : p.W) + (kx - p.pad);
+      const int drow = (ky - p.pad) * (YM ? T16Y_PITCH : p.W) + (kx - p.pad);
       const int shift = drow * 16 + cur * ABUF + abase;
       // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
       // would have used, so that the read group stays conflict-free  (YM: the segments' own padding)
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #if !RAC_TILE_READ_ALL  // (reading dead blocks too -- straight-line LDS traffic, exact waits -- measured +0 % on 5x5, +1 % on 3x3)
           if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;  // the tap leaves the image: no work
 #endif
-          const int ao = YM ? shift + mb * 512 : ((amask[mb] & bit) ? shift + mb * 256 : zr);
+          const int ao = YM ? shift + mb * (16 * T16Y_PITCH) : ((amask[mb] & bit) ? shift + mb * 256 : zr);
 #pragma unroll
           for (int part = 0; part < 2; ++part)
             fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * PP));
@@ -882,7 +887,8 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   // the image reads zeros by address: no per-lane validity mask / compare / select per (tap, block) -- as the tile
   // kernel's padded segments.  Otherwise: the staged rows + 16 zero rows that the select points at.
   const int WP = p.W + 2;
-  const int cplane = FAST ? (nrows / p.W) * WP * 16 : (nrows + 16) * 16;  // one 8-channel group
+  // one 8-channel group; (FAST) rounded to 256 B: the four k-groups of a read must start on the same 16-byte slot
+  const int cplane = FAST ? (((nrows / p.W) * WP + 15) & ~15) * 16 : (nrows + 16) * 16;
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;           // one buffer
   if constexpr (FAST) {
@@ -1168,7 +1174,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   const int halo = p.W;
   const int nrows = TM + 2 * halo;
   const int WP = p.W + 2;  // padded rows, as conv16_rows_kernel's unrolled form: a zero LDS row either side of an image row
-  const int cplane = (nrows / p.W) * WP * 16;
+  const int cplane = (((nrows / p.W) * WP + 15) & ~15) * 16;  // (a multiple of 256 B, as there)
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;
   for (int o = tid * 16; o < 2 * abuf; o += 4096) *reinterpret_cast<u32x4*>(lds_raw + o) = u32x4{0u, 0u, 0u, 0u};
@@ -2302,7 +2308,8 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast));
     if (fast) {
       fn = fast_fns[width][nv - 2];
-      lds_rows = (size_t)2 * 2 * 4 * (nrows / a->W) * (a->W + 2) * 16;  // padded rows: W + 2 LDS rows per image row
+      // padded rows: W + 2 LDS rows per image row, the plane rounded to 256 B
+      lds_rows = (size_t)2 * 2 * 4 * ((((nrows / a->W) * (a->W + 2)) + 15) & ~15) * 16;
     }
     // narrow layers (64 / 32 columns), unsplit K, many more tiles than the chip holds: persistent workgroups that walk
     // the tiles and request the next tile's first chunk under the current tile's last one
@@ -2347,7 +2354,7 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   const tile_fn fn = p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true> : (tile_fn)conv16_tile_kernel<2, true>)
                                      : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>);
   if (ym) {
-    lds_tile = 2 * T16Y_ABUF;  // 65,536 B (+ 512 B static): two workgroups per CU
+    lds_tile = 2 * T16Y_ABUF;  // 73,728 B (+ 512 B static): two workgroups per CU
     static bool ym_attr = false;
     if (!ym_attr) {
       for (tile_fn f : {(tile_fn)conv16_tile_kernel<2, true, true>, (tile_fn)conv16_tile_kernel<2, false, true>}) {
