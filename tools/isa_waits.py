@@ -32,6 +32,10 @@ def kernels(lines):
 def analyse(body):
     vm, lds, mf = [], [], 0
     hist = {"vmcnt": collections.Counter(), "lgkmcnt": collections.Counter()}
+    idx = [i for i, l in enumerate(body) if l.strip().startswith("v_mfma")]
+    if not idx:
+        return 0, hist
+    body = body[max(0, idx[0] - 200):idx[-1] + 1]  # the MFMA region (and the loads issued just ahead of it)
     for l in body:
         t = l.strip()
         if not t or t[0] in ";.":
@@ -40,9 +44,9 @@ def analyse(body):
             mf += 1
         elif t.startswith(("buffer_load", "global_load")):
             vm.append(mf)
-        elif t.startswith(("ds_read", "ds_load")):
+        elif t.startswith(("ds_", "s_load", "s_buffer_load")):  # everything lgkmcnt counts (LDS both ways, scalar loads)
             lds.append(mf)
-        elif t.startswith("s_waitcnt"):
+        elif t.startswith("s_waitcnt") and mf:
             for name, issued in (("vmcnt", vm), ("lgkmcnt", lds)):
                 m = re.search(name + r"\((\d+)\)", t)
                 if m and len(issued) > int(m.group(1)):
