@@ -316,13 +316,21 @@ class SVGConvModel(nn.Module):
         # weight and bias next to bias: stacked along Cout they are ONE conv (ops.GaussHead)
         heads = [m for m in self.modules() if isinstance(m, _GaussianConvLSTM)]
         paired = {id(p) for m in heads for c in (m.mu_net, m.logvar_net) for p in (c.weight, c.bias)}
-        order = [p for p in params if id(p) not in paired]
+        # ... and that the large conv weights come LAST: zero_grad(lazy=True) zeroes only the region before them
+        lazy = [p for p in params if id(p) not in paired and p.dim() == 4 and p.numel() >= (1 << 16)]
+        lazy_ids = {id(p) for p in lazy}
+        order = [p for p in params if id(p) not in paired and id(p) not in lazy_ids]
         for m in heads:
             order += [m.mu_net.weight, m.logvar_net.weight, m.mu_net.bias, m.logvar_net.bias]
         total = 0
-        for p in order:
+        for p in order + lazy:
+            if lazy and p is lazy[0]:
+                self._lazy_start = total
             p._rac_off = total
             total += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        if not lazy:
+            self._lazy_start = total
+        self._lazy_params = lazy
         flat = torch.zeros(total, device=dev, dtype=torch.float32)
         grad = torch.zeros(total, device=dev, dtype=torch.float32)
         with torch.no_grad():
@@ -356,15 +364,24 @@ class SVGConvModel(nn.Module):
     def flat_parameters(self):
         return self._flat, self._flat_grad
 
-    def zero_grad(self, set_to_none: bool = False):
-        """Gradients are accumulated in place by the kernels: zero the flat buffer, keep the views attached."""
+    def zero_grad(self, set_to_none: bool = False, lazy: bool = False):
+        """Gradients are accumulated in place by the kernels: zero the flat buffer, keep the views attached.
+        `lazy` (PredictionTrainer._train_step): the large conv weights' gradients are only marked stale -- their
+        weight-gradient launch overwrites them, `ops.finish_grads()` zeroes what nothing wrote (ops._STALE)."""
         if self._flat_grad is None:
             self._flatten()
-        self._flat_grad.zero_()
+        ops._STALE.clear()
+        if lazy and self._lazy_params:
+            self._flat_grad[:self._lazy_start].zero_()
+        else:
+            self._flat_grad.zero_()
         for p in self.parameters():
             off = p._rac_off
             if p.grad is None or p.grad.data_ptr() != self._flat_grad.data_ptr() + 4 * off:
                 p.grad = torch.as_strided(self._flat_grad, p.shape, p.stride(), off)
+        if lazy:
+            for p in self._lazy_params:
+                ops.mark_stale(p.grad)
 
     def train(self, mode: bool = True):
         for m in self.modules():

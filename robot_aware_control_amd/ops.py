@@ -48,10 +48,35 @@ def weight_mem(w: torch.Tensor) -> torch.Tensor:
     return w
 
 
+# Lazy zero_grad (the trainer's step only): the large conv weights' gradients are NOT zeroed at the start of a step --
+# their one time-batched weight-gradient launch WRITES them (rac_wgrad_args.accumulate = 0) instead of adding to zeros,
+# which saves the 954 MB fill and the read half of the read-modify-write.  A buffer listed here is "stale": whoever
+# touches it first either overwrites it whole (conv_wgrad_split_acc) or zeroes it on the spot (grad_buffer);
+# finish_grads() zeroes what nobody wrote, before anything reads gradients.
+_STALE = {}
+LAZY_ZERO_GRAD = os.environ.get("RAC_LAZY_ZERO_GRAD", "1") == "1"
+
+
+def mark_stale(g: torch.Tensor) -> None:
+    _STALE[g.data_ptr()] = g
+
+
+def take_stale(g: torch.Tensor) -> bool:
+    return bool(_STALE) and _STALE.pop(g.data_ptr(), None) is not None
+
+
+def finish_grads() -> None:
+    for g in _STALE.values():
+        g.zero_()
+    _STALE.clear()
+
+
 def grad_buffer(p: torch.Tensor) -> torch.Tensor:
-    """`p.grad`, allocated (zeroed, same strides) on first use."""
+    """`p.grad`, allocated (zeroed, same strides) on first use -- and zeroed now if a lazy zero_grad left it stale."""
     if p.grad is None:
         p.grad = torch.zeros_like(p)  # preserve_format keeps the channels_last strides
+    elif _STALE and take_stale(p.grad):
+        p.grad.zero_()
     return p.grad
 
 
@@ -941,9 +966,13 @@ def _wgrad_split_batch(items, weight):
         Cin = C0
     sp = stream_ptr()
     dev = dy.device
+    fresh = False
     if Cin != ci_real:
         g = torch.empty((Cout, k, k, Cin), device=dev, dtype=torch.float32)  # the first launch writes (accumulate 0)
     else:
+        # a stale buffer (lazy zero_grad) is overwritten whole by the first launch: every element of dw is stored by the
+        # K split 0 workgroup of its tile, with or without time steps to sum
+        fresh = weight.grad is not None and take_stale(weight.grad)
         g = weight_mem(grad_buffer(weight))
     n = Cout * k * k * Cin
     tiles = _cdiv(Cout, 128) * (_cdiv(C0, 64) + _cdiv(Cin - C0, 64)) * k
@@ -972,7 +1001,7 @@ def _wgrad_split_batch(items, weight):
             ns = plan_wgrad_split(tiles, T * _cdiv(B * H, 32))
         slabs = torch.empty((ns - 1, n), device=dev, dtype=torch.float32) if ns > 1 else None
         a = WgradArgs(B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, a_split=C0, T=T, nsplit=ns,
-                      accumulate=0 if (Cin != ci_real and lo == 0) else 1,
+                      accumulate=0 if ((Cin != ci_real or fresh) and lo == 0) else 1,
                       dw=ptr(g), slabs=ptr(slabs), slab_stride=n, x1_zero_steps=n_zero, presplit=0,
                       all_ky=1 if all_ky else 0, col_segments=nseg)
         for t, (dy_t, x0_t, x1_t) in enumerate(chunk):

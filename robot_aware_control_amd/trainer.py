@@ -234,7 +234,8 @@ class PredictionTrainer(object):
 
         ops.begin_step(x.device)
         self._mark("start")
-        self.model.zero_grad()
+        # (lazy: the large conv weights' gradients are written, not added to zeros, by their one launch per step)
+        self.model.zero_grad(lazy=ops.LAZY_ZERO_GRAD)
         bs = min(cf.batch_size, x.shape[1])
         self.model.init_hidden(bs)
         dontcare = "dontcare" in cf.reconstruction_loss or cf.black_robot_input
@@ -317,6 +318,7 @@ class PredictionTrainer(object):
         with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
             torch.autograd.backward(roots, seeds)
             self._mark("backward")
+        ops.finish_grads()  # a weight no launch wrote this step (none in the standard configurations) gets its zeros now
         self._mark("weight_grads")
         if reducer is not None:
             reducer.finish()

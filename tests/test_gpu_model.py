@@ -424,6 +424,33 @@ def test_cem_rollouts_48x64_vs_oracle(dev, ra):
     assert err < 1e-5, err
 
 
+def test_lazy_zero_grad_leaves_no_stale_gradient(dev):
+    """zero_grad(lazy=True) only marks the large conv weights' gradients stale (their weight-gradient launch overwrites
+    them); a gradient nobody writes is zeroed by finish_grads(), one touched through grad_buffer() on the spot, and a
+    plain zero_grad() forgets the marks."""
+    from robot_aware_control_amd import ops
+    cfg = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, **FLAGSETS["vanilla"])
+    model = build_model(cfg, orc.make_weights(cfg, seed=1), dev, train=True)
+    _, flat_grad = model.flat_parameters()
+    big = model._lazy_params
+    assert big and all(p.dim() == 4 for p in big) and model._lazy_start == min(p._rac_off for p in big)
+    flat_grad.fill_(7.0)
+    model.zero_grad(lazy=True)
+    assert float(flat_grad[:model._lazy_start].abs().max()) == 0.0 and float(flat_grad[model._lazy_start:].min()) == 7.0
+    assert len(ops._STALE) == len(big)
+    g0 = ops.grad_buffer(big[0])                       # a writer that adds: zeroed on the spot
+    assert float(g0.abs().max()) == 0.0 and len(ops._STALE) == len(big) - 1
+    assert ops.take_stale(big[1].grad) and not ops.take_stale(big[1].grad)   # a writer that overwrites takes the mark
+    big[1].grad.fill_(3.0)
+    ops.finish_grads()                                  # the rest: nobody wrote them
+    assert not ops._STALE and float(big[1].grad.min()) == 3.0
+    assert all(float(p.grad.abs().max()) == 0.0 for p in big[2:])
+    flat_grad.fill_(7.0)
+    model.zero_grad(lazy=True)
+    model.zero_grad()
+    assert not ops._STALE and float(flat_grad.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("kind", ["vanilla", "mask_common", "mask_differs"])
 def test_cem_shared_start_frame_is_the_same_bits(dev, kind):
     """Planner step 0 encodes the shared start frame once (`cem_shared_start`) and copies the maps to the candidates:
