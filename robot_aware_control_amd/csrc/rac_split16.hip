@@ -98,7 +98,9 @@ struct Conv16P {
   long stats_rows;
   int M, N, HW, P, taps, cchunks, nchunks, cps;
   int w_nchunks;  // chunk-taps per 32-column tile in the weight parts (>= nchunks: the conv may use a channel prefix)
-  int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2)
+  int xcd_group;  // remap workgroup ids so that the M-tiles sharing one weight slab run on one XCD (one L2).  (Only when
+                  // the (N-tile, K-split) groups are a multiple of 8; giving the narrow layers' 1 / 2 / 4 groups 8 / groups
+                  // XCDs each measured +0.5 % on a planner iteration: their slabs stream from the MALL just as well.)
   int tile_m;     // output rows per workgroup (whole images / whole image rows, a multiple of 16, <= 128)
   int n_store;    // columns stored and row stride of the output: N, or fewer when the weight rows are zero-padded to 32
   int a0_up;      // rows kernel: a0 is the half-resolution tensor, read at (y / 2, x / 2) (nearest 2x upsampling)
