@@ -139,6 +139,34 @@ def test_convT_head(dev, B, H, W, Ci, monkeypatch):
     assert relerr(bd.grad.cpu(), b.grad) < 2e-5
 
 
+def test_first_layer_and_head_on_constant_inputs(dev):
+    """Edge cases of the two matrix-pipe frame kernels' self-made operand scales: an all-zero frame (every pixel's own
+    maximum is 0: scale 1, output = act(shift)), a frame of ones next to it in the batch, and an all-zero head input
+    (output = sigmoid(bias)); one huge pixel does not cost its neighbours precision (per-pixel scales)."""
+    from robot_aware_control_amd import ops
+    w = rnd(5, 64, 3, 3, 3) * 0.2
+    scale, shift = rnd(6, 64).abs() + 0.5, rnd(7, 64, scale=0.3)
+    img = torch.zeros(3, 3, 32, 32)
+    img[1] = 1.0
+    img[2] = torch.rand(3, 32, 32, generator=torch.Generator().manual_seed(1)) * 1e-3
+    img[2, :, 7, 9] = 5e4                                     # 5e7 times its neighbours
+    ref = F.leaky_relu(F.conv2d(img.double(), w.double(), None, 1, 1) * scale.double().view(1, -1, 1, 1)
+                       + shift.double().view(1, -1, 1, 1), 0.2)
+    out = from_map(ops.first_layer_frozen(img.to(dev), None, None, cl_weight(w).to(dev), scale.to(dev), shift.to(dev)))
+    assert torch.equal(out[0], F.leaky_relu(shift.view(-1, 1, 1).expand(64, 32, 32), 0.2))
+    assert relerr(out[1], ref[1]) < 2e-6
+    far = torch.ones(32, 32, dtype=torch.bool)
+    far[5:10, 7:12] = False                                   # pixels whose 3 x 3 window does not see the huge one
+    assert float(((out[2].double() - ref[2]).abs()[:, far] / ref[2].abs()[:, far].clamp_min(1e-3)).max()) < 2e-6
+    assert relerr(out[2], ref[2]) < 2e-6
+    wh = (rnd(2, 64, 4, 3, 3) * 0.05)
+    b = rnd(3, 4, scale=0.1)
+    x = torch.zeros(2, 16, 16, 64, device=dev)
+    with torch.no_grad():
+        y = ops.ConvTHead.apply(x, cl_weight(wh).to(dev), b.to(dev), True)
+    assert torch.allclose(y.cpu(), torch.sigmoid(b).view(1, 1, 1, 4).expand(2, 16, 16, 4), atol=1e-7)
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 16, 64, 0, 128), (16, 8, 8, 256, 0, 512), (2, 32, 32, 128, 128, 64),
                                    (2, 64, 64, 5, 0, 64)])
 def test_vgg_layer_train_and_eval(dev, shape):
