@@ -77,6 +77,18 @@ def host_threads():
     return max(1, min(n, 16))
 
 
+def cpu_model():
+    """CPU model string of this host (BASELINE.md 4 asks for it beside the core count)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def barrier_sync(distributed):
     torch.cuda.synchronize()
     if distributed:
@@ -274,20 +286,37 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
                    lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic",
                    cem_shared_start=not args.no_cem_shared_start, **flags)
     model = SVGConvModel(cf)
-    model.load_state_dict(syn.synth_state_dict(model, seed=12))
+    # (action channels amplified 1000x: the eight graded candidates' costs then sit >= 1e-3 apart, relative)
+    model.load_state_dict(syn.synth_state_dict(model, seed=12, action_gain=1000.0))
     if exact_of is not None and exact_of["check"] is not None:
         model.load_state_dict({k: v.clone() for k, v in exact_of["check"]["sd"].items()})
     if distributed:
         dist.broadcast(model.flat_parameters()[0], src=0)
     model.eval()
     N = n_per_gpu * world
-    prob = syn.synth_cem_problem(seed=0, N=N, T=horizon - 1)
+    demo = None
+    if ra:
+        prob = syn.synth_cem_problem(seed=0, N=N, T=horizon - 1)
+    else:
+        # the planning problem with well-separated elites (K / K+1 cost gap >= 1e-3; the fixture of
+        # tests/test_gpu_fullsize.py): eight graded blends towards a demonstration among the N candidates, the per-step
+        # goal images = the model's own rollout of that demonstration (rolled out below, outside the timed region)
+        prob, demo = syn.demo_problem(False, N, horizon - 1, seed=0)
+        prob["actions"] = prob["actions"][:N].contiguous()
     robot = SyntheticRobotInputs(dev) if ra else None
     pol = CEMPolicy(cf, model, horizon=horizon, opt_iter=10, action_candidates=N, topk=5, init_std=0.015,
                     robot_model=robot)
     start = State(img=prob["start_img"], state=np.array([0.28, 0.0, 0.12, 0.0, 0.0], np.float32),
                   qpos=np.zeros(5, np.float32))
     goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+    if demo is not None:
+        if exact_of is not None and exact_of["check"] is not None:  # the split run's goal frames: same problem
+            prob["goal_imgs"] = exact_of["check"]["prob"]["goal_imgs"]
+        else:
+            obs = pol.traj_sampler.generate_model_rollouts(demo[None].clone(), start, goal, ret_obs=True)["obs"][0]
+            prob["goal_imgs"] = syn.frames_to_goal_images(obs)
+        prob["goal_masks"] = [prob["goal_masks"][0]] * (horizon - 1)
+        goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     g = cf.g_dim
     tag = ("cem-ra" if ra else "cem") + ("" if exact_of is None else " (exact fp32)")
     log(f"{tag}: model built, {N} candidates")
@@ -353,7 +382,7 @@ def cpu_baseline(train, cem):
     from oracle import svg_oracle as orc
     torch.set_num_threads(host_threads())
     cores = torch.get_num_threads()
-    out = {"unit": "frames/s", "cores": cores, "kind": "port", "checked": {}}
+    out = {"unit": "frames/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port", "checked": {}}
     sample = []
     if train is not None and train["check"] is not None:
         ck, cf = train["check"], train["cf"]
@@ -384,6 +413,10 @@ def cpu_baseline(train, cem):
                        model_use_mask=False, model_use_future_mask=False, model_use_robot_state=False,
                        reconstruction_loss="l1")
         prob = ck["prob"]
+        # warm the CPU leg (thread pool, conv primitive caches) on two candidates x two steps before the timed pass
+        wcfg = orc.Cfg(**{**ccfg.__dict__, "batch_size": 2, "candidates_batch_size": 2})
+        orc.cem_rollouts(ck["sd"], wcfg, prob["actions"][idx[:2], :2], prob["start_img"], prob["goal_imgs"][:2],
+                         prob["goal_masks"][:2])
         t0 = time.perf_counter()
         ref = orc.cem_rollouts(ck["sd"], ccfg, prob["actions"][idx], prob["start_img"], prob["goal_imgs"],
                                prob["goal_masks"])["sum_cost"]
@@ -392,20 +425,21 @@ def cpu_baseline(train, cem):
         err = float(np.abs(ck["gpu_sum_cost"] - ref).max() / np.abs(ref).max())
         assert err <= 1e-5, ("GPU rollout costs drifted from the oracle", err)
         out["checked"]["cem_sum_cost_rel_err"] = err
-        # elite set: the oracle's ranking of the GPU's top 32 must start with the GPU's top 5, in order, wherever
-        # neighbours are further apart than the error (this synthetic goal is far from every rollout: costs differ by
-        # ~1e-4 relative, SURVEY.md 7 "hard parts"; tests/test_gpu_fullsize.py pins a fixture with gaps >= 1e-2)
+        # elite set (north_star: "CEM elite indices are bit-exact"): on this fixture the GPU's ranks 1..6 are >= 1e-3 apart
+        # (asserted), so the oracle's ranking of the GPU's top 32 must start with the GPU's top 5, indices AND order --
+        # unconditionally
         top_ref = idx[np.argsort(-ref, kind="stable")][:5]
         g = np.sort(ck["gpu_sum_cost"])[::-1]
-        gaps = (g[:5] - g[1:6]) / np.abs(ref).max()
-        agree = [int(a) == int(b) for a, b in zip(top_ref, ck["gpu_top"])]
-        out["checked"]["cem_top5_identical"] = bool(all(agree))
+        gaps = (g[:5] - g[1:6]) / np.abs(g[1:6])
+        out["checked"]["cem_top5_identical"] = bool(all(int(a) == int(b) for a, b in zip(top_ref, ck["gpu_top"])))
         out["checked"]["cem_top5_min_gap_rel"] = float(gaps.min())
-        assert all(a or gap <= 10 * err for a, gap in zip(agree, np.minimum(gaps, np.r_[np.inf, gaps[:-1]]))), \
-            ("GPU elite set differs from the oracle's beyond rounding", top_ref, ck["gpu_top"], gaps, err)
+        out["checked"]["cem_rank5_rank6_gap_rel"] = float(gaps[4])
+        out["checked"]["cem_fixture"] = "synthetic.demo_problem: graded blends towards a demonstration whose rollout is the goal"
+        assert gaps.min() >= 1e-3, ("the benchmark's planning fixture no longer separates its elites", gaps)
+        assert out["checked"]["cem_top5_identical"], ("GPU elite set differs from the oracle's", top_ref, ck["gpu_top"], gaps, err)
         out["cem_value"], out["cem_unit"] = n / t_cem, "candidate-rollouts/s"
         sample.append(f"cem: {n} of the 1000 candidates (the GPU's top {CEM_CHECK_TOP} + {CEM_CHECK_OTHERS} others) x 14 "
-                      f"steps in one pass ({t_cem:.1f} s)")
+                      f"steps in one pass ({t_cem:.1f} s, after a 2-candidate x 2-step warm-up pass)")
         if "value" not in out:
             out["value"], out["unit"] = out["cem_value"], out["cem_unit"]
     out["sample"] = "; ".join(sample)
@@ -470,6 +504,8 @@ def main():
                     help="train workload on 48x64 frames, the reference's default --image_height (not the headline)")
     ap.add_argument("--cfg5", action="store_true",
                     help="train workload at BASELINE configs[4] per-GPU size (128x128, bs 8, n_future 10); not the headline")
+    ap.add_argument("--no-side", action="store_true", help="skip the configs[4] per-GPU side line (`side.cfg5`)")
+    ap.add_argument("--side-steps", type=int, default=5, help="timed steps of the configs[4] per-GPU side line")
     ap.add_argument("--group-norm", action="store_true",
                     help="both workloads with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
     args = ap.parse_args()
@@ -477,7 +513,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    distributed = world > 1
+    # (RAC_DIST_FORCE=1: a one-rank process group -- every collective of the path runs through RCCL on a one-GPU box)
+    distributed = world > 1 or os.environ.get("RAC_DIST_FORCE", "0") == "1"
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     backend = os.environ.get("RAC_DIST_BACKEND", "nccl")  # "gloo" + RAC_BENCH_ONE_GPU=1: rehearse N ranks on one GPU
     if os.environ.get("RAC_BENCH_ONE_GPU") == "1":
@@ -510,6 +547,21 @@ def main():
         if not args.no_cem_ra and not args.group_norm:
             cem_ra = bench_cem(args, dev, rank, world, distributed, ra=True)
             torch.cuda.empty_cache()
+    side = None
+    if train is not None and not args.no_side and not (args.h48 or args.cfg5 or args.group_norm):
+        # BASELINE configs[4] per GPU (128x128 frames, bs 8, n_future 10: the shard one of 8 DDP ranks trains on), driver-timed
+        sa = argparse.Namespace(**vars(args))
+        sa.cfg5, sa.steps, sa.warmup = True, args.side_steps, 2
+        st = bench_train(sa, dev, rank, world, distributed)
+        torch.cuda.empty_cache()
+        side = {"cfg5": {"value": st["frames_per_s"], "unit": "frames/s", "ms_per_step": st["ms_per_step"],
+                         "steps": st["steps"], "warmup": 2,
+                         "config": {"workload": st["workload"], "global_batch": st["global_batch"],
+                                    "parallelism": f"ddp{world}",
+                                    "algorithmic_tflop_per_step_per_gpu": st["step_tflop"]},
+                         "step_achieved": st["step_tflops_per_gpu"], "step_peak": SPLIT_PEAK_TFLOPS,
+                         "step_frac": st["step_tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
+                         "time_breakdown_ms": st["phases"]}}
     exact = arith_err = None
     if not args.no_exact and not (args.h48 or args.cfg5 or args.group_norm):
         exact, arith_err = exact_fp32_runs(args, dev, rank, world, distributed, train, cem)
@@ -589,6 +641,8 @@ def main():
         if distributed:
             out["cem_ra"]["ranks"] = {"s_per_iteration": cem_ra["rank_s_per_iter"],
                                       "cost_allgather_ms": cem_ra["cost_allgather_ms"]}
+    if side is not None:
+        out["side"] = side
     if exact is not None:
         out["fp32_exact"] = exact
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -10,6 +10,7 @@ import torch
 import torch.distributed as dist
 from torch.distributions.normal import Normal
 
+from . import parallel_env
 from .state import DemoGoalState, State
 from .trajectory_sampler import TrajectorySampler
 
@@ -49,7 +50,7 @@ class CEMPolicy(object):
             act_seq = mean + std * noise
         else:
             act_seq = Normal(mean, std).sample((N,))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if parallel_env.active():
             dev = torch.device(self.cfg.device)
             buf = act_seq.to(dev) if dist.get_backend() == "nccl" else act_seq.clone()
             dist.broadcast(buf, src=0)
@@ -103,9 +104,11 @@ class SimCEMPolicy(CEMPolicy):
     src/cem/pick/cem.py): `CEMPolicy(cfg, physics="learned", horizon, opt_iter, action_candidates, topk, init_std)`
     loads the model itself from `cfg.dynamics_model_ckpt` and clamps actions to [-1, 1]; `action_dim` is 2 (push)
     or 4 (pick).  Only the `physics="learned"` branch runs here -- `"gt"` steps MuJoCo on the CPU and is outside
-    the accelerated path.  Per-candidate masks/states come from `robot_model` (see TrajectorySampler)."""
+    the accelerated path.  The DEFAULT is the reference's (`physics="gt"`, push/cem.py:24): a caller that relies on it
+    gets the clear NotImplementedError below, never silently the other branch.  Per-candidate masks/states come from
+    `robot_model` (see TrajectorySampler)."""
 
-    def __init__(self, cfg, physics="learned", horizon=5, opt_iter=10, action_candidates=100, topk=5, init_std=1.0,
+    def __init__(self, cfg, physics="gt", horizon=5, opt_iter=10, action_candidates=100, topk=5, init_std=1.0,
                  action_dim=2, robot_model=None, model=None):
         if physics != "learned":
             raise NotImplementedError("physics='gt' rolls candidates through MuJoCo on the CPU (reference "

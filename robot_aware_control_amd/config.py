@@ -106,6 +106,7 @@ _COMPAT = [("stoch", B, False), ("multiview", B, False)]
 _NATIVE = [("ddp_bucket_mb", I, 64), ("cem_shard", B, True),
            ("cem_exact_elites", I, 0),  # re-roll the M best candidates of an atlas pass with exactly rendered masks
            ("cem_shared_start", B, True),  # planner step 0: encode the (shared) start frame once, not per candidate
+           ("ddp_shard_optimizer", B, False),  # DDP: reduce-scatter + Adam on 1/world slices + parameter all-gather
            ("plot", B, False)]          # write the per-epoch generation GIFs of PredictionTrainer.plot
 
 

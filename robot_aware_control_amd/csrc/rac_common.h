@@ -6,6 +6,17 @@
 
 #include "rac_hip.h"
 
+// No v_pk_{mul,add,fma}_f32 in DEVICE code: the compiler's packed form of an fp32 inner product (broadcast operand through
+// op_sel) was not reproducible when several processes shared the GPU (profiles/r03_pk_fma_experiment.md); the
+// scalar forms measure the same on the train step and the planner.  A function attribute of the device pass only (the
+// host pass of the same translation unit never sees an AMDGPU feature name); every .hip file ends with RAC_DEVICE_CODE_END.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#define RAC_DEVICE_CODE_END _Pragma("clang attribute pop")
+#else
+#define RAC_DEVICE_CODE_END
+#endif
+
 namespace rac {
 
 void set_error(const char* fmt, ...);

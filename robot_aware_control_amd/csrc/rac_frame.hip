@@ -793,3 +793,5 @@ extern "C" int rac_psnr_ssim(const float* a, const float* b, const float* mask, 
                      mask, sq_err, ssim_sum, ssim_map, H, W, tx, win);
   return check_launch("rac_psnr_ssim");
 }
+
+RAC_DEVICE_CODE_END

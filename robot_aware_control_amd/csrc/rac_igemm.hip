@@ -849,3 +849,5 @@ extern "C" int rac_conv2d(const rac_conv_args* a, void* stream) {
   bool bv = (a->Cin % 4 == 0) && (p.a_split % 4 == 0) && aligned16(a->a0) && (!a->a1 || aligned16(a->a1));
   return launch_mode<RAC_CONV_WGRAD>(p, st, av, bv);
 }
+
+RAC_DEVICE_CODE_END

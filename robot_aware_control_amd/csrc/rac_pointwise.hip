@@ -1115,3 +1115,5 @@ int rac_lstm_core_bwd(const float* dc_raw, const float* d_act, const float* act,
 }
 
 }  // extern "C"
+
+RAC_DEVICE_CODE_END

@@ -2542,3 +2542,5 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, reinterpret_cast<hipStream_t>(stream), p);
   return check_launch("rac_conv2d_wgrad_split");
 }
+
+RAC_DEVICE_CODE_END

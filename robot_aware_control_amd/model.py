@@ -239,8 +239,8 @@ class _GaussianConvLSTM(_ConvLSTM):
         (None, h, None) -- the caller applies `heads` to the hidden states of all time steps at once."""
         h = super().forward(x)
         if defer_head:
-            if need_z:
-                eps_fn(h[..., :self.mu_net.weight.shape[0]])  # the draw z = eps * sigma + mu would have consumed
+            if need_z:  # the draw z = eps * sigma + mu would have consumed: a (B, H, W, z) map, whatever g is
+                eps_fn(h.new_empty(tuple(h.shape[:3]) + (self.mu_net.weight.shape[0],)))
             return None, h, None
         mu, logvar = self.heads(h)
         z = ops.Reparam.apply(mu, logvar, eps_fn(mu)) if need_z else None
@@ -326,6 +326,7 @@ class SVGConvModel(nn.Module):
         # zero_grad(lazy=True): the large conv weights' gradients are not zeroed (ops._STALE), everything else is -- by ONE
         # multi-tensor fill.  (Moving the large weights to the end of the buffer instead, so that one slice fill would do,
         # slowed the fused Adam pass from 1.7 to 2.8 ms: its blocks then walk the three 210 MB gate weights back to back.)
+        total = (total + 1023) // 1024 * 1024  # whole 4 KB: any 1 / 2 / 4 / 8-way slice of a bucket stays 16-byte aligned
         self._lazy_params = [p for p in params if id(p) not in paired and p.dim() == 4 and p.numel() >= (1 << 16)]
         lazy_ids = {id(p) for p in self._lazy_params}
         self._eager_params = [p for p in params if id(p) not in lazy_ids]

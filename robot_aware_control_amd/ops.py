@@ -638,6 +638,8 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
     sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(),
            tuple((off, ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items()))) for off, ent, _ in covered))
     plan = st["adam_plan"]
+    if plan is not None and plan["sig"] == sig and plan.get("unsupported"):
+        return False
     if plan is None or plan["sig"] != sig:
         lib = _lib.load()
         jobs = (AdamFragJob * len(covered))()
@@ -645,7 +647,11 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
         for i, (off, ent, w) in enumerate(covered):
             co, ci, k, _ = w.shape
             n = w.numel()
-            assert off % 4 == 0 and n % 4 == 0 and off >= pos, "overlapping conv weights in the flat buffer"
+            if off % 4 or n % 4 or off < pos or flat.numel() % 4:
+                # registered views that overlap (the merged mu | logvar head next to its own two parameters) or are not
+                # 16-byte aligned: this layout is not the fused pass's -- plain Adam, parts refreshed lazily
+                st["adam_plan"] = {"sig": sig, "unsupported": True}
+                return False
             if off > pos:
                 ranges.append((pos // 4, (off - pos) // 4))
             pos = off + n
@@ -662,7 +668,6 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
         for i, (b4, n4) in enumerate(ranges):
             rjobs[i] = AdamRange(begin4=b4, n4=n4, block_begin=rblocks)
             rblocks += _cdiv(n4, 1024)
-        assert flat.numel() % 4 == 0
         plan = st["adam_plan"] = {
             "sig": sig, "jobs": _wp_upload(jobs, dev), "n_jobs": len(covered), "blocks": blocks,
             "ranges": _wp_upload(rjobs, dev), "n_ranges": len(ranges), "rblocks": rblocks,

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import torch
 
+import torch.distributed as dist
+
 from . import _lib, ops
 
 
@@ -31,6 +33,8 @@ class FusedAdam(torch.optim.Optimizer):
         m, v = self._moments()
         g = self.param_groups[0]
         self._steps += 1
+        if ops._STALE:  # a lazy zero_grad whose step never reached finish_grads(): no stale gradient is ever applied
+            ops.finish_grads()
         # one pass that also writes the next step's operand parts of the split-precision conv weights, when their parts
         # and maxima are current (every step after the first); plain Adam over the whole buffer otherwise
         if ops.fused_adam_step(flat, grad, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps):
@@ -61,5 +65,133 @@ class FusedAdam(torch.optim.Optimizer):
                 mv.copy_(st["exp_avg"])
                 vv.copy_(st["exp_avg_sq"])
                 steps = max(steps, int(st["step"]))
+        self._steps = steps
+        self.state.clear()
+
+
+def shard_plan(total: int, world: int, bucket_elems: int):
+    """Buckets of the flat buffers for the sharded optimiser step: [(start, size)] in flat-buffer order (= the order the
+    forward pass first uses the weights), every size a multiple of 4 * world so that the `world` slices of a bucket are
+    equal and 16-byte aligned.  `total` must itself be such a multiple (SVGConvModel pads its flat buffers to 1024)."""
+    q = 4 * world
+    assert total % q == 0, (total, world)
+    step = max(q, bucket_elems // q * q)
+    return [(s, min(step, total - s)) for s in range(0, total, step)]
+
+
+class ShardedAdam(FusedAdam):
+    """Data-parallel optimiser step with the optimiser state and the update sharded over the ranks (ZeRO-1 on the flat
+    buffers; `--ddp_shard_optimizer True`), instead of all-reduce + the same full Adam on every rank:
+
+      backward   reduce-scatter (SUM) of each gradient bucket: rank r receives slice r of the bucket -- the bytes of HALF an
+                 all-reduce stand between the last weight gradient and the optimiser (`ShardReducer`);
+      step       1 / world scale and Adam on the owned slices only: 1 / world of the 6.7 GB Adam traffic, exp_avg /
+                 exp_avg_sq exist only for the owned 1 / world of the parameters;
+      next step  all-gather of the updated parameter buckets, asynchronous and in the order the forward pass needs the
+                 weights; `wait_params()` is called before the first kernel that reads a parameter (today: the start of
+                 the next train step, and any state_dict / evaluation in between).
+
+    The conv weights' split-precision operand parts are refreshed lazily after the all-gather (ops._wp_refresh: one
+    absmax + one fragment-split launch over all weights) -- the fused Adam + parts pass needs the whole updated weight.
+    Same arithmetic per element as FusedAdam (`rac_adam_step` on slices), so a one-rank group reproduces it bit for bit."""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, bucket_mb: int = 64):
+        super().__init__(model, lr=lr, betas=betas, eps=eps)
+        self.bucket_elems = max(1, int(bucket_mb)) * (1 << 20) // 4
+        self._pending = []   # async all-gather works of the last step's parameters
+        self._adam = None    # tests on the CPU inject a torch Adam here; the product path is the HIP kernel
+        self._ms = self._vs = None
+
+    def plan(self):
+        flat, _ = self._model.flat_parameters()
+        world = dist.get_world_size()
+        return shard_plan(flat.numel(), world, self.bucket_elems), world, dist.get_rank()
+
+    def _shard_moments(self, n_own, device):
+        if self._ms is None or self._ms.numel() != n_own or self._ms.device != device:
+            self._ms = torch.zeros(n_own, device=device, dtype=torch.float32)
+            self._vs = torch.zeros(n_own, device=device, dtype=torch.float32)
+        return self._ms, self._vs
+
+    def wait_params(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """Expects the gradient buckets reduce-scattered (ShardReducer.finish): slice `rank` of every bucket of the flat
+        gradient holds the SUM over ranks."""
+        flat, grad = self._model.flat_parameters()
+        buckets, world, rank = self.plan()
+        g = self.param_groups[0]
+        self._steps += 1
+        if ops._STALE:
+            ops.finish_grads()
+        n_own = sum(size // world for _, size in buckets)
+        ms, vs = self._shard_moments(n_own, flat.device)
+        pos = 0
+        inv = 1.0 / world
+        for start, size in buckets:
+            n = size // world
+            lo = start + rank * n
+            p_s, g_s = flat[lo:lo + n], grad[lo:lo + n]
+            if world > 1:
+                g_s.mul_(inv)
+            if self._adam is not None:
+                self._adam(p_s, g_s, ms[pos:pos + n], vs[pos:pos + n], g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                           self._steps)
+            else:
+                if not flat.is_cuda:
+                    raise _lib.RacError("ShardedAdam runs on the GPU only")
+                _lib.call("rac_adam_step", p_s.data_ptr(), g_s.data_ptr(), ms[pos:pos + n].data_ptr(),
+                          vs[pos:pos + n].data_ptr(), n, float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
+                          float(g["eps"]), self._steps, _lib.stream_ptr())
+            pos += n
+        # the updated slices travel to every rank, bucket by bucket in forward order, while the host moves on
+        for start, size in buckets:
+            n = size // world
+            self._pending.append(dist.all_gather_into_tensor(flat[start:start + size], flat[start + rank * n:start + (rank + 1) * n],
+                                                             async_op=True))
+        ops.PARAM_EPOCH += 1  # caches derived from the parameters (padded copies, operand parts) are stale
+
+    # torch.optim.Adam-compatible state: the full moments are assembled from all ranks' slices
+    def _moments(self):
+        flat, _ = self._model.flat_parameters()
+        buckets, world, rank = self.plan()
+        n_own = sum(size // world for _, size in buckets)
+        ms, vs = self._shard_moments(n_own, flat.device)
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        pos = 0
+        for start, size in buckets:
+            n = size // world
+            dist.all_gather_into_tensor(m[start:start + size], ms[pos:pos + n].contiguous())
+            dist.all_gather_into_tensor(v[start:start + size], vs[pos:pos + n].contiguous())
+            pos += n
+        return m, v
+
+    def state_dict(self):
+        self.wait_params()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        torch.optim.Optimizer.load_state_dict(self, state_dict)
+        flat, _ = self._model.flat_parameters()
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        steps = 0
+        for p in self.param_groups[0]["params"]:
+            st = self.state.get(p)
+            if st:
+                torch.as_strided(m, p.shape, p.stride(), p._rac_off).copy_(st["exp_avg"])
+                torch.as_strided(v, p.shape, p.stride(), p._rac_off).copy_(st["exp_avg_sq"])
+                steps = max(steps, int(st["step"]))
+        buckets, world, rank = self.plan()
+        ms, vs = self._shard_moments(sum(size // world for _, size in buckets), flat.device)
+        pos = 0
+        for start, size in buckets:
+            n = size // world
+            ms[pos:pos + n].copy_(m[start + rank * n:start + (rank + 1) * n])
+            vs[pos:pos + n].copy_(v[start + rank * n:start + (rank + 1) * n])
+            pos += n
         self._steps = steps
         self.state.clear()

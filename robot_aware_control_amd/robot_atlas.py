@@ -55,6 +55,7 @@ class AtlasRobotModel:
         self.device = dev
         self.preprocess_action = preprocess_action
         self.exact = exact
+        self.shared_start_mask = None  # set by predict_batch: do all samples of the last batch share row 0?
 
     # ------------------------------------------------------------------ build / cache
     @classmethod
@@ -120,6 +121,11 @@ class AtlasRobotModel:
             raise ValueError(f"actions {tuple(actions.shape)} do not match states {tuple(src_states.shape)}")
         A = actions.shape[2] if T else 2
         rows = lambda t: torch.as_tensor(t).to(dev, torch.float32).reshape(-1, 5).expand(N, 5).contiguous()
+        s0 = torch.as_tensor(src_states[0]).reshape(-1, 5)
+        if s0.device.type == "cpu":  # told to TrajectorySampler: every sample starts from one state -> one start mask
+            self.shared_start_mask = bool((s0 == s0[:1]).all())
+        else:
+            self.shared_start_mask = None
         start, low, high = rows(src_states[0]), rows(data[pre + "low"]), rows(data[pre + "high"])
         states = torch.empty((T1, N, 5), device=dev, dtype=torch.float32)
         masks = torch.empty((T1, N, 1, self.H, self.W), device=dev, dtype=torch.float32)

@@ -67,6 +67,32 @@ def synth_cem_problem(seed: int, N: int, T: int, H: int = 64, W: int = 64, with_
     return out
 
 
+ELITE_SLOTS = [17, 923, 401, 655, 88, 760, 333, 512]  # where the graded candidates sit among the 1000
+
+
+def demo_problem(ra: bool, N: int, T: int, seed: int = 6):
+    """A planning problem whose elites are well separated (K / K+1 cost gap >= 1e-3): candidate N of the
+    draw is the DEMONSTRATION -- the planner's per-step goal images are to be the model's own rollout of it (how the
+    reference is driven: DemoGoalState.imgs holds one goal frame per step, trajectory_sampler.py:154) -- and the
+    candidates at ELITE_SLOTS (taken modulo N) are graded blends demo + 0.1 k (candidate - demo), k = 1..8 (with the
+    demo's robot states / masks).  Returns (problem with N + 1 action rows, the demonstration's actions)."""
+    prob = synth_cem_problem(seed=seed, N=N + 1, T=T, with_robot=ra, goal_blend=0.15)
+    acts = prob["actions"]
+    demo = acts[N].clone()
+    for k, j in enumerate(ELITE_SLOTS, start=1):
+        j = j % N
+        acts[j] = demo + 0.1 * k * (acts[j] - demo)
+        if ra:
+            prob["states"][:, j] = prob["states"][:, N]
+            prob["masks"][:, j] = prob["masks"][:, N]
+    return prob, demo
+
+
+def frames_to_goal_images(obs) -> list:
+    """(T, 3, H, W) float frames in [0, 1] -> T uint8 (H, W, 3) goal images, as a camera would hand them over."""
+    return [np.clip(np.rint(np.asarray(o).transpose(1, 2, 0) * 255), 0, 255).astype(np.uint8) for o in obs]
+
+
 def synth_arm_atlas(nx: int = 108, ny: int = 121, H: int = 64, W: int = 64, x_range=(0.015, 0.55),
                     y_range=(-0.3, 0.3), device="cpu") -> dict:
     """A synthetic robot-mask atlas for `robot_atlas.AtlasRobotModel` (5 mm grid over the workspace of

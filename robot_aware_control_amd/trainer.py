@@ -20,16 +20,16 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import ops
+from . import ops, parallel_env
 from .model import SVGConvModel
-from .optim import FusedAdam
+from .optim import FusedAdam, ShardedAdam
 
 # teacher-forced windows run the encoder / decoder once over all time steps (RAC_SEQUENCE_PATH=0: step by step)
 SEQUENCE_PATH = os.environ.get("RAC_SEQUENCE_PATH", "1") == "1"
 
 
 def _dist_on() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return parallel_env.active()
 
 
 def allreduce_flat_grad(flat_grad: torch.Tensor, bucket_mb: int = 64):
@@ -82,6 +82,45 @@ class GradReducer:
         self.flat.mul_(1.0 / dist.get_world_size())
 
 
+class ShardReducer:
+    """The sharded optimiser's half of the exchange (optim.ShardedAdam): a reduce-scatter (SUM) per bucket of the flat
+    gradient, issued as soon as every weight gradient inside the bucket is final -- the ConvLSTM weights' buckets right
+    after their time-batched wgrad launch (`ready`), the rest in `finish()`.  Rank r's slice of each bucket is reduced
+    IN PLACE (output = that slice of the input bucket)."""
+
+    def __init__(self, flat_grad: torch.Tensor, buckets, world: int, rank: int):
+        self.flat, self.buckets, self.world, self.rank = flat_grad, buckets, world, rank
+        self.covered = [0] * len(buckets)
+        self.issued = [False] * len(buckets)
+        self.works = []
+
+    def _issue(self, b: int):
+        start, size = self.buckets[b]
+        n = size // self.world
+        bucket = self.flat[start:start + size]
+        self.works.append(dist.reduce_scatter_tensor(bucket[self.rank * n:(self.rank + 1) * n], bucket,
+                                                     op=dist.ReduceOp.SUM, async_op=True))
+        self.issued[b] = True
+
+    def ready(self, param: torch.Tensor):
+        g = param.grad
+        if g is None or g.untyped_storage().data_ptr() != self.flat.untyped_storage().data_ptr():
+            return
+        lo = g.storage_offset() - self.flat.storage_offset()
+        hi = lo + g.numel()
+        for b, (start, size) in enumerate(self.buckets):
+            ov = min(hi, start + size) - max(lo, start)
+            if ov > 0 and lo <= start and start + size <= hi and not self.issued[b]:
+                self._issue(b)  # the bucket lies inside this weight's gradient: final now
+
+    def finish(self):
+        for b in range(len(self.buckets)):
+            if not self.issued[b]:
+                self._issue(b)
+        for w in self.works:
+            w.wait()
+
+
 class PredictionTrainer(object):
     """Video prediction training (reference trainer.py:53-897, hot path only)."""
 
@@ -125,7 +164,11 @@ class PredictionTrainer(object):
             dist.broadcast(self.model.flat_parameters()[0], src=0)
         if cf.optimizer != "adam":
             raise ValueError("Unknown optimizer on the HIP path: %s" % cf.optimizer)
-        self.optimizer = FusedAdam(self.model, lr=cf.lr, betas=(cf.beta1, 0.999))
+        if getattr(cf, "ddp_shard_optimizer", False) and _dist_on():
+            self.optimizer = ShardedAdam(self.model, lr=cf.lr, betas=(cf.beta1, 0.999),
+                                         bucket_mb=getattr(cf, "ddp_bucket_mb", 64))
+        else:
+            self.optimizer = FusedAdam(self.model, lr=cf.lr, betas=(cf.beta1, 0.999))
 
     def _schedule_prob(self):
         """Probability of feeding ground truth (trainer.py:132-140)."""
@@ -232,6 +275,8 @@ class PredictionTrainer(object):
             batch_weight = (cf.movement_weight * mv).to(f32)
             batch_weight[~mv.bool()] = 1.0
 
+        if isinstance(self.optimizer, ShardedAdam):
+            self.optimizer.wait_params()  # the previous step's parameter all-gather (host-side: nothing is enqueued yet)
         ops.begin_step(x.device)
         self._mark("start")
         # (lazy: the large conv weights' gradients are written, not added to zeros, by their one launch per step)
@@ -313,12 +358,21 @@ class PredictionTrainer(object):
         copied = torch.cuda.Event()
         copied.record()
         # loss = sum_t recon_t + beta * sum_t kl_t (trainer.py:459): seed each term's gradient directly
-        reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64)) if _dist_on() else None
+        reducer = None
+        if _dist_on():
+            if isinstance(self.optimizer, ShardedAdam):
+                reducer = ShardReducer(self.model.flat_parameters()[1], *self.optimizer.plan())
+            else:
+                reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
         # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce
-        with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
-            torch.autograd.backward(roots, seeds)
-            self._mark("backward")
-        ops.finish_grads()  # a weight no launch wrote this step (none in the standard configurations) gets its zeros now
+        try:
+            with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
+                torch.autograd.backward(roots, seeds)
+                self._mark("backward")
+        finally:
+            # a weight no launch wrote this step (none in the standard configurations) gets its zeros now -- also when
+            # backward raised: a caller that catches the exception must not find last step's values in a .grad
+            ops.finish_grads()
         self._mark("weight_grads")
         if reducer is not None:
             reducer.finish()

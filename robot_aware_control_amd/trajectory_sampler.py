@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops
+from . import _lib, ops, parallel_env
 from .losses import RobotWorldCost
 from .state import DemoGoalState, State
 
@@ -35,7 +35,7 @@ def shard_bounds(n: int, world: int, rank: int):
 def gather_costs(local: torch.Tensor, N: int, world: int, rank: int) -> np.ndarray:
     """All ranks' per-candidate fp64 cost sums -> one float64[N] on every rank (one all-gather; RCCL on the
     GPU path, any backend works).  Slices are padded to a common width because shards may differ by one."""
-    if world == 1:
+    if world == 1 and not parallel_env.active():
         return local.cpu().numpy()
     width = (N + world - 1) // world
     send = torch.zeros(width, device=local.device, dtype=torch.float64)
@@ -104,12 +104,26 @@ class TrajectorySampler(object):
         """states (T+1,N,5) normalised, masks (T+1,N,1,H,W) for every candidate (trajectory_sampler.py:86-109)."""
         return self._get_robot_model().predict_batch(self._robot_data(action_sequences, start, N, T), thick=True)
 
+    def _start_masks_shared(self, masks) -> bool:
+        """Is row 0 of the robot model's masks (the start state's mask) the same for every candidate?  It is by
+        construction of `_robot_data` (one start state for all candidates); answered WITHOUT a device readback on the
+        planner's hot path: a model may say so itself (`shared_start_mask`: AtlasRobotModel does, from the host copy of
+        the start states it was handed), host tensors (the analytical models return those) are compared on the host,
+        and only an unknown model's device tensors cost one readback per call."""
+        flag = getattr(self.robot_model, "shared_start_mask", None)
+        if flag is not None:
+            return bool(flag)
+        m0 = masks[0]
+        return bool((m0 == m0[:1]).all())  # CPU tensor: no device sync; device tensor: one readback per call
+
     def _refine_elites(self, sum_cost, action_sequences, start, goal):
         """`cfg.cem_exact_elites = M` with an atlas robot model that remembers the model it was rendered from
         (`AtlasRobotModel.exact`): the M best candidates of the atlas pass are rolled out again with EXACTLY rendered
         masks (the reference's own `predict_batch`, trajectory_sampler.py:86-109 -- M per-candidate renders instead of
         N) and their costs replaced, so the elite set is the one exact masks give whenever it lies inside the screened
-        top M.  Every rank re-rolls the same M candidates (no collective)."""
+        top M.  Every rank re-rolls the same M candidates (no collective when `sample_mean` or an `eps_source` makes the
+        re-roll deterministic; otherwise rank 0's M costs are broadcast).  With `sample_mean=False` the re-rolled
+        costs carry a fresh draw of the prior noise, like any second evaluation of a stochastic model would."""
         M = int(getattr(self.cfg, "cem_exact_elites", 0) or 0)
         exact = getattr(self.robot_model, "exact", None)
         if M <= 0 or exact is None or self._refining or not self._needs_robot():
@@ -121,8 +135,17 @@ class TrajectorySampler(object):
             redo = self.generate_model_rollouts(action_sequences[:n][torch.from_numpy(top)].clone(), start, goal)
         finally:
             self.robot_model, self._refining = atlas_model, False
+        redo_cost = np.asarray(redo["sum_cost"], dtype=np.float64)
+        if not self.cfg.sample_mean and getattr(self.model, "eps_source", None) is None and parallel_env.active():
+            # a stochastic re-roll draws its prior noise from each rank's own generator (the sharded pass consumed
+            # different amounts of it): every rank takes rank 0's M costs, so that all ranks pick the same elites
+            buf = torch.from_numpy(redo_cost.copy())
+            if dist.get_backend() == "nccl":
+                buf = buf.to(torch.device(self.cfg.device))
+            dist.broadcast(buf, src=0)
+            redo_cost = buf.cpu().numpy()
         sum_cost = sum_cost.copy()
-        sum_cost[top] = redo["sum_cost"]
+        sum_cost[top] = redo_cost
         self.last_refined = top
         return sum_cost
 
@@ -146,11 +169,6 @@ class TrajectorySampler(object):
         goal_masks = None
         if goal.masks is not None:
             goal_masks = torch.stack([torch.from_numpy(np.asarray(g)) for g in goal.masks]).to(dev).to(torch.uint8)
-        states = masks = None
-        if self._needs_robot():
-            states, masks = self._predict_robot(action_sequences, start, N, T)
-            states = states.to(dev, non_blocking=True)
-            masks = masks.to(dev, torch.float32, non_blocking=True)
         dontcare_in = "dontcare" in cfg.reconstruction_loss or cfg.black_robot_input
         dontcare_cost = "dontcare" in cfg.reward_type
         kind = 1 if dontcare_cost else 0
@@ -160,11 +178,20 @@ class TrajectorySampler(object):
         world, rank = 1, 0
         # the debug outputs (predicted frames / per-step costs of the elites, indexed over ALL candidates) are not
         # gathered: a call that asks for them rolls every candidate out on every rank
-        if (dist.is_available() and dist.is_initialized() and getattr(cfg, "cem_shard", True)
-                and not (ret_obs or ret_step_cost) and not self._refining):
-            world, rank = dist.get_world_size(), dist.get_rank()
+        if getattr(cfg, "cem_shard", True) and not (ret_obs or ret_step_cost) and not self._refining:
+            world, rank = parallel_env.world_rank()
         lo, hi = shard_bounds(N, world, rank)
         n_local = hi - lo
+        # the robot model is asked about THIS rank's candidates only (the reference asks about all N,
+        # trajectory_sampler.py:86-109; a candidate's states and masks depend on nothing but its own actions): at cfg4 a
+        # rank builds (15, 1000, 1, 64, 64) masks, not (15, 8000, ...).  `states` / `masks` are indexed shard-locally.
+        states = masks = None
+        shared_mask0 = True
+        if self._needs_robot() and n_local > 0:
+            states, masks = self._predict_robot(action_sequences[lo:hi], start, n_local, T)
+            shared_mask0 = self._start_masks_shared(masks)
+            states = states.to(dev, non_blocking=True)
+            masks = masks.to(dev, torch.float32, non_blocking=True)
         per = cfg.candidates_batch_size
         nb = max(n_local // per, 1)
         sum_cost_dev = torch.zeros(max(n_local, 1), device=dev, dtype=torch.float64)
@@ -172,49 +199,49 @@ class TrajectorySampler(object):
         step_cost = np.zeros((N, T)) if ret_step_cost else None
         start_img = (torch.from_numpy(start.img.copy()).permute(2, 0, 1).float() / 255).to(dev)
         actions_dev = action_sequences.to(dev, torch.float32)
+        # step 0: every candidate sees the start frame (and the start mask, row 0 of the robot model's answer): the encoder
+        # runs on one image.  A future mask is the candidate's own.  Decided once per call, without a device readback.
+        shared0 = (getattr(cfg, "cem_shared_start", True) and not cfg.model_use_future_mask
+                   and not getattr(cfg, "model_use_heatmap", False)
+                   and (shared_mask0 or not (cfg.model_use_mask or dontcare_in)))
 
         for b in range(nb if n_local > 0 else 0):
             s = lo + b * per
             e = lo + (b + 1) * per if b < nb - 1 else hi
             n = e - s
+            ls, le = s - lo, e - lo  # shard-local rows of states / masks / sum_cost_dev
             model.init_hidden(batch_size=n)
             curr = start_img.expand(n, -1, -1, -1).contiguous()
             if dontcare_in:
-                curr = ops.ZeroRegion.apply(curr, masks[0, s:e].contiguous())
-            # step 0: every candidate sees the start frame (and the start mask, row 0 of the robot model's answer --
-            # checked, one readback per batch): the encoder runs on one image.  A future mask is the candidate's own.
-            shared0 = (getattr(cfg, "cem_shared_start", True) and not cfg.model_use_future_mask
-                       and not getattr(cfg, "model_use_heatmap", False))
-            if shared0 and (cfg.model_use_mask or dontcare_in):
-                shared0 = bool((masks[0, s:e] == masks[0, s:s + 1]).all())
+                curr = ops.ZeroRegion.apply(curr, masks[0, ls:le].contiguous())
             for t in range(T):
                 ac = actions_dev[s:e, t].contiguous()
-                mask = masks[t, s:e] if cfg.model_use_mask else None
-                state = states[t, s:e] if cfg.model_use_robot_state else None
+                mask = masks[t, ls:le] if cfg.model_use_mask else None
+                state = states[t, ls:le] if cfg.model_use_robot_state else None
                 if cfg.model_use_future_mask:
-                    mask = torch.cat([mask, masks[t + 1, s:e]], 1)
+                    mask = torch.cat([mask, masks[t + 1, ls:le]], 1)
                 if cfg.model_use_future_robot_state:
-                    state = (state, states[t + 1, s:e])
+                    state = (state, states[t + 1, ls:le])
                 shared = t == 0 and shared0
                 x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean,
                                         shared_frame=shared)[0]
                 gi = t if t < len(goal_imgs) else -1
                 add = (not cfg.sparse_cost) or t == T - 1
                 nxt = torch.empty_like(curr)
-                before = sum_cost_dev[s - lo:e - lo].clone() if ret_step_cost else None
+                before = sum_cost_dev[ls:le].clone() if ret_step_cost else None
                 # locals: the (possibly copied) operands must outlive the raw-pointer launch
-                next_mask = masks[t + 1, s:e].contiguous() if (dontcare_in or dontcare_cost) else None
+                next_mask = masks[t + 1, ls:le].contiguous() if (dontcare_in or dontcare_cost) else None
                 goal_mask = goal_masks[gi].contiguous() if (dontcare_cost and goal_masks is not None) else None
                 goal_img = goal_imgs[gi].contiguous()
                 _lib.call(
                     "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(), _lib.ptr(next_mask) if dontcare_in else None,
                     goal_img.data_ptr(), _lib.ptr(next_mask) if dontcare_cost else None, _lib.ptr(goal_mask),
                     kind, w_world, 1 if (add and w_world != 0) else 0, nxt.data_ptr(),
-                    sum_cost_dev[s - lo:e - lo].data_ptr(), n, H * W, _lib.stream_ptr())
+                    sum_cost_dev[ls:le].data_ptr(), n, H * W, _lib.stream_ptr())
                 if ret_obs:
                     all_obs[s:e, t] = nxt.cpu()
                 if ret_step_cost:
-                    step_cost[s:e, t] = (sum_cost_dev[s - lo:e - lo] - before).cpu().numpy()
+                    step_cost[s:e, t] = (sum_cost_dev[ls:le] - before).cpu().numpy()
                 curr = nxt
 
         # ---- gather the per-candidate costs: the only collective of a CEM iteration ----

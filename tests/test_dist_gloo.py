@@ -116,3 +116,102 @@ def test_data_parallel_ranks_train_on_different_batches(tmp_path):
         assert not set(a) & set(b) and sorted(a + b) == list(range(12)), (a, b)
     assert e0[0] != e0[1]  # set_epoch: a new shuffle every epoch
     assert s0 != s1
+
+
+def _torch_adam(p, g, m, v, lr, b1, b2, eps, step):
+    """torch.optim.Adam's update on flat slices (the HIP kernel's stand-in on the CPU: this test is about WHICH
+    elements each rank updates and what travels, not about the arithmetic, which tests/test_gpu_ops.py pins)."""
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    denom = (v / (1 - b2 ** step)).sqrt_().add_(eps)
+    p.addcdiv_(m / (1 - b1 ** step), denom, value=-lr)
+
+
+class _FlatModel(torch.nn.Module):
+    """A parameter holder with SVGConvModel's flat-buffer contract (flat_parameters, parameters as views, _rac_off)."""
+
+    def __init__(self, sizes, total):
+        super().__init__()
+        self._flat, self._grad = torch.zeros(total), torch.zeros(total)
+        off = 0
+        for i, n in enumerate(sizes):
+            p = torch.nn.Parameter(torch.empty(0))
+            p.data = self._flat[off:off + n]
+            p.grad = self._grad[off:off + n]
+            p._rac_off = off
+            self.register_parameter(f"p{i}", p)
+            off += (n + 3) // 4 * 4
+
+    def flat_parameters(self):
+        return self._flat, self._grad
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from robot_aware_control_amd.optim import ShardedAdam, shard_plan
+    from robot_aware_control_amd.trainer import ShardReducer
+    total, sizes = 4096, [700, 1400, 37, 1000]
+    torch.manual_seed(0)
+    p0 = torch.randn(total)
+    grads = torch.randn(3, world, total)          # three optimiser steps, one gradient per rank and step
+    off, inside = 0, torch.zeros(total, dtype=torch.bool)
+    for n in sizes:                               # (the alignment gaps between parameters never receive a gradient)
+        inside[off:off + n] = True
+        off += (n + 3) // 4 * 4
+    grads = grads * inside
+    # reference: all-reduce mean + the same Adam over the whole buffer on every rank
+    ref_p, ref_m, ref_v = p0.clone(), torch.zeros(total), torch.zeros(total)
+    for t in range(3):
+        _torch_adam(ref_p, grads[t].mean(0), ref_m, ref_v, 1e-2, 0.9, 0.999, 1e-8, t + 1)
+    model = _FlatModel(sizes, total)
+    model._flat.copy_(p0)
+    opt = ShardedAdam(model, lr=1e-2, betas=(0.9, 0.999))
+    opt.bucket_elems = 1024                       # four buckets of two 512-element slices
+    opt._adam = _torch_adam
+    buckets, w, r = opt.plan()
+    assert buckets == shard_plan(total, world, 1024) == [(0, 1024), (1024, 1024), (2048, 1024), (3072, 1024)] and (w, r) == (world, rank)
+    for t in range(3):
+        opt.wait_params()                         # the previous step's parameter all-gather
+        model._grad.copy_(grads[t, rank])
+        red = ShardReducer(model._grad, buckets, world, rank)
+        red.ready(model.p1)                       # covers bucket 1 wholly ([700, 2100) contains [1024, 2048)): issued early
+        early = list(red.issued)
+        red.finish()
+        opt.step()
+    opt.wait_params()
+    ok = early == [False, True, False, False] and torch.allclose(model._flat, ref_p, atol=1e-6, rtol=1e-6)
+    # every rank ends with the same parameters; the optimiser state lives in slices and reassembles to the reference's
+    sd = opt.state_dict()
+    m_full = torch.zeros(total)
+    for i, p in enumerate(model.parameters()):
+        m_full[p._rac_off:p._rac_off + p.numel()] = sd["state"][i]["exp_avg"]
+    mask = torch.zeros(total, dtype=torch.bool)
+    for p in model.parameters():
+        mask[p._rac_off:p._rac_off + p.numel()] = True
+    ok = ok and torch.allclose(m_full[mask], ref_m[mask], atol=1e-6) and opt._ms.numel() == total // world
+    # ... and loads back (a resumed run continues exactly)
+    opt2 = ShardedAdam(model, lr=1e-2, betas=(0.9, 0.999))
+    opt2.bucket_elems, opt2._adam = 1024, _torch_adam
+    opt2.load_state_dict(sd)
+    ok = ok and opt2._steps == 3 and torch.equal(opt2._ms, opt._ms) and torch.equal(opt2._vs, opt._vs)
+    q.put((rank, bool(ok), model._flat.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_allreduce_adam_world2():
+    """reduce-scatter -> Adam on 1/world slices -> parameter all-gather (optim.ShardedAdam + trainer.ShardReducer) leaves
+    every rank with the parameters of all-reduce(mean) + full Adam, over three steps, with buckets issued out of order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), [r[:2] for r in res]
+    assert res[0][2] == res[1][2]

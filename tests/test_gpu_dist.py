@@ -80,6 +80,41 @@ def _worker(rank, world, port, q):
         out["dbg"] = [float(np.abs(dbg_sh["obs"] - dbg_1["obs"]).max()),
                       float(np.abs(dbg_sh["step_cost"] - dbg_1["step_cost"]).max() / np.abs(dbg_1["step_cost"]).max()),
                       [int(i) for i in dbg_sh["topk_idx"]], [int(i) for i in dbg_1["topk_idx"]]]
+        # ---- robot-aware planner: sharded BEFORE the robot model is asked (a rank asks about ITS candidates only) ----
+        from robot_aware_control_amd.trajectory_sampler import TrajectorySampler, shard_bounds
+        ra_flags = dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=True,
+                        reconstruction_loss="dontcare_l1")
+        cfg_ra = orc.Cfg(g_dim=64, z_dim=16, batch_size=2, candidates_batch_size=4, sample_mean=True,
+                         reward_type="dontcare", topk=3, **ra_flags)
+        _, ns_ra = _ns(dev, reward_type="dontcare", experiment="control_wx250s_synthetic", **ra_flags)
+        m_ra = SVGConvModel(ns_ra)
+        m_ra.load_state_dict({k: v.clone() for k, v in orc.make_weights(cfg_ra, seed=9, action_gain=200.0).items()})
+        m_ra.eval()
+
+        class Counting:  # the atlas robot model, recording how many candidates each call asked about
+            def __init__(self, inner):
+                self.inner, self.asked, self.shared_start_mask = inner, [], None
+
+            def predict_batch(self, data, thick=True):
+                self.asked.append(int(data["actions"].shape[1]))
+                res = self.inner.predict_batch(data, thick)
+                self.shared_start_mask = self.inner.shared_start_mask
+                return res
+        robot = Counting(syn.SyntheticArmModel(dev).atlas(54, 61))
+        s_ra = State(img=prob["start_img"], state=np.array([0.28, 0.0, 0.12, 0.0, 0.0], np.float32),
+                     qpos=np.zeros(5, np.float32))
+        g_ra = DemoGoalState(imgs=prob["goal_imgs"], masks=[np.zeros((1, 64, 64), bool)])
+        smp = TrajectorySampler(ns_ra, m_ra, robot_model=robot)
+        ra_sh = smp.generate_model_rollouts(prob["actions"].clone(), s_ra, g_ra, opt_traj=opt.clone())
+        lo_, hi_ = shard_bounds(N + 1, world, rank)
+        out["ra_asked_local"] = robot.asked == [hi_ - lo_] and robot.shared_start_mask is True
+        ns_ra.cem_shard = False
+        ra_1 = smp.generate_model_rollouts(prob["actions"].clone(), s_ra, g_ra, opt_traj=opt.clone())
+        ns_ra.cem_shard = True
+        out["ra_equal"] = bool(np.array_equal(ra_sh["sum_cost"], ra_1["sum_cost"]) and robot.asked[-1] == N + 1
+                               and ra_sh["optimal_sum_cost"] == ra_1["optimal_sum_cost"]
+                               and np.unique(ra_1["sum_cost"]).size > N // 2)
+        del m_ra, smp
         # the same at the benchmarked width (g 512 / z 64): 37 candidates in ragged shards and batches of 8 against one
         # un-sharded pass of all 37 -- per-image operand scales and an unsplit K make a cost independent of its batch
         cfg5, ns5 = _ns(dev, g_dim=512, z_dim=64, candidates_batch_size=8)
@@ -144,6 +179,8 @@ def test_ranks_sharing_one_gpu(world):
         assert "error" not in r, r.get("error")
     assert all(r["cem_equal"] and r["debug_equal"] for r in res), [(r["cem_equal"], r["debug_equal"], r["dbg"]) for r in res]
     assert all(r["g512_equal"] for r in res)
+    # robot-aware: each rank asked its robot model about its own shard only, and the costs are the single-rank bits
+    assert all(r["ra_asked_local"] and r["ra_equal"] for r in res), [(r["ra_asked_local"], r["ra_equal"]) for r in res]
     assert all(r["action"] == res[0]["action"] for r in res)
     # identical inputs exclude slope flips; what is left is the all-reduce's summation order
     assert all(r["ddp_err"] < 1e-5 for r in res), res
@@ -166,7 +203,7 @@ def test_bench_two_ranks_rehearsal():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--cem-candidates", "64", "--cem-batch", "64", "--cem-iters", "1", "--cem-opt-iter", "2",
-           "--exact-steps", "2"]
+           "--exact-steps", "2", "--side-steps", "1"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -180,4 +217,5 @@ def test_bench_two_ranks_rehearsal():
     assert cem["config"]["parallelism"] == "candidate-shard2" and cem["config"]["candidates"] == 128
     assert cem["ranks"]["cost_allgather_ms"] is not None and len(cem["ranks"]["s_per_iteration"]) == 2
     assert out["cem_ra"]["value"] > 0 and out["fp32_exact"]["train"]["ms_per_step"] > 0
+    assert out["side"]["cfg5"]["value"] > 0 and "128x128" in out["side"]["cfg5"]["config"]["workload"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only

@@ -266,23 +266,7 @@ def test_cem_costs_do_not_depend_on_batching(dev, ra):
     assert np.array_equal(run(1, few[:1]), full[few[:1]])
 
 
-ELITE_SLOTS = [17, 923, 401, 655, 88, 760, 333, 512]  # where the graded candidates sit among the 1000
-
-
-def demo_problem(ra, N, T, seed=6):
-    """A planning problem whose elites are well separated (K / K+1 cost gap >= 1e-3): candidate N of the
-    draw is the DEMONSTRATION -- the planner's per-step goal images are the model's own rollout of it (how the reference
-    is driven: DemoGoalState.imgs holds one goal frame per step, trajectory_sampler.py:154) -- and the candidates at
-    ELITE_SLOTS are graded blends demo + 0.1 k (candidate - demo), k = 1..8 (with the demo's robot states / masks)."""
-    prob = syn.synth_cem_problem(seed=seed, N=N + 1, T=T, with_robot=ra, goal_blend=0.15)
-    acts = prob["actions"]
-    demo = acts[N].clone()
-    for k, j in enumerate(ELITE_SLOTS, start=1):
-        acts[j] = demo + 0.1 * k * (acts[j] - demo)
-        if ra:
-            prob["states"][:, j] = prob["states"][:, N]
-            prob["masks"][:, j] = prob["masks"][:, N]
-    return prob, demo
+demo_problem = syn.demo_problem  # the well-separated-elites fixture (also what bench.py times and checks)
 
 
 @pytest.mark.parametrize("ra", [False, True])
@@ -307,7 +291,7 @@ def test_cem_elite_indices_cfg3_full_size(dev, ra):
                             robot_model=FakeRobotModel(sl("states", [N]), sl("masks", [N])) if ra else None)
     placeholder = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     obs = one.generate_model_rollouts(demo[None].clone(), start, placeholder, ret_obs=True)["obs"][0]  # (T,3,H,W)
-    goal_imgs = [np.clip(np.rint(obs[t].transpose(1, 2, 0) * 255), 0, 255).astype(np.uint8) for t in range(T)]
+    goal_imgs = syn.frames_to_goal_images(obs)
     goal_masks = [prob["goal_masks"][0]] * T
     goal = DemoGoalState(imgs=goal_imgs, masks=goal_masks)
     cand = np.arange(N)

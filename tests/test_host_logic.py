@@ -48,6 +48,8 @@ def test_sim_cem_variants_vs_reference(golden_dir, tag, adim):
         assert float(pol.traj_sampler.calls[0][:, :, -1].max()) <= 0 and float(pol.traj_sampler.calls[0][:, :, -1].min()) >= -0.01
     with pytest.raises(NotImplementedError):
         SimCEMPolicy(cfg, physics="gt", model=object())
+    with pytest.raises(NotImplementedError):  # the reference's default (push/cem.py:24) is "gt": never silently "learned"
+        SimCEMPolicy(cfg, model=object())
 
 
 @pytest.mark.parametrize("tag,snippet", [("seq", False), ("rand", True)])
@@ -152,4 +154,5 @@ def test_reset_parameters_moments():
     assert abs(float(g.mean()) - 1) < 2e-3 and abs(float(g.std()) - 0.02) < 2e-3
     # parameters are views of ONE flat buffer (the fused Adam / all-reduce contract)
     flat, grad = m.flat_parameters()
-    assert sum((p.numel() + 3) // 4 * 4 for p in m.parameters()) == flat.numel() == grad.numel()
+    used = sum((p.numel() + 3) // 4 * 4 for p in m.parameters())  # 16-byte aligned views, the buffer padded to whole 4 KB
+    assert (used + 1023) // 1024 * 1024 == flat.numel() == grad.numel() and float(flat[used:].abs().max()) == 0.0
