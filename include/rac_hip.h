@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 5
+#define RAC_ABI_VERSION 6
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -315,6 +315,31 @@ int rac_lstm_out_bwd(const float* dh, const float* act, const float* c, float* d
  * d_act (gradient of the activated gates [M][4g], may be NULL) -> dgates [M][4g], dc_prev [M][g] */
 int rac_lstm_core_bwd(const float* dc_raw, const float* d_act, const float* act, const float* c_prev, float* dgates,
                       float* dc_prev, int64_t M, int32_t g, void* stream);
+
+/* Gradient maps given as SUMS OF SOURCES (the hand-scheduled backward of the recurrent core, ops.RecurrentCore; replaces
+ * what autograd's accumulation adds and the split-K combine passes did between the ConvLSTM cells' backward kernels,
+ * lstm.py:129-149 / 252-257 unrolled over time).  A source is a stack of n_slabs K-split slabs of a (possibly wider)
+ * tensor, read through a column window: value[m][c] = sum_s p[s * slab_stride + m * row_stride + col_off + c].  A plain
+ * [M][C] tensor is n_slabs = 1, row_stride = C, col_off = 0.  C % 4 == 0; a window may start at any column (sources are
+ * read with 4-byte alignment).  The array is HOST memory (at most 3 entries, copied into the launch). */
+typedef struct rac_grad_src {
+  const float* p;
+  int64_t slab_stride;
+  int32_t n_slabs, row_stride, col_off, reserved;
+} rac_grad_src;
+/* out[m][c] = sum over the sources (+ max |out| folded into out_amax, nullable) */
+int rac_grad_sum(const rac_grad_src* srcs, int32_t n_srcs, float* out, int64_t M, int32_t C, uint32_t* out_amax,
+                 void* stream);
+/* rac_lstm_cell_bwd with dh = sum over dh_srcs (n_srcs = 0: dh = 0) */
+int rac_lstm_cell_bwd_srcs(const rac_grad_src* dh_srcs, int32_t n_srcs, const float* dc_next, const float* act,
+                           const float* c_prev, const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g,
+                           uint32_t* dgates_amax, void* stream);
+/* backward of the reparameterisation into the merged mu | logvar head's output gradient (lstm.py:273-279):
+ * dy[m] = [dz + dmu_add | dz * eps * 0.5 * exp(0.5 * logvar) + dlogvar_add], dz = sum over dz_srcs; the addends (the
+ * KL term's gradients, [M][z]) may be NULL; dy is [M][2z]. */
+int rac_reparam_head_bwd(const rac_grad_src* dz_srcs, int32_t n_srcs, const float* logvar, const float* eps,
+                         const float* dmu_add, const float* dlogvar_add, float* dy, int64_t M, int32_t z,
+                         uint32_t* dy_amax, void* stream);
 
 /* z = eps*exp(0.5*logvar) + mu (lstm.py:276-279); dlogvar = dz*eps*0.5*exp(0.5*logvar) */
 int rac_reparam_fwd(const float* mu, const float* logvar, const float* eps, float* z, int64_t n, void* stream);

@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 5  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 6  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -55,6 +55,12 @@ class AdamFragJob(C.Structure):
 class AdamRange(C.Structure):
     """struct rac_adam_range (include/rac_hip.h)."""
     _fields_ = [("begin4", i64), ("n4", i64), ("block_begin", i64)]
+
+
+class GradSrc(C.Structure):
+    """struct rac_grad_src (include/rac_hip.h): one addend of a gradient map, slabs read through a column window."""
+    _fields_ = [("p", vp), ("slab_stride", i64), ("n_slabs", i32), ("row_stride", i32), ("col_off", i32),
+                ("reserved", i32)]
 
 
 class WgradArgs(C.Structure):
@@ -111,6 +117,9 @@ _SIGS = {
     "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],
     "rac_lstm_out_bwd": [vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_core_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],
+    "rac_grad_sum": [C.POINTER(GradSrc), i32, vp, i64, i32, vp, vp],
+    "rac_lstm_cell_bwd_srcs": [C.POINTER(GradSrc), i32, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
+    "rac_reparam_head_bwd": [C.POINTER(GradSrc), i32, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "rac_reparam_fwd": [vp, vp, vp, vp, i64, vp],
     "rac_reparam_bwd": [vp, vp, vp, vp, i64, vp],
     "rac_pack_input": [vp, vp, vp, i32, i32, vp, i32, i32, vp],

@@ -582,6 +582,114 @@ __global__ void reparam_bwd_kernel(const float* dz, const float* lv, const float
     dlv[i] = dz[i] * eps[i] * (0.5f * expf(0.5f * lv[i]));
 }
 
+// ------------------------------------------------- gradient maps given as sums of sources (hand-scheduled BPTT)
+// A gradient map [M][C] as the sum of up to three sources, each a stack of K-split slabs of a wider tensor read through a
+// column window: src[s][m][col_off + c].  The recurrent core's backward hands the data-gradient convs' raw slabs straight
+// to their consumers (the cell kernel below, rac_grad_sum, rac_reparam_head_bwd): no combine pass, no accumulation add.
+struct GradSrcs {
+  const float* p[3];
+  long slab_stride[3];
+  int n_slabs[3], row_stride[3], col_off[3];
+  int n;
+};
+
+// (a window may start at any column -- e.g. behind the 10 tiled action / state channels of an input conv's gradient --
+// so source loads promise 4-byte alignment only; gfx950 global loads take dword-aligned dwordx4 accesses)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ f32x4 grad_src_load4(const GradSrcs& S, long m, int c) {
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    if (k < S.n) {
+      const float* q = S.p[k] + m * S.row_stride[k] + S.col_off[k] + c;
+      for (int s = 0; s < S.n_slabs[k]; ++s) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(q + s * S.slab_stride[k]);
+        a += f32x4{v.x, v.y, v.z, v.w};
+      }
+    }
+  return a;
+}
+
+__global__ void grad_sum_kernel(GradSrcs S, float* out, long M, int C, unsigned* amax) {
+  const int C4 = C / 4;
+  const long n4 = M * C4;
+  unsigned mx = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / C4;
+    const int c = (int)(i - m * C4) * 4;
+    const f32x4 a = grad_src_load4(S, m, c);
+    mx = max(max(mx, max(absbits(a.x), absbits(a.y))), max(absbits(a.z), absbits(a.w)));
+    *reinterpret_cast<f32x4*>(out + m * C + c) = a;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
+// lstm_cell_bwd_kernel with dh = sum of sources, four channels per thread
+__global__ void lstm_cell_bwd_srcs_kernel(GradSrcs S, const float* dc_next, const float* act, const float* c_prev,
+                                          const float* c_new, float* dgates, float* dc_prev, long M, int g,
+                                          unsigned* amax) {
+  const int g4 = g / 4;
+  const long n4 = M * g4;
+  unsigned mx = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / g4;
+    const int c = (int)(i - m * g4) * 4;
+    const f32x4 dh = grad_src_load4(S, m, c);
+    const float* a = act + m * 4 * g + c;
+    const f32x4 gi = *reinterpret_cast<const f32x4*>(a), gf = *reinterpret_cast<const f32x4*>(a + g),
+                go = *reinterpret_cast<const f32x4*>(a + 2 * g), gg = *reinterpret_cast<const f32x4*>(a + 3 * g);
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(c_new + m * g + c), cp = *reinterpret_cast<const f32x4*>(c_prev + m * g + c);
+    f32x4 dcn = {0.f, 0.f, 0.f, 0.f};
+    if (dc_next) dcn = *reinterpret_cast<const f32x4*>(dc_next + m * g + c);
+    f32x4 d0, d1, d2, d3, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // the arithmetic of lstm_cell_bwd_kernel, element by element
+      const float tc = tanhf(cn[e]);
+      const float dhv = dh[e];
+      const float dc = dhv * go[e] * (1.f - tc * tc) + dcn[e];
+      d0[e] = dc * gg[e] * gi[e] * (1.f - gi[e]);
+      d1[e] = dc * cp[e] * gf[e] * (1.f - gf[e]);
+      d2[e] = dhv * tc * go[e] * (1.f - go[e]);
+      d3[e] = dc * gi[e] * (1.f - gg[e] * gg[e]);
+      dcp[e] = dc * gf[e];
+      mx = max(max(mx, absbits(d0[e])), max(max(absbits(d1[e]), absbits(d2[e])), absbits(d3[e])));
+    }
+    float* d = dgates + m * 4 * g + c;
+    *reinterpret_cast<f32x4*>(d) = d0;
+    *reinterpret_cast<f32x4*>(d + g) = d1;
+    *reinterpret_cast<f32x4*>(d + 2 * g) = d2;
+    *reinterpret_cast<f32x4*>(d + 3 * g) = d3;
+    *reinterpret_cast<f32x4*>(dc_prev + m * g + c) = dcp;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
+// backward of z = eps * exp(0.5 logvar) + mu feeding the merged mu | logvar head: dy[m] = [dz + dmu_add | dz * eps * 0.5 *
+// exp(0.5 logvar) + dlv_add]  (dz a sum of sources; the addends are the KL term's gradients, nullable)
+__global__ void reparam_head_bwd_kernel(GradSrcs S, const float* lv, const float* eps, const float* dmu_add,
+                                        const float* dlv_add, float* dy, long M, int z, unsigned* amax) {
+  const int z4 = z / 4;
+  const long n4 = M * z4;
+  unsigned mx = 0;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / z4;
+    const int c = (int)(i - m * z4) * 4;
+    const f32x4 dz = grad_src_load4(S, m, c);
+    const f32x4 l = *reinterpret_cast<const f32x4*>(lv + m * z + c), e = *reinterpret_cast<const f32x4*>(eps + m * z + c);
+    f32x4 a = dz, b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = dz[k] * e[k] * (0.5f * expf(0.5f * l[k]));
+    if (dmu_add) a += *reinterpret_cast<const f32x4*>(dmu_add + m * z + c);
+    if (dlv_add) b += *reinterpret_cast<const f32x4*>(dlv_add + m * z + c);
+    *reinterpret_cast<f32x4*>(dy + m * 2 * z + c) = a;
+    *reinterpret_cast<f32x4*>(dy + m * 2 * z + z + c) = b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) mx = max(mx, max(absbits(a[k]), absbits(b[k])));
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
 // ----------------------------------------------------------------------- Adam
 __global__ void adam_kernel(f32x4* p, const f32x4* g, f32x4* m, f32x4* v, long n4, float* pt, const float* gt,
                             float* mt, float* vt, int tail, float b1, float b2, float eps, float step_size,
@@ -906,6 +1014,64 @@ int rac_reparam_bwd(const float* dz, const float* logvar, const float* eps, floa
   hipLaunchKernelGGL(reparam_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, ST(stream), dz, logvar, eps, dlogvar,
                      (long)n);
   return check_launch("rac_reparam_bwd");
+}
+
+static int pack_srcs(const rac_grad_src* srcs, int32_t n_srcs, int32_t C, GradSrcs* S, const char* who) {
+  RAC_REQUIRE(n_srcs >= 0 && n_srcs <= 3 && (n_srcs == 0 || srcs), "%s: 0..3 gradient sources", who);
+  S->n = n_srcs;
+  for (int k = 0; k < 3; ++k) {
+    S->p[k] = nullptr;
+    S->slab_stride[k] = 0;
+    S->n_slabs[k] = S->row_stride[k] = S->col_off[k] = 0;
+  }
+  for (int k = 0; k < n_srcs; ++k) {
+    const rac_grad_src& q = srcs[k];
+    RAC_REQUIRE(q.p && q.n_slabs >= 1 && q.col_off >= 0 && q.row_stride >= q.col_off + C, "%s: source %d out of its rows",
+                who, k);
+    RAC_REQUIRE((reinterpret_cast<uintptr_t>(q.p) & 3u) == 0, "%s: source %d is not a float pointer", who, k);
+    S->p[k] = q.p, S->slab_stride[k] = (long)q.slab_stride, S->n_slabs[k] = q.n_slabs, S->row_stride[k] = q.row_stride,
+    S->col_off[k] = q.col_off;
+  }
+  return RAC_OK;
+}
+
+int rac_grad_sum(const rac_grad_src* srcs, int32_t n_srcs, float* out, int64_t M, int32_t C, uint32_t* out_amax,
+                 void* stream) {
+  RAC_REQUIRE(out && M > 0 && C > 0 && C % 4 == 0 && n_srcs >= 1 && aligned16(out), "rac_grad_sum: bad args");
+  GradSrcs S;
+  if (int e = pack_srcs(srcs, n_srcs, C, &S, "rac_grad_sum")) return e;
+  hipLaunchKernelGGL(grad_sum_kernel, dim3(grid_for_amax((long)M * C / 4, out_amax)), dim3(256), 0, ST(stream), S, out,
+                     (long)M, C, out_amax);
+  return check_launch("rac_grad_sum");
+}
+
+int rac_lstm_cell_bwd_srcs(const rac_grad_src* dh_srcs, int32_t n_srcs, const float* dc_next, const float* act,
+                           const float* c_prev, const float* c_new, float* dgates, float* dc_prev, int64_t M, int32_t g,
+                           uint32_t* dgates_amax, void* stream) {
+  RAC_REQUIRE(act && c_prev && c_new && dgates && dc_prev && M > 0 && g > 0 && g % 4 == 0,
+              "rac_lstm_cell_bwd_srcs: bad args");
+  RAC_REQUIRE(aligned16(act) && aligned16(c_prev) && aligned16(c_new) && aligned16(dgates) && aligned16(dc_prev) &&
+                  (!dc_next || aligned16(dc_next)),
+              "rac_lstm_cell_bwd_srcs: 16-byte aligned maps");
+  GradSrcs S;
+  if (int e = pack_srcs(dh_srcs, n_srcs, g, &S, "rac_lstm_cell_bwd_srcs")) return e;
+  hipLaunchKernelGGL(lstm_cell_bwd_srcs_kernel, dim3(grid_for_amax((long)M * g / 4, dgates_amax)), dim3(256), 0,
+                     ST(stream), S, dc_next, act, c_prev, c_new, dgates, dc_prev, (long)M, g, dgates_amax);
+  return check_launch("rac_lstm_cell_bwd_srcs");
+}
+
+int rac_reparam_head_bwd(const rac_grad_src* dz_srcs, int32_t n_srcs, const float* logvar, const float* eps,
+                         const float* dmu_add, const float* dlogvar_add, float* dy, int64_t M, int32_t z,
+                         uint32_t* dy_amax, void* stream) {
+  RAC_REQUIRE(logvar && eps && dy && M > 0 && z > 0 && z % 4 == 0 && n_srcs >= 1, "rac_reparam_head_bwd: bad args");
+  RAC_REQUIRE(aligned16(logvar) && aligned16(eps) && aligned16(dy) && (!dmu_add || aligned16(dmu_add)) &&
+                  (!dlogvar_add || aligned16(dlogvar_add)),
+              "rac_reparam_head_bwd: 16-byte aligned maps");
+  GradSrcs S;
+  if (int e = pack_srcs(dz_srcs, n_srcs, z, &S, "rac_reparam_head_bwd")) return e;
+  hipLaunchKernelGGL(reparam_head_bwd_kernel, dim3(grid_for_amax((long)M * z / 4, dy_amax)), dim3(256), 0, ST(stream), S,
+                     logvar, eps, dmu_add, dlogvar_add, dy, (long)M, z, dy_amax);
+  return check_launch("rac_reparam_head_bwd");
 }
 
 int rac_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

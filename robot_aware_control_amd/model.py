@@ -271,6 +271,7 @@ class SVGConvModel(nn.Module):
         self._image_width = cf.image_width
         self._image_height = cf.image_height
         self.eps_source = None  # optional callable(shape_bzhw) -> N(0,1) tensor; tests inject the reference's draws
+        self.sequence_batched = None  # forward_sequence_maps: (mu, logvar, mu_p, logvar_p) over all T*B samples, if batched
         self._flat = self._flat_grad = None
         if cf.image_width not in (64, 128):  # dynamics.py:470-473
             raise ValueError
@@ -491,6 +492,16 @@ class SVGConvModel(nn.Module):
         else:
             q = self.posterior_input_conv
             post_all = ops.ConvBias.apply(h_all, None, q.weight, q.bias, ACT_NONE, not torch.is_grad_enabled())
+        core = self._recurrent_core(T, B, h_all, prior_all, post_all, robots, actions)
+        if core is not None:
+            h_pred_all, mu_all, lv_all, h_prior_all = core
+            mu_p_all, logvar_p_all = self.prior.heads(h_prior_all)
+            x4 = self.decoder(h_pred_all, skips, T)
+            # (the trainer's KL term takes the batched tensors: one launch, no per-step slices for autograd to stack)
+            self.sequence_batched = (mu_all, lv_all, mu_p_all, logvar_p_all)
+            per_step = lambda t_: list(t_.view((T, B) + tuple(t_.shape[1:])).unbind(0))
+            return x4, per_step(mu_all), per_step(lv_all), per_step(mu_p_all), per_step(logvar_p_all)
+        self.sequence_batched = None
         # (a step's slice inherits the whole tensor's maximum: a valid bound, and no reduction pass per step)
         steps_of = lambda t_: [ops.retag(s_, ops.amax_tag(t_)) for s_ in t_.view((T, B) + tuple(t_.shape[1:])).unbind(0)]
         prior_steps, post_steps = steps_of(prior_all), steps_of(post_all)
@@ -510,6 +521,40 @@ class SVGConvModel(nn.Module):
         logvar_ps = list(logvar_p_all.view((T, B) + tuple(logvar_p_all.shape[1:])).unbind(0))
         x4 = self.decoder(torch.cat(h_preds, 0), skips, T)
         return x4, mus, logvars, mu_ps, logvar_ps
+
+    def _recurrent_core(self, T, B, h_all, prior_all, post_all, robots, actions):
+        """The T-step recurrence as ONE hand-scheduled autograd node (ops.RecurrentCore) where its kernels apply; None
+        otherwise (GroupNorm cells, narrow models, frozen parameters: the per-step autograd path below)."""
+        cf = self._config
+        lstms = {"prior": self.prior, "post": self.posterior, "fp": self.frame_predictor}
+        if any(not isinstance(c, _LstmCell) for m in lstms.values() for c in m.lstm):
+            return None
+        g, z = cf.g_dim, cf.z_dim
+        vs = []
+        for t in range(T):
+            a = actions[t].contiguous()
+            if cf.model_use_robot_state:
+                r = robots[t]
+                vs.append([a] + ([r[0].contiguous(), r[1].contiguous()] if cf.model_use_future_robot_state
+                                 else [r.contiguous()]))
+            else:
+                vs.append([a])
+        nv = sum(v.shape[1] for v in vs[0])
+        head = self.posterior._head
+        cells = [c for m in lstms.values() for c in m.lstm]
+        if not ops.recurrent_core_ok(h_all, g, z, nv, cells, head, self.frame_pred_input_conv):
+            return None
+        for t in head:  # the merged views follow the parameters they alias
+            if t.requires_grad != self.posterior.mu_net.weight.requires_grad:
+                t.requires_grad_(self.posterior.mu_net.weight.requires_grad)
+        plan = dict(T=T, B=B, g=g, z=z, nv=nv, vs=vs, cells={k: tuple(m.lstm) for k, m in lstms.items()}, head=head,
+                    frame_conv=self.frame_pred_input_conv, init_state={k: m.hidden for k, m in lstms.items()},
+                    eps_fn=self._eps, draw_prior_noise=True)
+        params = [c.gates.weight for c in cells] + [head[0], self.frame_pred_input_conv.weight]
+        out = ops.RecurrentCore.apply(plan, h_all, prior_all, post_all, *params)
+        for k, m in lstms.items():
+            m.hidden = plan["final_state"][k]
+        return out
 
     def sequence_ok(self, batch: int, height: int, width: int) -> bool:
         """`forward_sequence_maps` needs per-step row ranges that are whole 128-row tiles at every resolution."""

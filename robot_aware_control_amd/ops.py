@@ -27,7 +27,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import AbsmaxJob, AdamFragJob, AdamRange, ConvArgs, FragJob, WgradArgs, call, ptr, stream_ptr
+from ._lib import AbsmaxJob, AdamFragJob, AdamRange, ConvArgs, FragJob, GradSrc, WgradArgs, call, ptr, stream_ptr
 
 FWD, DGRAD, WGRAD = 0, 1, 2
 ACT_NONE, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2
@@ -1535,6 +1535,241 @@ class LstmCell(torch.autograd.Function):
         if bias.requires_grad:
             bias_grad_acc(dgates, bias)
         return dx, dh_prev, dc_prev, None, None, None
+
+
+# --------------------------------------------------------------------------- #
+# the recurrent core of a teacher-forced training window, scheduled by hand
+# --------------------------------------------------------------------------- #
+# Between the encoder and the decoder a window is T steps of: prior ConvLSTM (2 cells), posterior ConvLSTM (2 cells) +
+# mu | logvar head + reparameterisation, frame-predictor input conv over cat[tile(a, r), h_t, z_t] + ConvLSTM (2 cells)
+# (dynamics.py:591-641, lstm.py:252-286).  Under autograd each of those was a node: the backward pass paid one split-K
+# combine per data gradient (rac_slab_reduce2: dx | dh_prev), one accumulation add per hidden state with two consumers,
+# and stack / copy kernels for every per-step slice of a batched tensor (profiles/r03i_train_shapes.md: 33 + 39 + 47
+# launches per step).  Here the whole recurrence is ONE autograd node: the forward pass calls the kernels directly and
+# keeps what backward needs; the backward pass walks t = T-1 .. 0 and hands every data-gradient conv's RAW K-split slabs
+# to their consumers as "gradient sources" (rac_grad_src: slabs read through a column window), so that
+#   dh[l, t]  = dx-half of layer l+1's slabs at t  +  dh_prev-half of layer l's slabs at t+1  (+ the head's / decoder's)
+# is summed inside rac_lstm_cell_bwd_srcs; no combine pass and no add exists for it.  Weight and bias gradients go
+# through the same deferred, time-batched launches as before (conv_wgrad_split_acc(..., defer=True)).
+RECURRENT_CORE = os.environ.get("RAC_RECURRENT_CORE", "1") == "1"
+
+
+def _src(t: torch.Tensor, n_slabs: int, row_stride: int, col_off: int = 0):
+    """A gradient source over `t`: [n_slabs][M][row_stride] slabs (or one plain [M][row_stride] map), window at col_off."""
+    return (t, n_slabs, t.numel() // n_slabs if n_slabs > 1 else 0, row_stride, col_off)
+
+
+def _pack_srcs(srcs):
+    arr = (GradSrc * max(1, len(srcs)))()
+    for i, (t, n, stride, row, col) in enumerate(srcs):
+        arr[i] = GradSrc(p=ptr(t), slab_stride=stride, n_slabs=n, row_stride=row, col_off=col, reserved=0)
+    return arr
+
+
+def grad_sum(srcs, out: torch.Tensor, C: int, amax=None):
+    """out[M][C] = sum of the gradient sources (+ max |out| folded into the slot `amax`)."""
+    M = out.numel() // C
+    call("rac_grad_sum", _pack_srcs(srcs), len(srcs), ptr(out), M, C, ptr(amax), stream_ptr())
+    return out
+
+
+def conv_dgrad_slabs(dy, weight, cin: int):
+    """Raw K-split slabs [split][M][cin] of the data gradient w.r.t. the first `cin` input channels of `weight`'s conv
+    (a channel prefix of the transposed weight is a prefix of its parts); nothing combines them: the consumers read
+    them as gradient sources."""
+    B, H, W, Cout = dy.shape
+    k = weight.shape[2]
+    M = B * H * W
+    pw, wslot = weight_parts(weight, transposed=True)
+    split = plan_split_k(M, cin, k * k * _cdiv(Cout, 32), tile128_only=True)
+    slabs = torch.empty((split, M, cin), device=dy.device, dtype=torch.float32)
+    _split_launch(dy, None, amax_for(dy), None, pw, wslot, slabs, B=B, H=H, W=W, k=k, Cin=Cout, Cout=cin, C0=Cout,
+                  split_k=split, slab_stride=M * cin)
+    return slabs, split
+
+
+def recurrent_core_ok(h_all, g: int, z: int, nv: int, cells, head, frame_conv) -> bool:
+    """Configurations the hand-scheduled core takes: plain ConvLSTM cells whose gate convs, the merged posterior head and
+    the frame predictor's 32-channel-padded input conv all run on the split-precision pipe (g >= 128 at 64x64 / 128x128);
+    anything else keeps the autograd path."""
+    if not (RECURRENT_CORE and SPLIT_GEMM and h_all.is_cuda and torch.is_grad_enabled()):
+        return False
+    _, H, W, gg = h_all.shape
+    if gg != g or g % 32 or z % 4 or head is None or not gauss_head_ok((1, H, W, g), head[0]):
+        return False
+    hw = H * W
+    ct = nv + g + z
+    cpad = ct + (-ct) % 32
+    if not (ct >= 128 and hw <= 128 and ((128 // hw) * hw) % 16 == 0):  # TileCat's whole-chunk padding rule
+        return False
+    if not split_supported(H, W, frame_conv.weight.shape[2], cpad, frame_conv.weight.shape[0], 0):
+        return False
+    for cell in cells:
+        w = cell.gates.weight
+        if tuple(w.shape[:2]) != (4 * g, 2 * g) or not split_supported(H, W, w.shape[2], 2 * g, 4 * g, g):
+            return False
+        if not (w.requires_grad and cell.gates.bias.requires_grad):
+            return False
+    return frame_conv.weight.requires_grad and head[0].requires_grad
+
+
+class RecurrentCore(torch.autograd.Function):
+    """h_pred (T*B), mu, logvar (posterior, T*B), h_prior (T*B) = the T-step recurrence over the encoder's latents.
+
+    forward(h_all, prior_all, post_all, *params): `prior_all` / `post_all` are the prior's / posterior's input convs over all
+    T*B latents (run by the caller, batched); `ctx_args` carries the modules and per-step data (not tensors autograd
+    tracks).  Parameter gradients are accumulated in place (None is returned for them)."""
+
+    @staticmethod
+    def forward(ctx, plan, h_all, prior_all, post_all, *params):
+        T, B = plan["T"], plan["B"]
+        g, z = plan["g"], plan["z"]
+        dev = h_all.device
+        _, H, W, _ = h_all.shape
+        M = B * H * W
+        sp = stream_ptr()
+        step = lambda t_: t_.view((T, B) + tuple(t_.shape[1:]))
+        h_steps, prior_steps, post_steps = step(h_all), step(prior_all), step(post_all)
+        one = amax_one(dev)
+        h_pred_all = torch.empty_like(h_all)
+        h_prior_all = torch.empty_like(h_all)
+        mu_all = torch.empty((T * B, H, W, z), device=dev, dtype=torch.float32)
+        lv_all = torch.empty_like(mu_all)
+        hp_s, hq_s, mu_s, lv_s = step(h_pred_all), step(h_prior_all), step(mu_all), step(lv_all)
+        state = {L: list(plan["init_state"][L]) for L in ("prior", "post", "fp")}
+        cells = plan["cells"]  # {L: (cell0, cell1)}
+        head_w, head_b = plan["head"]
+        fconv = plan["frame_conv"]
+        tape = []
+
+        def run_cell(L, l, x, h_out=None):
+            cell = cells[L][l].gates
+            h_prev, c_prev = state[L][l]
+            slabs, n_slabs, stride = conv_forward_split(x, h_prev, cell.weight, want_slabs=True)
+            h = h_out if h_out is not None else torch.empty_like(x)
+            c = torch.empty_like(x)
+            act = torch.empty((B, H, W, 4 * g), device=dev, dtype=torch.float32)
+            call("rac_lstm_cell_fwd", ptr(slabs), n_slabs, stride, ptr(cell.bias), ptr(c_prev), ptr(h), ptr(c), ptr(act), M, g, sp)
+            tag_amax(h, one)  # |h| = |o * tanh(c)| < 1
+            state[L][l] = (h, c)
+            return h, {"x": x, "h_prev": h_prev, "c_prev": c_prev, "act": act, "c": c}
+
+        vs = plan["vs"]  # per step: the tiled vectors (action, robot state(s)) of the frame predictor's input conv
+        nv = plan["nv"]
+        ct = nv + g + z
+        pad = (-ct) % 32
+        fw_pad = padded_weight(fconv.weight, ct + pad)
+        for t in range(T):
+            rec = {}
+            x = retag(prior_steps[t], amax_tag(prior_all))
+            x, rec["prior0"] = run_cell("prior", 0, x)
+            _, rec["prior1"] = run_cell("prior", 1, x, hq_s[t])
+            if plan["draw_prior_noise"]:  # the reference draws the prior's z (and drops it) before the posterior's
+                plan["eps_fn"](mu_s[t])
+            x = retag(post_steps[t], amax_tag(post_all))
+            x, rec["post0"] = run_cell("post", 0, x)
+            h_post, rec["post1"] = run_cell("post", 1, x)
+            slabs, split, stride = conv_forward_split(h_post, None, head_w, want_slabs=True)
+            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_s[t]), ptr(lv_s[t]), M, 2 * z, z, None,
+                 None, sp)
+            eps = plan["eps_fn"](mu_s[t])
+            z_t = torch.empty_like(mu_s[t])
+            call("rac_reparam_fwd", ptr(mu_s[t]), ptr(lv_s[t]), ptr(eps), ptr(z_t), z_t.numel(), sp)
+            v3 = list(vs[t]) + [None] * (3 - len(vs[t]))
+            cat = torch.empty((B, H, W, ct + pad), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
+                 v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
+                 ptr(h_steps[t]), g, ptr(z_t), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
+            tag_amax(cat, slot)
+            x = conv_forward_split(cat, None, fw_pad, fconv.bias)
+            x, rec["fp0"] = run_cell("fp", 0, x)
+            _, rec["fp1"] = run_cell("fp", 1, x, hp_s[t])
+            rec.update(cat=cat, h_post=h_post, eps=eps)
+            tape.append(rec)
+        ctx.plan, ctx.tape = plan, tape
+        ctx.lv_all = lv_all
+        ctx.shape = (T, B, H, W)
+        plan["final_state"] = state
+        return h_pred_all, mu_all, lv_all, h_prior_all
+
+    @staticmethod
+    def backward(ctx, d_hpred, d_mu, d_lv, d_hprior):
+        plan, tape = ctx.plan, ctx.tape
+        T, B, H, W = ctx.shape
+        g, z, nv = plan["g"], plan["z"], plan["nv"]
+        M = B * H * W
+        dev = ctx.lv_all.device
+        sp = stream_ptr()
+        cells, fconv = plan["cells"], plan["frame_conv"]
+        head_w, head_b = plan["head"]
+        ct = nv + g + z
+        cpad = ct + (-ct) % 32
+        fw_pad = padded_weight(fconv.weight, cpad)
+        step = lambda t_: None if t_ is None else t_.contiguous().view((T, B) + tuple(t_.shape[1:]))
+        d_hpred, d_mu, d_lv, d_hprior = step(d_hpred), step(d_mu), step(d_lv), step(d_hprior)
+        lv_s = ctx.lv_all.view((T, B, H, W, z))
+        d_h_all = torch.empty((T, B, H, W, g), device=dev, dtype=torch.float32)
+        d_prior_all = torch.empty_like(d_h_all)
+        d_post_all = torch.empty_like(d_h_all)
+        slot_prior, slot_post = amax_slot(dev), amax_slot(dev)
+        carry = {L: [None, None] for L in ("prior", "post", "fp")}  # per layer: (dc_prev, dh_prev source) from step t+1
+
+        def cell_bwd(L, l, rec, srcs):
+            cell = cells[L][l].gates
+            nxt = carry[L][l]
+            if nxt is not None and nxt[1] is not None:
+                srcs = srcs + [nxt[1]]
+            dgates = torch.empty_like(rec["act"])
+            dc_prev = torch.empty_like(rec["c"])
+            slot = amax_slot(dev)
+            call("rac_lstm_cell_bwd_srcs", _pack_srcs(srcs), len(srcs), ptr(nxt[0]) if nxt is not None else None,
+                 ptr(rec["act"]), ptr(rec["c_prev"]), ptr(rec["c"]), ptr(dgates), ptr(dc_prev), M, g, ptr(slot), sp)
+            tag_amax(dgates, slot)
+            first = is_zero(rec["h_prev"])  # t = 0: nothing flows into the (all-zero, constant) initial state
+            cin = g if first else 2 * g
+            slabs, n = conv_dgrad_slabs(dgates, cell.weight, cin)
+            conv_wgrad_split_acc(dgates, rec["x"], rec["h_prev"], cell.weight, defer=True)
+            bias_grad_acc(dgates, cell.bias)
+            carry[L][l] = None if first else (dc_prev, _src(slabs, n, cin, g))
+            return _src(slabs, n, cin, 0)
+
+        for t in range(T - 1, -1, -1):
+            rec = tape[t]
+            # frame predictor: layer 1 (its h feeds the decoder), layer 0, then the input conv over cat[v | h_t | z_t]
+            ext = [_src(d_hpred[t], 1, g)] if d_hpred is not None else []
+            s1 = cell_bwd("fp", 1, rec["fp1"], ext)
+            s0 = cell_bwd("fp", 0, rec["fp0"], [s1])
+            dy_f = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            tag_amax(grad_sum([s0], dy_f, g, slot), slot)
+            dcat, n_c = conv_dgrad_slabs(dy_f, fw_pad, cpad)
+            conv_wgrad_split_acc(dy_f, rec["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
+            bias_grad_acc(dy_f, fconv.bias)
+            grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
+            # posterior: reparameterisation + KL gradients -> merged head -> layer 1, layer 0 -> its input conv's output
+            dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(lv_s[t]), ptr(rec["eps"]),
+                 ptr(d_mu[t]) if d_mu is not None else None, ptr(d_lv[t]) if d_lv is not None else None, ptr(dy_h), M, z,
+                 ptr(slot), sp)
+            tag_amax(dy_h, slot)
+            dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
+            conv_wgrad_split_acc(dy_h, rec["h_post"], None, head_w, defer=True)
+            bias_grad_acc(dy_h, head_b)
+            q1 = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
+            q0 = cell_bwd("post", 0, rec["post0"], [q1])
+            grad_sum([q0], d_post_all[t], g, slot_post)
+            # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
+            ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
+            p1 = cell_bwd("prior", 1, rec["prior1"], ext)
+            p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
+            grad_sum([p0], d_prior_all[t], g, slot_prior)
+            tape[t] = None  # (launches are stream ordered: what this step allocated may be reused by the next)
+        ctx.tape = None
+        flat = lambda t_: t_.view((T * B, H, W, g))
+        d_prior_all, d_post_all = tag_amax(flat(d_prior_all), slot_prior), tag_amax(flat(d_post_all), slot_post)
+        return (None, flat(d_h_all), d_prior_all, d_post_all) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 class GroupNorm(torch.autograd.Function):

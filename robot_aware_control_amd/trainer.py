@@ -287,7 +287,7 @@ class PredictionTrainer(object):
         roots, seeds, log = [], [], []  # autograd roots, their incoming grads, (name, tensor, index) for the readback
         n_steps = cf.n_past + cf.n_future - 1
 
-        def add_losses(x_pred, i, mu, logvar, mu_p, logvar_p):
+        def add_losses(x_pred, i, mu, logvar, mu_p, logvar_p, kl_here=True):
             x_i, m_i = x[i], mask[i]
             rec = self._recon_loss(x_pred, x_i.contiguous(), m_i.contiguous(), batch_weight)
             roots.append(rec)
@@ -300,6 +300,10 @@ class PredictionTrainer(object):
                         sub = ops.ReconLoss.apply(x_pred.detach()[idx].contiguous(), x_i[idx].contiguous(),
                                                   m_i[idx].contiguous(), None, 0, 0.0)
                         log.extend([(f"{r}_robot_loss", sub, 1), (f"{r}_world_loss", sub, 2)])
+            if kl_here:
+                add_kl(mu, logvar, mu_p, logvar_p)
+
+        def add_kl(mu, logvar, mu_p, logvar_p):
             kl = ops.KLLoss.apply(mu, logvar, mu_p, logvar_p, bs)
             roots.append(kl)
             seeds.append(self._seed(float(cf.beta)))
@@ -322,8 +326,13 @@ class PredictionTrainer(object):
                 mask[:T] if dontcare else None)
             x_pred_all = ops.Composite.apply(x4, x[:T].reshape((T * bs,) + tuple(x.shape[2:])).contiguous())
             x_preds = x_pred_all.view((T, bs) + tuple(x_pred_all.shape[1:])).unbind(0)
+            batched = self.model.sequence_batched
             for t in range(T):
-                add_losses(x_preds[t], t + 1, mus[t], logvars[t], mu_ps[t], logvar_ps[t])
+                add_losses(x_preds[t], t + 1, mus[t], logvars[t], mu_ps[t], logvar_ps[t], kl_here=batched is None)
+            if batched is not None:
+                # sum_t KL_t: every term is a sum over its elements / bs (losses.py:97-106), so the window's KL is ONE
+                # launch over all T*B samples' elements (and one backward launch writing the batched gradients)
+                add_kl(*batched)
         else:
             x_pred = None
             skip = None

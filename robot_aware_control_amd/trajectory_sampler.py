@@ -35,8 +35,8 @@ def shard_bounds(n: int, world: int, rank: int):
 def gather_costs(local: torch.Tensor, N: int, world: int, rank: int) -> np.ndarray:
     """All ranks' per-candidate fp64 cost sums -> one float64[N] on every rank (one all-gather; RCCL on the
     GPU path, any backend works).  Slices are padded to a common width because shards may differ by one."""
-    if world == 1 and not parallel_env.active():
-        return local.cpu().numpy()
+    if world == 1 and not (parallel_env.active() and dist.get_world_size() == 1):
+        return local.cpu().numpy()  # (a one-rank group under RAC_DIST_FORCE=1 still runs the collective: RCCL rehearsal)
     width = (N + world - 1) // world
     send = torch.zeros(width, device=local.device, dtype=torch.float64)
     send[:local.numel()] = local

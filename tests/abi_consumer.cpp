@@ -96,6 +96,9 @@ int main(int argc, char** argv) {
   printf("sizeof_rac_absmax_job %zu\n", sizeof(rac_absmax_job));
   printf("sizeof_rac_frag_job %zu\n", sizeof(rac_frag_job));
   printf("offsetof_rac_frag_job_block_begin %zu\n", offsetof(rac_frag_job, block_begin));
+  printf("sizeof_rac_grad_src %zu\n", sizeof(rac_grad_src));
+  printf("offsetof_rac_grad_src_n_slabs %zu\n", offsetof(rac_grad_src, n_slabs));
+  printf("offsetof_rac_grad_src_col_off %zu\n", offsetof(rac_grad_src, col_off));
   if (rac_version() != RAC_ABI_VERSION || strcmp(rac_device_arch(), "gfx950") != 0) return 1;
   if (argc > 1 && strcmp(argv[1], "gpu") == 0) return gpu_conv_check();
   return 0;

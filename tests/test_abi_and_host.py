@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 30
     assert declared == set(rac.EXPORTS), declared ^ set(rac.EXPORTS)
     lib = rac.load()  # dlopen + every symbol typed; raises on a missing one
-    assert lib.rac_version() == 5
+    assert lib.rac_version() == 6
     assert lib.rac_device_arch() == b"gfx950"
 
 
@@ -48,7 +48,7 @@ def test_ctypes_signatures_match_the_header():
     from robot_aware_control_amd import _lib
     protos = _prototypes()
     assert set(protos) == set(_lib._SIGS)
-    structs = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs}
+    structs = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs, "rac_grad_src": _lib.GradSrc}
 
     def expected(ctype):
         t = re.sub(r"\bconst\b", "", ctype).replace(" ", "")
@@ -88,12 +88,14 @@ def test_compiled_consumer_sees_the_same_structs():
     kv = dict(line.split() for line in res.stdout.splitlines())
     assert int(kv["rac_version"]) == int(kv["RAC_ABI_VERSION"]) == _lib.ABI_VERSION and kv["arch"] == "gfx950"
     for cname, cls in (("rac_conv_args", _lib.ConvArgs), ("rac_wgrad_args", _lib.WgradArgs),
-                       ("rac_absmax_job", _lib.AbsmaxJob), ("rac_frag_job", _lib.FragJob)):
+                       ("rac_absmax_job", _lib.AbsmaxJob), ("rac_frag_job", _lib.FragJob),
+                       ("rac_grad_src", _lib.GradSrc)):
         assert int(kv[f"sizeof_{cname}"]) == C.sizeof(cls), cname
     for key, val in kv.items():
-        m = re.match(r"offsetof_(rac_conv_args|rac_wgrad_args|rac_frag_job)_(\w+)", key)
+        m = re.match(r"offsetof_(rac_conv_args|rac_wgrad_args|rac_frag_job|rac_grad_src)_(\w+)", key)
         if m:
-            cls = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs, "rac_frag_job": _lib.FragJob}[m.group(1)]
+            cls = {"rac_conv_args": _lib.ConvArgs, "rac_wgrad_args": _lib.WgradArgs, "rac_frag_job": _lib.FragJob,
+                   "rac_grad_src": _lib.GradSrc}[m.group(1)]
             assert getattr(cls, m.group(2)).offset == int(val), key
 
 

@@ -213,6 +213,35 @@ def test_train_step_vs_oracle_g128(dev, seq, monkeypatch):
     assert dot / np.sqrt(na * nb) > GRAD_COS
 
 
+@pytest.mark.parametrize("tag", ["ra", "vanilla"])
+def test_recurrent_core_matches_the_autograd_path(dev, tag, monkeypatch):
+    """ops.RecurrentCore -- the T-step recurrence as ONE autograd node whose backward hands the data-gradient convs' raw
+    K-split slabs to their consumers (rac_lstm_cell_bwd_srcs, rac_grad_sum, rac_reparam_head_bwd) -- against the per-step
+    autograd path (one node per cell, rac_slab_reduce2 + accumulation adds): the same conv kernels on the same
+    operands, only the order in which a hidden state's gradient addends are summed differs.  Losses to 1e-6, every
+    parameter's gradient to 1e-5 norm-wise; and the core really ran (no silent fallback)."""
+    from robot_aware_control_amd import ops
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-4, **FLAGSETS[tag])
+    sd = orc.make_weights(cfg, seed=3, randomize_bn_stats=False)
+    data = syn.synth_video(seed=9, T=5, B=4)
+    eps = syn.synth_eps(seed=10, steps=4, B=4, z=16, h=8, w=8)
+    out = {}
+    for core in (True, False):
+        monkeypatch.setattr(ops, "RECURRENT_CORE", core)
+        tr = make_trainer(cfg, sd, dev)
+        queue = [e for pair in eps for e in pair]
+        tr.model.eps_source = lambda shape: queue.pop(0)
+        tr.optimizer.step = lambda: None
+        losses = tr._train_step(data)
+        assert (tr.model.sequence_batched is not None) == core
+        out[core] = (losses, {k: p.grad.detach().double().cpu().clone() for k, p in tr.model.named_parameters()})
+    for k, v in out[False][0].items():
+        assert abs(out[True][0][k] - v) <= 1e-6 * abs(v) + 1e-9, k
+    for k, b in out[False][1].items():
+        a = out[True][1][k]
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5, k
+
+
 def test_train_step_128x128_vs_oracle(dev):
     """BASELINE configs[4] geometry (128x128 frames -> 16x16 latent maps, larger than a GEMM tile) at plumbing
     width: the ConvLSTM gate convs take the image-rows + halo kernel, forward and data gradient."""
