@@ -1612,6 +1612,12 @@ typedef __fp16 h16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 #define RAC_LDS_PTR(T, base, off) reinterpret_cast<__attribute__((address_space(3))) T*>( \
     (__attribute__((address_space(3))) unsigned char*)(base) + (off))
 
+// Swizzle of the [pixel row][256 B] operand images of the weight-gradient kernels: the 32-byte segment index of row r is
+// XORed with wg_swz(r).  A half-wave of a transposing read (ds_read_b64_tr_b16) touches rows {a .. a+3} and {a+8 .. a+11},
+// 32 bytes each, and needs eight different values there: the low two bits separate four consecutive rows, bit 2 the
+// two groups (measured conflict free, tools/micro/lds_conflicts.hip).
+__device__ __forceinline__ int wg_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
 // the 16x16x32 operand of lane (i = l & 15, g = l >> 4): column i of pixel rows 8g .. 8g+7 of a [row][256 B] image
 __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int addr) {
   typedef __fp16 h16x8 __attribute__((__vector_size__(8 * sizeof(__fp16))));
@@ -1657,12 +1663,20 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
 
   // ---- staging roles: row kk = tid >> 3 of the 32-row block; dy: 16 channels (segment tid & 7), x: 8 channels ----
   const int skk = tid >> 3, ssub = tid & 7;
-  const int ssw = (skk & 3) | (((skk >> 3) & 1) << 2);
+  const int ssw = wg_swz(skk);
   // dy roles of the 64-co form: threads 0..127 (waves 0 and 1), row tid >> 2, 16-channel segment tid & 3
   const bool dy_role = WMW == 2 || tid < 128;
   const int dkk = WMW == 2 ? skk : (tid >> 2) & 31, dsub = WMW == 2 ? ssub : tid & 3;
-  const int dsw = (dkk & 3) | (((dkk >> 3) & 1) << 2);
+  const int dsw = wg_swz(dkk);
   const int dy_lds = dkk * 256 + ((dsub ^ dsw) * 32);                       // + buf * DYB + part * 8192
+  // A dy thread stores its 16 channels as the two 16-byte halves of one 32-byte segment.  LDS stores retire 8 lanes x 16
+  // bytes per clock into 32 banks (addresses mod 128 B: measured, tools/micro/lds_conflicts.hip), and the 8 lanes of one
+  // store instruction sit either in the SAME half of the eight segments of a row (128-co form: segments s and s + 4
+  // collide) or of four segments of two rows (64-co form: the rows collide) -- round 3's 2-way conflict on every dy
+  // store (18-20 % of the kernels' LDS cycles, profiles/r03i_sq_summary.md).  So half of them take their halves in the
+  // opposite order: by bit 2 of the segment, or by the row's parity.  The loads are issued in the matching order: no
+  // data moves, only lane-constant address bits.
+  const unsigned dflip = (unsigned)(WMW == 2 ? ((dsub ^ dsw) >> 2) & 1 : dkk & 1) * 16u;
   const int x_lds = X_BASE + skk * 256 + (((ssub >> 1) ^ ssw) * 32) + (ssub & 1) * 16;  // part 1: segment ^ 4 -> ^ 128
   const bool dy_ch_ok = co0 + dsub * 16 < p.Cout;
   const bool x_ch_ok = cl0 + ssub * 8 < Cs;
@@ -1678,15 +1692,15 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
         const unsigned pbytes = (unsigned)((long)p.R * p.W * p.Cout * 2);
         const rsrc_t rs = make_rsrc(p.dy[t], 2u * pbytes);
         const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 2u;
-        rd[0] = load16(rs, ok ? off : OOB);
-        rd[1] = load16(rs, ok ? off + 16u : OOB);
-        rd[2] = load16(rs, ok ? off + pbytes : OOB);
-        rd[3] = load16(rs, ok ? off + pbytes + 16u : OOB);
+        rd[0] = load16(rs, ok ? off + dflip : OOB);           // (the half this thread stores first)
+        rd[1] = load16(rs, ok ? off + (dflip ^ 16u) : OOB);
+        rd[2] = load16(rs, ok ? off + pbytes + dflip : OOB);
+        rd[3] = load16(rs, ok ? off + pbytes + (dflip ^ 16u) : OOB);
       } else {
         const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
         const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+        for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + ((16u * v) ^ (2u * dflip)) : OOB);  // channels 8..15 first
       }
     }
     if (++dc == p.W) dc = 0, ++dg;
@@ -1722,8 +1736,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
-      *reinterpret_cast<u32x4*>(d) = q0[part];
-      *reinterpret_cast<u32x4*>(d + 16) = q1[part];
+      *reinterpret_cast<u32x4*>(d + dflip) = q0[part];
+      *reinterpret_cast<u32x4*>(d + (dflip ^ 16u)) = q1[part];
     }
   };
   auto store_x = [&](int slot) {
@@ -1738,7 +1752,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
 
   // ---- fragment addresses (lane constants) ----
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
-  const int fsw = fq | ((fg & 1) << 2);
+  const int fsw = wg_swz(8 * fg + fq);  // (= that of row + 4, the second half of a fragment)
   const int lane_base = (8 * fg + fq) * 256 + fp * 8;
   int offA[4], offB[2][NU];
 #pragma unroll
@@ -1882,15 +1896,16 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
   // dy: threads 0..127, row tid >> 2 of the 32-row block, 16-channel segment tid & 3 (co 64..127 of the rows stay zero)
   const bool dy_role = tid < 128;
   const int dkk = (tid >> 2) & 31, dsub = tid & 3;
-  const int dsw = (dkk & 3) | (((dkk >> 3) & 1) << 2);
+  const int dsw = wg_swz(dkk);
   const int dy_lds = dkk * 256 + ((dsub ^ dsw) * 32);
+  const unsigned dflip = (unsigned)(dkk & 1) * 16u;  // (see wgrad16_kernel: conflict-free staging stores)
   const bool dy_ch_ok = co0 + dsub * 16 < p.Cout;
   // x: staged row i = tid >> 3 (and 32 + (tid >> 3) for tid < 16), 8 channels tid & 7; row i holds image row
   // 32 * group + i - 1
   const int ssub = tid & 7;
   const bool x_ch_ok = cl0 + ssub * 8 < Cs;
   auto x_lds_of = [&](int i) {
-    const int sw = (i & 3) | (((i >> 3) & 1) << 2);
+    const int sw = wg_swz(i);
     return X_BASE + i * 256 + (((ssub >> 1) ^ sw) * 32) + (ssub & 1) * 16;
   };
   const int xi0 = tid >> 3, xi1 = 32 + (tid >> 3);
@@ -1905,7 +1920,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
       const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
       const unsigned off = (unsigned)(((long)r * p.W + col) * p.Cout + co0 + dsub * 16) * 4u;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + 16u * v : OOB);
+      for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + ((16u * v) ^ (2u * dflip)) : OOB);
     }
   };
   auto issue_x = [&](int gidx, int col) {
@@ -1937,8 +1952,8 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
       unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
-      *reinterpret_cast<u32x4*>(d) = q0[part];
-      *reinterpret_cast<u32x4*>(d + 16) = q1[part];
+      *reinterpret_cast<u32x4*>(d + dflip) = q0[part];
+      *reinterpret_cast<u32x4*>(d + (dflip ^ 16u)) = q1[part];
     }
   };
   auto store_x = [&](int slot) {
@@ -1955,7 +1970,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
 
   // ---- fragment addresses (lane constants) ----
   const int fg = lane >> 4, fq = (lane & 15) >> 2, fp = lane & 3;
-  const int fsw = fq | ((fg & 1) << 2);
+  const int fsw = wg_swz(8 * fg + fq);
   const int lane_base = (8 * fg + fq) * 256 + fp * 8;
   int offA[4];
 #pragma unroll
@@ -1967,7 +1982,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_allky_kernel(Wgrad16P p) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int i = ky + 8 * fg + fq + 4 * h;
-      const int sw = (i & 3) | (((i >> 3) & 1) << 2);
+      const int sw = wg_swz(i);
 #pragma unroll
       for (int part = 0; part < 2; ++part) offB[ky][part][h] = X_BASE + i * 256 + fp * 8 + (((part * 4 + wn) ^ sw) * 32);
     }

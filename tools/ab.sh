@@ -4,7 +4,7 @@
 w=$1; rounds=$2; shift 2
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
-    out=$(env $v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-cem-ra --cem-opt-iter 1 --workload $w --cem-iters 2 2>/dev/null)
+    out=$(env $v python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-exact --no-side --no-cem-ra --cem-opt-iter 1 --workload $w --cem-iters 2 2>/dev/null)
     python - "$v" "$out" <<'PY'
 import json, sys
 d = json.loads(sys.argv[2])

@@ -7,7 +7,7 @@ tag=${1:-prof}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-T="--workload train --steps 5 --warmup 2 --no-cpu-baseline --no-exact"
+T="--workload train --steps 5 --warmup 2 --no-cpu-baseline --no-exact --no-side"
 C="--workload cem --cem-iters 1 --cem-warmup 1 --no-cpu-baseline --no-exact --no-cem-ra --cem-opt-iter 1"
 echo "[profiles] kernel trace + stats, train" >&2
 RAC_SHAPE_LOG=$out/train_shapes.json rocprofv3 --kernel-trace --stats -d "$out/stats_train" -o run --output-format csv -- python3 bench.py $T > "$out/stats_train.json" 2> "$out/stats_train.err"
@@ -24,7 +24,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_gemm_cem" -o run --output-format csv -- $G2 > /dev/null 2> "$out/pmc_${ctr}_2.err"
   rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_wgrad5" -o run --output-format csv -- $G3 > /dev/null 2> "$out/pmc_${ctr}_3.err"
   rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_wgrad3" -o run --output-format csv -- $G4 > /dev/null 2> "$out/pmc_${ctr}_4.err"
-  rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_train" -o run --output-format csv -- python3 bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline --no-exact > /dev/null 2> "$out/pmc_${ctr}_5.err"
+  rocprofv3 --pmc $ctr -d "$out/pmc_${ctr}_train" -o run --output-format csv -- python3 bench.py --workload train --steps 2 --warmup 1 --no-cpu-baseline --no-exact --no-side > /dev/null 2> "$out/pmc_${ctr}_5.err"
 done
 SQ1="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 SQ2="SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
