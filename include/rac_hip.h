@@ -273,6 +273,11 @@ int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, i
 /* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,
                     int64_t n, int32_t N, uint32_t* out_amax, void* stream);
+/* rac_slab_reduce (no bias) + rac_col_stats in one pass: out[M][C] = sum of slabs, and the BatchNorm batch statistics of
+ * `groups` row groups (vgg_64.py:8-18 in training mode: one nn.BatchNorm2d call per time step batched along M):
+ * stats[g][0][c] += sum, stats[g][1][c] += sum of squares (fp64, zeroed by the caller).  C = 4 * 2^k <= 1024. */
+int rac_slab_reduce_stats(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, double* stats, int64_t M,
+                          int32_t C, int32_t groups, uint32_t* out_amax, void* stream);
 /* as rac_slab_reduce for [M][N] slabs, but columns [0,o_split) go to out0 (row stride o_split) and the rest to
  * out1 (row stride N - o_split): the split-K combine of a DGRAD whose input was a virtual concat, and of the merged
  * mu | logvar head conv (lstm.py:273-274; n_slabs = 1 splits a finished [M][N] tensor) */

@@ -105,6 +105,7 @@ _SIGS = {
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
     "rac_colsum_acc": [vp, vp, i64, i32, vp],
     "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp, vp],
+    "rac_slab_reduce_stats": [vp, i32, i64, vp, vp, i64, i32, i32, vp, vp],
     "rac_slab_reduce2": [vp, i32, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp],
     "rac_cat2_channels": [vp, i32, vp, i32, vp, i64, vp, vp],
     "rac_colsum_steps": [C.POINTER(vp), i32, vp, i64, i32, vp],

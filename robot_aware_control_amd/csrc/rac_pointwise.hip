@@ -164,6 +164,96 @@ __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float
   }
 }
 
+// The same two passes for channel counts C = 4 * 2^k <= 1024 (every layer of the model), walking ROWS: a thread owns four
+// channels -- its per-channel constants (scale, shift, mean, 1 / std, the two means of the reduce pass) are set up once,
+// not re-derived per element through 64-bit index divisions and fp64 multiplies as in the element-indexed kernels above
+// (which ran at 2.4-2.8 TB/s: instruction bound) -- and streams 16-byte vectors of rows r0 + tid / C4, + 256 / C4, ...
+__global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const f32x4* dy, const f32x4* x, const f32x4* scale,
+                                                                 const f32x4* shift, const f32x4* mean, const f32x4* invstd,
+                                                                 double* sums, long Mg, int C4, int rows_per_block, int bpg) {
+  __shared__ f32x4 s1[256], s2[256];
+  const int tid = threadIdx.x;
+  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int g = blockIdx.x / bpg;
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
+  const int gc = g * C4 + c4;
+  const f32x4 sc = scale[gc], sh = shift[gc], mu = mean[gc], is = invstd[gc];
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (long r = r_begin + rl; r < r_end; r += rpi) {
+    const f32x4 xv = x[r * C4 + c4], dv = dy[r * C4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = xv[e] * sc[e] + sh[e];
+      const float dz = dv[e] * (z > 0.f ? 1.f : 0.2f);
+      a1[e] += dz;
+      a2[e] += dz * ((xv[e] - mu[e]) * is[e]);
+    }
+  }
+  s1[tid] = a1;
+  s2[tid] = a2;
+  __syncthreads();
+  if (tid < C4) {
+    f32x4 t1 = s1[tid], t2 = s2[tid];
+    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4 + tid], t2 += s2[k * C4 + tid];
+    double* sg = sums + (long)g * 8 * C4 + 4 * tid;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(sg + e, (double)t1[e]);
+      atomicAdd(sg + 4 * C4 + e, (double)t2[e]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_rows_kernel(const f32x4* dy, const f32x4* x, const float* scale,
+                                                                const float* shift, const float* mean, const float* invstd,
+                                                                const double* sums, f32x4* dx, float* dgamma, float* dbeta,
+                                                                long Mg, int C4, int G, int rows_per_block, int bpg,
+                                                                unsigned* amax) {
+  const int tid = threadIdx.x, C = 4 * C4;
+  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int g = blockIdx.x / bpg;
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
+  const double invM = 1.0 / (double)Mg;
+  f32x4 sc, sh, mu, is, m1, m2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int gc = g * C + 4 * c4 + e;
+    sc[e] = scale[gc], sh[e] = shift[gc], mu[e] = mean[gc], is[e] = invstd[gc];
+    const double* sg = sums + (long)g * 2 * C;
+    m1[e] = (float)(sg[4 * c4 + e] * invM), m2[e] = (float)(sg[C + 4 * c4 + e] * invM);
+  }
+  unsigned mx = 0;
+#pragma unroll 4
+  for (long r = r_begin + rl; r < r_end; r += rpi) {
+    const f32x4 xv = x[r * C4 + c4], dv = dy[r * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (the arithmetic of bn_bwd_apply_kernel, element by element)
+      const float z = xv[e] * sc[e] + sh[e];
+      const float dz = dv[e] * (z > 0.f ? 1.f : 0.2f);
+      const float xh = (xv[e] - mu[e]) * is[e];
+      o[e] = sc[e] * (dz - m1[e] - xh * m2[e]);
+      mx = max(mx, absbits(o[e]));
+    }
+    dx[r * C4 + c4] = o;
+  }
+  if (amax) amax_commit_block(mx, amax);
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      double a = 0., b = 0.;
+      for (int gg = 0; gg < G; ++gg) {
+        a += sums[(long)gg * 2 * C + C + c];
+        b += sums[(long)gg * 2 * C + c];
+      }
+      dgamma[c] += (float)a;
+      dbeta[c] += (float)b;
+    }
+  }
+}
+
 // ------------------------------------------------------------ pool / upsample
 template <typename T>
 __global__ void maxpool2_fwd_kernel(const T* x, T* y, int B, int H, int W, int Cv) {
@@ -458,6 +548,45 @@ __global__ void slab_reduce2_kernel4(const f32x4* slabs, int n_slabs, long slab_
   if (amax1) {
     __syncthreads();
     amax_commit_block(mx1, amax1);
+  }
+}
+
+// split-K combine of a train-mode vgg layer's conv + its BatchNorm batch statistics in one pass (row-walking form, C =
+// 4 * 2^k): out = sum of slabs; stats[g][0][c] += sum over the group's rows, stats[g][1][c] += sum of squares (fp64 atomics)
+__global__ __launch_bounds__(256) void slab_reduce_stats_rows_kernel(const f32x4* slabs, int n_slabs, long slab_stride4,
+                                                                     f32x4* out, double* stats, long Mg, int C4,
+                                                                     int rows_per_block, int bpg, unsigned* amax) {
+  __shared__ f32x4 s1[256], s2[256];
+  const int tid = threadIdx.x;
+  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int g = blockIdx.x / bpg;
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  unsigned mx = 0;
+#pragma unroll 2
+  for (long r = r_begin + rl; r < r_end; r += rpi) {
+    const long i = r * C4 + c4;
+    f32x4 v = slabs[i];
+    for (int sidx = 1; sidx < n_slabs; ++sidx) v += slabs[sidx * slab_stride4 + i];
+    out[i] = v;
+    a1 += v;
+    a2 += v * v;
+    mx = max(max(mx, max(absbits(v.x), absbits(v.y))), max(absbits(v.z), absbits(v.w)));
+  }
+  if (amax) amax_commit_block(mx, amax);
+  s1[tid] = a1;
+  s2[tid] = a2;
+  __syncthreads();
+  if (tid < C4) {
+    f32x4 t1 = s1[tid], t2 = s2[tid];
+    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4 + tid], t2 += s2[k * C4 + tid];
+    double* sg = stats + (long)g * 8 * C4 + 4 * tid;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      atomicAdd(sg + e, (double)t1[e]);
+      atomicAdd(sg + 4 * C4 + e, (double)t2[e]);
+    }
   }
 }
 
@@ -790,12 +919,40 @@ static int rows_per_block_for(long M, int* nblocks) {
   return rpb;
 }
 
+// the row-walking BatchNorm backward kernels: C = 4 * 2^k <= 1024; `bpg` workgroups per statistics group (about
+// `max_blocks` in total), each a whole number of 256 / (C / 4)-row passes
+static bool bn_rows_form(int C, long Mg, int groups, int max_blocks, int* bpg, int* rows_per_block) {
+  const int C4 = C / 4;
+  if (C % 4 || C4 < 1 || C4 > 256 || (C4 & (C4 - 1))) return false;
+  static const bool off = getenv("RAC_BN_ROWS") && getenv("RAC_BN_ROWS")[0] == '0';  // A/B switch: the element-indexed kernels
+  if (off) return false;
+  const int rpi = 256 / C4;
+  long nb = max_blocks / groups;
+  if (nb < 1) nb = 1;
+  const long most = (Mg + 4L * rpi - 1) / (4L * rpi);  // at least four passes per workgroup
+  if (nb > most) nb = most;
+  long rpb = (Mg + nb - 1) / nb;
+  rpb = (rpb + rpi - 1) / rpi * rpi;
+  *rows_per_block = (int)rpb;
+  *bpg = (int)((Mg + rpb - 1) / rpb);
+  return true;
+}
+
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                       const float* invstd, double* sums, int64_t M, int32_t C, int32_t groups, void* stream) {
   RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
               "rac_bn_bwd_reduce: bad args");
   int rpb;
   const long Mg = M / groups;
+  int bpg_rows, rpb_rows;
+  // (about 1024 workgroups: every one ends in 8 fp64 atomics per channel quad onto the same 2 C addresses)
+  if (bn_rows_form(C, Mg, groups, 1024, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
+      aligned16(shift) && aligned16(mean) && aligned16(invstd)) {
+    hipLaunchKernelGGL(bn_bwd_reduce_rows_kernel, dim3(bpg_rows * groups), dim3(256), 0, ST(stream), (const f32x4*)dy,
+                       (const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)mean, (const f32x4*)invstd,
+                       sums, Mg, C / 4, rpb_rows, bpg_rows);
+    return check_launch("rac_bn_bwd_reduce");
+  }
   dim3 grid = reduce_grid(Mg, C, &rpb);
   const int bpg = (int)grid.x;
   grid.x *= groups;
@@ -811,6 +968,14 @@ int rac_bn_bwd_apply(const float* dy, const float* x, const float* scale, const 
                   M % groups == 0,
               "rac_bn_bwd_apply: bad args");
   RAC_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "rac_bn_bwd_apply: dgamma/dbeta must come together");
+  int bpg_rows, rpb_rows;
+  if (bn_rows_form(C, M / groups, groups, dx_amax ? 512 : 2048, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) &&
+      aligned16(dx)) {
+    hipLaunchKernelGGL(bn_bwd_apply_rows_kernel, dim3(bpg_rows * groups), dim3(256), 0, ST(stream), (const f32x4*)dy,
+                       (const f32x4*)x, scale, shift, mean, invstd, sums, (f32x4*)dx, dgamma, dbeta, (long)(M / groups), C / 4,
+                       groups, rpb_rows, bpg_rows, dx_amax);
+    return check_launch("rac_bn_bwd_apply");
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for_amax((long)M * C, dx_amax)), dim3(256), 0, ST(stream), dy, x, scale, shift,
                      mean, invstd, sums, dx, dgamma, dbeta, (long)(M / groups), C, groups, dx_amax);
   return check_launch("rac_bn_bwd_apply");
@@ -966,6 +1131,21 @@ int rac_slab_reduce2(const float* slabs, int32_t n_slabs, int64_t slab_stride, c
                      0, ST(stream), slabs, n_slabs, (long)slab_stride, bias, out0, out1, (long)M, N, o_split, out0_amax,
                      out1_amax);
   return check_launch("rac_slab_reduce2");
+}
+
+static bool bn_rows_form(int C, long Mg, int groups, int max_blocks, int* bpg, int* rows_per_block);
+
+int rac_slab_reduce_stats(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* out, double* stats, int64_t M,
+                          int32_t C, int32_t groups, uint32_t* out_amax, void* stream) {
+  RAC_REQUIRE(slabs && out && stats && n_slabs >= 1 && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
+              "rac_slab_reduce_stats: bad args");
+  int bpg, rpb;
+  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, out_amax ? 512 : 2048, &bpg, &rpb) && slab_stride % 4 == 0 &&
+                  aligned16(slabs) && aligned16(out),
+              "rac_slab_reduce_stats: C must be 4 * 2^k <= 1024, 16-byte aligned slabs (use rac_slab_reduce + rac_col_stats)");
+  hipLaunchKernelGGL(slab_reduce_stats_rows_kernel, dim3(bpg * groups), dim3(256), 0, ST(stream), (const f32x4*)slabs,
+                     n_slabs, (long)(slab_stride / 4), (f32x4*)out, stats, (long)(M / groups), C / 4, rpb, bpg, out_amax);
+  return check_launch("rac_slab_reduce_stats");
 }
 
 int rac_col_stats(const float* x, double* stats, int64_t M, int32_t C, int32_t groups, void* stream) {

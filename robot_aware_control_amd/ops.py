@@ -747,6 +747,9 @@ def per_image_ok(H: int, W: int) -> bool:
     return H * W > 128 or (H * W) % 16 == 0
 
 
+SLAB_STATS = os.environ.get("RAC_SLAB_STATS", "1") == "1"  # split-K combine + BatchNorm statistics in one pass
+
+
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
                        want_slabs=False, groups=1, x0_up=False, per_image=False):
     """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
@@ -791,6 +794,12 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     else:
         slabs = torch.empty((split, M * Cout), device=x0.device, dtype=torch.float32)
         _split_launch(x0, x1, a0, a1, pw, wslot, slabs, split_k=split, slab_stride=M * Cout, **kw)
+        if (SLAB_STATS and stats is not None and bias is None and Cout % 4 == 0 and (Cout // 4) & (Cout // 4 - 1) == 0
+                and Cout <= 1024):
+            # a train-mode vgg layer: the combine pass also leaves the BatchNorm batch statistics (one read of the slabs)
+            call("rac_slab_reduce_stats", ptr(slabs), split, M * Cout, ptr(out), ptr(stats), M, Cout, groups, ptr(slot),
+                 stream_ptr())
+            return tag_amax(out, slot)
         call("rac_slab_reduce", ptr(slabs), split, M * Cout, ptr(bias), ptr(out), M * Cout, Cout, ptr(slot),
              stream_ptr())
         if stats is not None:
@@ -943,6 +952,12 @@ def plan_wgrad_split(tiles: int, groups: int) -> int:
     forced = os.environ.get("RAC_WGRAD_SPLITK")
     if forced:
         return max(1, min(int(forced), groups))
+    if tiles >= 512:
+        # more than one round of workgroups without splitting K: a split only evens out the last round, and pays for it
+        # with a slab of the whole gradient written, read back and added (the 5x5 gate weights: 210 MB per slab).  Measured
+        # (round 4, T = 5 steps of B = 16, g 512, launch + combine): 5x5 1.21 ms unsplit against 1.31 (x 2), 1.40 (x 3),
+        # 1.50 (x 4); 3x3 0.605 unsplit = 0.605 (x 2), 0.64 (x 3)
+        return 1
     best, best_eff = 1, 0.0
     for ns in range(1, min(groups, 64) + 1):
         rounds = tiles * ns / 512.0

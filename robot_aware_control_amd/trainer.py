@@ -327,8 +327,18 @@ class PredictionTrainer(object):
             x_pred_all = ops.Composite.apply(x4, x[:T].reshape((T * bs,) + tuple(x.shape[2:])).contiguous())
             x_preds = x_pred_all.view((T, bs) + tuple(x_pred_all.shape[1:])).unbind(0)
             batched = self.model.sequence_batched
-            for t in range(T):
-                add_losses(x_preds[t], t + 1, mus[t], logvars[t], mu_ps[t], logvar_ps[t], kl_here=batched is None)
+            if batched is not None and len(all_robots) == 1:
+                # sum_t recon_t = sum_t mean_b f(t, b) = T * mean over ALL T*B samples: one launch over the window (every
+                # loss kind normalises per sample, losses.py:11-50), seeded with T; the logged terms are scaled back
+                bw_all = None if batch_weight is None else batch_weight.repeat(T)
+                flatw = lambda t_: t_[1:T + 1].reshape((T * bs,) + tuple(t_.shape[2:])).contiguous()
+                rec = self._recon_loss(x_pred_all, flatw(x), flatw(mask), bw_all)
+                roots.append(rec)
+                seeds.append(self._seed(float(T), 3, first_only=True))
+                log.extend([("recon_loss", rec, 0, T), ("robot_loss", rec, 1, T), ("world_loss", rec, 2, T)])
+            else:
+                for t in range(T):
+                    add_losses(x_preds[t], t + 1, mus[t], logvars[t], mu_ps[t], logvar_ps[t], kl_here=batched is None)
             if batched is not None:
                 # sum_t KL_t: every term is a sum over its elements / bs (losses.py:97-106), so the window's KL is ONE
                 # launch over all T*B samples' elements (and one backward launch writing the batched gradients)
@@ -359,7 +369,7 @@ class PredictionTrainer(object):
         # backward pass or Adam (the reference likewise reads its losses before loss.backward(), trainer.py:433-458)
         self._mark("forward")
         with torch.no_grad():
-            vals_dev = torch.stack([t.detach()[k] for _, t, k in log])
+            vals_dev = torch.stack([e[1].detach()[e[2]] for e in log])
         if self._loss_host is None or self._loss_host.numel() < vals_dev.numel():
             self._loss_host = torch.empty(max(64, vals_dev.numel()), dtype=vals_dev.dtype).pin_memory()
         vals_host = self._loss_host[:vals_dev.numel()]
@@ -392,8 +402,8 @@ class PredictionTrainer(object):
         copied.synchronize()  # the one host wait of the step (normally already satisfied)
         vals = vals_host.tolist()
         losses = defaultdict(float)
-        for (name, _, _), v in zip(log, vals):
-            losses[name] += v
+        for e, v in zip(log, vals):
+            losses[e[0]] += v * (e[3] if len(e) > 3 else 1)
         for k in losses:
             losses[k] = losses[k] / cf.n_future
         return losses

@@ -44,7 +44,10 @@ def gpu_selections(model, trainer=None):
         orig_loss = trainer._recon_loss
 
         def recon(prediction, target, mask=None, batch_weight=None):
-            l1.append((target.detach() - prediction.detach() > 0).cpu())
+            sg = (target.detach() - prediction.detach() > 0).cpu()
+            bs = int(trainer._config.batch_size)
+            # (a teacher-forced window's reconstruction loss is ONE call over all T*B samples; the oracle calls once per step)
+            l1.extend(sg.split(bs) if sg.shape[0] > bs and sg.shape[0] % bs == 0 else [sg])
             return orig_loss(prediction, target, mask, batch_weight)
         trainer._recon_loss = recon
     M._VggLayer.forward = fwd
