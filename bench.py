@@ -185,7 +185,7 @@ def train_workload_name(args, cf):
 
 
 def build_train(args, dev):
-    cf = namespace(dev, lstm_group_norm=args.group_norm)
+    cf = namespace(dev, lstm_group_norm=args.group_norm, ddp_shard_optimizer=bool(getattr(args, "shard_optimizer", False)))
     if args.h48:  # the reference's default frame size (config/__init__.py:166-171): 48 x 64 -> 6 x 8 latent maps
         cf.image_height = 48
     if args.cfg5:  # BASELINE configs[4] per GPU: 128x128 frames, 8 samples, 10 predicted frames (16x16 latent maps)
@@ -504,6 +504,9 @@ def main():
                     help="train workload on 48x64 frames, the reference's default --image_height (not the headline)")
     ap.add_argument("--cfg5", action="store_true",
                     help="train workload at BASELINE configs[4] per-GPU size (128x128, bs 8, n_future 10); not the headline")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + Adam on 1/N slices + parameter all-gather (optim.ShardedAdam) instead of "
+                         "all-reduce + the fused Adam pass on every rank (not the default: unmeasured on multi-GPU hardware)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[4] per-GPU side line (`side.cfg5`)")
     ap.add_argument("--side-steps", type=int, default=5, help="timed steps of the configs[4] per-GPU side line")
     ap.add_argument("--group-norm", action="store_true",
@@ -570,7 +573,8 @@ def main():
         out.update(value=train["frames_per_s"], unit="frames/s", ms_per_step=train["ms_per_step"],
                    median_ms_per_step=train["median_ms_per_step"],
                    config={"workload": train["workload"],
-                           "global_batch": train["global_batch"], "parallelism": f"ddp{world}",
+                           "global_batch": train["global_batch"],
+                           "parallelism": f"ddp{world}" + ("-sharded-optimizer" if args.shard_optimizer and distributed else ""),
                            "algorithmic_tflop_per_step_per_gpu": train["step_tflop"]})
         k = train["kernel"]
         if k is None:  # no launch of the profiled shape (e.g. --group-norm: separate ih / hh gate convs)

@@ -851,6 +851,37 @@ def test_fused_adam_step_writes_the_next_parts(dev):
     assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
 
 
+def test_bound_scaled_weight_parts_cost_at_most_one_bit(dev):
+    """After a fused optimiser step the weight parts are scaled by the exponent of an UPPER BOUND of max |w| (old maximum
+    + the largest step Adam can take, ops.adam_step_bound), not of the exact maximum: when the bound crosses a power of two
+    that the maximum does not, the operands keep 21 of their 22 significant bits.  Pinned here on the realistic worst case
+    -- small weights (max |w| = 0.0156 = just under 2^-6, a gate conv with large fan-in) and lr 1e-3, whose margin 7.3e-3
+    lifts the bound over 2^-6: the conv with bound-scaled parts stays within 2e-6 of fp64 (the bar of every split kernel)
+    and within 2.5x the error of the exact-scaled parts; at most ONE exponent step separates the two scales."""
+    from robot_aware_control_amd import _lib, ops
+    co, ci, k = 128, 256, 3
+    w = (rnd(33, co, ci, k, k) * 0.004).clamp_(-0.0156, 0.0156)
+    w[3, 5, 1, 1] = 0.0156
+    w = cl_weight(w).to(dev)
+    assert w.stride() == (k * k * ci, 1, k * ci, ci)
+    x = to_map(rnd(34, 4, ci, 8, 8), dev)
+    refc = F.conv2d(from_map(x).double(), w.detach().cpu().double(), None, 1, 1)
+    exact_bits = w.abs().max().view(torch.int32).reshape(1).clone()
+    bound = (w.abs().max() + 1e-3 * ops.adam_step_bound(0.9, 0.999) * 1.01).reshape(1)
+    assert float(bound) > 2.0 ** -6 > float(w.abs().max())          # the bound crosses the power of two
+    errs = {}
+    for name, slot in (("exact", exact_bits), ("bound", bound.view(torch.int32).clone())):
+        parts = torch.empty((2, w.numel()), device=dev, dtype=torch.float16)
+        _lib.call("rac_weight_frag_split", w.data_ptr(), slot.data_ptr(), parts.data_ptr(), co, ci, k, 0, w.numel(),
+                  _lib.stream_ptr())
+        out = torch.empty((4, 8, 8, co), device=dev, dtype=torch.float32)
+        ops._split_launch(x, None, ops.amax_of(x), None, parts, slot, out, B=4, H=8, W=8, k=k, Cin=ci, Cout=co, C0=ci)
+        errs[name] = relerr(from_map(out), refc)
+    assert errs["bound"] < 2e-6 and errs["bound"] <= 2.5 * errs["exact"] + 1e-7, errs
+    import math
+    assert math.frexp(float(bound))[1] - math.frexp(float(w.abs().max()))[1] == 1
+
+
 @pytest.mark.parametrize("B,H,W,g,k", [(5, 8, 8, 64, 5), (3, 6, 8, 128, 3), (2, 8, 8, 512, 5)])
 def test_frozen_cell_in_the_gate_conv_epilogue(dev, B, H, W, g, k, monkeypatch):
     """rac_convlstm_cell_fwd_split (the frozen model's ConvLSTM cell in one launch, gate-interleaved weight rows) against

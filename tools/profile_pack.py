@@ -43,7 +43,7 @@ def counters(d):
 def main(src, tag):
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)
-    for wl, steps, title in (("train", 10, "cfg2 train step (3 priming + 2 warm-up + 5 timed steps profiled)"),
+    for wl, steps, title in (("train", 5, "cfg2 train step (the 5 timed steps of the run)"),
                              ("cem", None, "cfg3 CEM")):
         trace = os.path.join(src, f"stats_{wl}", "run_kernel_trace.csv")
         shapes = os.path.join(src, f"{wl}_shapes.json")
@@ -51,12 +51,12 @@ def main(src, tag):
         if os.path.exists(stats):
             shutil.copy(stats, os.path.join(prof, f"{tag}_{wl}_kernel_stats.csv"))
         if os.path.exists(trace) and os.path.exists(shapes):
-            if steps is None:  # CEM: model steps profiled (one cem_step_tail launch each) / 14 per iteration
-                n = sum(1 for r in csv.DictReader(open(trace)) if "cem_step_tail" in r["Kernel_Name"])
-                steps = n / 14
-                title += f" ({n} model steps profiled = {steps:.2f} iterations of 14; per-iteration numbers)"
+            window = "adam_frag_multi:5"
+            if steps is None:  # CEM: the timed iteration = the last 14 model steps (one cem_step_tail launch each)
+                steps, window = 1, "cem_step_tail:14"
+                title += " (the timed iteration: 14 model steps; per-iteration numbers)"
             md = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shape_profile.py"), trace, shapes,
-                                 str(steps), title], capture_output=True, text=True, check=True).stdout
+                                 str(steps), title, window], capture_output=True, text=True, check=True).stdout
             open(os.path.join(prof, f"{tag}_{wl}_shapes.md"), "w").write(md)
     # ---- fabric traffic
     res = {}

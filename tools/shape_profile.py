@@ -17,20 +17,35 @@ FAMILIES = [("conv16", re.compile(r"conv16_(tile|rows|rows_persist)_kernel")), (
             ("igemm", re.compile(r"igemm_\w*kernel"))]
 
 
-def main(trace, shapes, steps, title):
+def main(trace, shapes, steps, title, window=None):
+    """`window` = "<kernel substring>:<count>": only the launches after the (count + 1)-th last launch of that kernel up to
+    its last one are tabulated (train: "adam_frag_multi:5" = the five timed steps; planner: "cem_step_tail:14" = the timed
+    iteration) -- model construction, allocator priming and warm-up launches stay out of the per-step numbers."""
     log = defaultdict(list)
     for r in json.load(open(shapes)):
         log[r["family"]].append(r)
     rows = sorted(csv.DictReader(open(trace)), key=lambda r: int(r["Dispatch_Id"]))
+    lo, hi = 0, len(rows)
+    if window:
+        sub, cnt = window.rsplit(":", 1)
+        marks = [i for i, r in enumerate(rows) if sub in r["Kernel_Name"]]
+        lo, hi = marks[-1 - int(cnt)] + 1, marks[-1] + 1
     seen = defaultdict(int)
     agg = OrderedDict()
     other = defaultdict(lambda: [0, 0.0])
     total = 0.0
-    for r in rows:
+    n_rows = 0
+    for i, r in enumerate(rows):
         name = r["Kernel_Name"]
         dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3  # us
-        total += dur
         fam = next((f for f, rx in FAMILIES if rx.search(name)), None)
+        inside = lo <= i < hi
+        if not inside:  # (the launch log stays aligned: every conv launch of the run consumes its record)
+            if fam is not None and seen[fam] < len(log[fam]):
+                seen[fam] += 1
+            continue
+        total += dur
+        n_rows += 1
         if fam is None or seen[fam] >= len(log[fam]):
             short = re.sub(r"\(.*", "", name.replace("rac::", "").replace("void ", ""))[:60]
             other[short][0] += 1
@@ -66,8 +81,8 @@ def main(trace, shapes, steps, title):
     rest = sorted(other.items(), key=lambda kv: -kv[1][1])[25:]
     if rest:
         print(f"| ({len(rest)} more) | {sum(v[0] for _, v in rest) / steps:g} | {sum(v[1] for _, v in rest) / 1e3 / steps:.3f} |")
-    print(f"\nlaunches per step: {len(rows) / steps:.0f}")
+    print(f"\nlaunches per step: {n_rows / steps:.0f}")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4])
+    main(sys.argv[1], sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else None)
