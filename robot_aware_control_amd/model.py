@@ -272,6 +272,7 @@ class SVGConvModel(nn.Module):
         self._image_height = cf.image_height
         self.eps_source = None  # optional callable(shape_bzhw) -> N(0,1) tensor; tests inject the reference's draws
         self.sequence_batched = None  # forward_sequence_maps: (mu, logvar, mu_p, logvar_p) over all T*B samples, if batched
+        self.used_recurrent_core = False  # did the last forward_sequence_maps take ops.RecurrentCore?
         self._flat = self._flat_grad = None
         if cf.image_width not in (64, 128):  # dynamics.py:470-473
             raise ValueError
@@ -499,9 +500,11 @@ class SVGConvModel(nn.Module):
             x4 = self.decoder(h_pred_all, skips, T)
             # (the trainer's KL term takes the batched tensors: one launch, no per-step slices for autograd to stack)
             self.sequence_batched = (mu_all, lv_all, mu_p_all, logvar_p_all)
+            self.used_recurrent_core = True
             per_step = lambda t_: list(t_.view((T, B) + tuple(t_.shape[1:])).unbind(0))
             return x4, per_step(mu_all), per_step(lv_all), per_step(mu_p_all), per_step(logvar_p_all)
         self.sequence_batched = None
+        self.used_recurrent_core = False
         # (a step's slice inherits the whole tensor's maximum: a valid bound, and no reduction pass per step)
         steps_of = lambda t_: [ops.retag(s_, ops.amax_tag(t_)) for s_ in t_.view((T, B) + tuple(t_.shape[1:])).unbind(0)]
         prior_steps, post_steps = steps_of(prior_all), steps_of(post_all)

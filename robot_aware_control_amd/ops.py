@@ -1702,7 +1702,10 @@ class RecurrentCore(torch.autograd.Function):
             _, rec["fp1"] = run_cell("fp", 1, x, hp_s[t])
             rec.update(cat=cat, h_post=h_post, eps=eps)
             tape.append(rec)
-        ctx.plan, ctx.tape = plan, tape
+        # (the node keeps what backward reads, not the caller's closures: `eps_fn` is a bound method of the model, and a
+        # model -> output tensor -> grad_fn -> plan -> model cycle would keep a dropped model's 4 GB alive until a full GC)
+        ctx.plan = {k: plan[k] for k in ("g", "z", "nv", "cells", "head", "frame_conv")}
+        ctx.tape = tape
         ctx.lv_all = lv_all
         ctx.shape = (T, B, H, W)
         plan["final_state"] = state
@@ -1781,7 +1784,7 @@ class RecurrentCore(torch.autograd.Function):
             p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
             grad_sum([p0], d_prior_all[t], g, slot_prior)
             tape[t] = None  # (launches are stream ordered: what this step allocated may be reused by the next)
-        ctx.tape = None
+        ctx.tape = ctx.plan = None
         flat = lambda t_: t_.view((T * B, H, W, g))
         d_prior_all, d_post_all = tag_amax(flat(d_prior_all), slot_prior), tag_amax(flat(d_post_all), slot_post)
         return (None, flat(d_h_all), d_prior_all, d_post_all) + (None,) * (len(ctx.needs_input_grad) - 4)

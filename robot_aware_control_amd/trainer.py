@@ -398,6 +398,7 @@ class PredictionTrainer(object):
             self._mark("allreduce_exposed")
         self.optimizer.step()
         self._mark("adam")
+        self.model.sequence_batched = None  # (graph references of this step)
 
         copied.synchronize()  # the one host wait of the step (normally already satisfied)
         vals = vals_host.tolist()

@@ -233,7 +233,7 @@ def test_recurrent_core_matches_the_autograd_path(dev, tag, monkeypatch):
         tr.model.eps_source = lambda shape: queue.pop(0)
         tr.optimizer.step = lambda: None
         losses = tr._train_step(data)
-        assert (tr.model.sequence_batched is not None) == core
+        assert tr.model.used_recurrent_core == core and tr.model.sequence_batched is None
         out[core] = (losses, {k: p.grad.detach().double().cpu().clone() for k, p in tr.model.named_parameters()})
     for k, v in out[False][0].items():
         assert abs(out[True][0][k] - v) <= 1e-6 * abs(v) + 1e-9, k
