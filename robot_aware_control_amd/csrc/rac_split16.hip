@@ -315,6 +315,12 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_TILE_READ_ALL
 #define RAC_TILE_READ_ALL 0
 #endif
+#ifndef RAC_EXP_ROWS_NOZERO
+#define RAC_EXP_ROWS_NOZERO 0
+#endif
+#ifndef RAC_EXP_ROWS_NOSTORE
+#define RAC_EXP_ROWS_NOSTORE 0
+#endif
 template <int WM, bool FULL, bool YM = false>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;   // waves along the columns
@@ -894,7 +900,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;           // one buffer
   if constexpr (FAST) {
+#if !RAC_EXP_ROWS_NOZERO  // (timing / counter builds: which LDS stream of this kernel conflicts?  tools/build_variant.sh)
     for (int o = tid * 16; o < 2 * abuf; o += 4096) *reinterpret_cast<u32x4*>(lds_raw + o) = u32x4{0u, 0u, 0u, 0u};
+#endif
     __syncthreads();  // (the staging below writes some of the same rows from other threads)
   } else {  // zero rows of both buffers: 2 buffers x 2 parts x 4 groups x 16 rows = 256 vectors
     const int pl = tid >> 4, r = tid & 15;
@@ -978,9 +986,13 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       if (s_off[i] < 0) continue;
       u32x4 q[2];
       split8h(ra[2 * i], ra[2 * i + 1], sa, q);
+#if !RAC_EXP_ROWS_NOSTORE
 #pragma unroll
       for (int part = 0; part < 2; ++part)
         *reinterpret_cast<u32x4*>(lds_raw + buf * abuf + part * pplane + s_off[i]) = q[part];
+#else
+      if (q[0].x == 0x12345678u && q[1].y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(lds_raw) = q[0];
+#endif
     }
   };
 
