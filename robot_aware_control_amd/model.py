@@ -581,6 +581,14 @@ class SVGConvModel(nn.Module):
             scale, shift = first.folded()
             x1 = ops.first_layer_frozen(image, zm, mask_planes, first.main[0].weight, scale, shift)
             return self.encoder(x1, n_updates, groups, first_done=True)
+        if (self.training and torch.is_grad_enabled() and ops.first_layer_train_ok(image, mask_planes, first.main[0].weight)
+                and (image.shape[0] * image.shape[-2] * image.shape[-1]) % groups == 0):
+            # training, frames are data: the first layer reads the planes on the matrix pipe (ops.FirstVggLayer)
+            bn = first.main[1]
+            bn.pending_updates += n_updates * groups
+            x1 = ops.FirstVggLayer.apply(image, zm, mask_planes, first.main[0].weight, bn.weight, bn.bias, bn.running_mean,
+                                         bn.running_var, n_updates, groups)
+            return self.encoder(x1, n_updates, groups, first_done=True)
         # one whole 32-channel chunk (zero padded) where the first layer can take the split-precision kernels
         H, W = image.shape[-2], image.shape[-1]
         pad_to = 32 if (ops.SPLIT_GEMM and ops.split_supported(H, W, 3, 32, 64)) else 0

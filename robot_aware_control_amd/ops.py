@@ -1377,6 +1377,71 @@ class VggLayer(torch.autograd.Function):
         return dx0, dx1, None, None, None, None, None, None, None, None, None
 
 
+# the TRAINING path's first encoder layer straight from the frame / mask planes on the matrix pipe (rac_first_layer_fwd_split
+# without a folded BatchNorm: raw conv output), instead of packing a 32-channel-padded NHWC tensor and running the
+# exact-fp32 implicit GEMM over it (round 3: rac_pack_input 0.063 ms + igemm_fast_kernel 0.146 ms per step at ~0.6 TB/s)
+FIRST_TRAIN_MFMA = os.environ.get("RAC_FIRST_TRAIN_MFMA", "1") == "1"
+
+
+class FirstVggLayer(torch.autograd.Function):
+    """c1[0] in training mode: Conv3x3(no bias) over [img * (1 - zero_mask) | mask] -> BatchNorm2d (batch statistics, one set
+    per time step group) -> LeakyReLU(0.2)  (dynamics.py:578-582 + vgg_64.py:8-18), from the NCHW planes.  The frames are
+    data here (no gradient flows into them: teacher-forced windows); the weight gradient reads a small packed copy of the
+    input (3 + Cm channels padded to a multiple of 4), built in backward."""
+
+    @staticmethod
+    def forward(ctx, img, zero_mask, mask, weight, gamma, beta, rmean, rvar, n_updates, groups):
+        B, _, H, W = img.shape
+        Cm = mask.shape[1] if mask is not None else 0
+        dev = img.device
+        raw = torch.empty((B, H, W, 64), device=dev, dtype=torch.float32)
+        sp = stream_ptr()
+        call("rac_first_layer_fwd_split", ptr(img), ptr(zero_mask), ptr(mask), Cm, ptr(weight_mem(weight.detach())), None,
+             None, ACT_NONE, ptr(raw), None, 0, B, H, W, 64, sp)
+        G = int(groups)
+        M = B * H * W
+        stats = zeros64((G, 2, 64), dev)
+        call("rac_col_stats", ptr(raw), ptr(stats), M, 64, G, sp)
+        aff = torch.empty((4, G, 64), device=dev, dtype=torch.float32)
+        call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
+             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), 64, G, sp)
+        y = torch.empty_like(raw)
+        slot = amax_slot(dev)
+        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, 64, G, ptr(slot), sp)
+        tag_amax(y, slot)
+        ctx.save_for_backward(img, zero_mask, mask, weight, gamma, beta, raw, aff)
+        ctx.groups = G
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        img, zero_mask, mask, weight, gamma, beta, raw, aff = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, _ = raw.shape
+        M, G = B * H * W, ctx.groups
+        sp = stream_ptr()
+        sums = zeros64((G, 2, 64), dy.device)
+        call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M, 64, G,
+             sp)
+        draw = torch.empty_like(raw)
+        want_affine = gamma.requires_grad
+        call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), ptr(draw),
+             ptr(grad_buffer(gamma)) if want_affine else None, ptr(grad_buffer(beta)) if want_affine else None, M, 64, G,
+             None, sp)
+        if weight.requires_grad:
+            Cm = mask.shape[1] if mask is not None else 0
+            pad = pad4(3 + Cm)
+            x0 = torch.empty((B, H, W, 3 + Cm + pad), device=dy.device, dtype=torch.float32)
+            call("rac_pack_input", ptr(img), ptr(zero_mask), ptr(mask), Cm, pad, ptr(x0), B, H * W, sp)
+            thin_wgrad_acc(draw, x0, 3 + Cm, weight)
+        return (None,) * 10
+
+
+def first_layer_train_ok(img, mask, weight) -> bool:
+    return (FIRST_TRAIN_MFMA and FIRST_MFMA and SPLIT_GEMM and not img.requires_grad and first_layer_ok(img, mask, weight)
+            and img.shape[0] * (img.shape[-2] // 16) * (img.shape[-1] // 16) > 0)
+
+
 class MaxPool2(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

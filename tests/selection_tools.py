@@ -12,6 +12,19 @@ import torch
 import torch.nn.functional as F
 
 
+class _FirstLayerShim:
+    """ops.FirstVggLayer (the training path's first encoder layer from the planes): records the same slope pattern the
+    _VggLayer.forward hook records for the other layers, under the layer's module name."""
+
+    def __init__(self, orig, signs, name):
+        self.orig, self.signs, self.name = orig, signs, name
+
+    def apply(self, *a):
+        y = self.orig.apply(*a)
+        self.signs.setdefault(self.name, []).append((y.detach() > 0).permute(0, 3, 1, 2).cpu())
+        return y
+
+
 class _PoolShim:
     def __init__(self, orig, rec):
         self.orig, self.rec = orig, rec
@@ -52,11 +65,14 @@ def gpu_selections(model, trainer=None):
         trainer._recon_loss = recon
     M._VggLayer.forward = fwd
     ops.MaxPool2 = _PoolShim(orig_pool, pools)
+    orig_first = ops.FirstVggLayer
+    ops.FirstVggLayer = _FirstLayerShim(orig_first, signs, names[id(model.encoder.c1[0])])
     try:
         yield out
     finally:
         M._VggLayer.forward = orig_fwd
         ops.MaxPool2 = orig_pool
+        ops.FirstVggLayer = orig_first
         if trainer is not None:
             del trainer._recon_loss
     out["l1_signs"] = l1 or None
