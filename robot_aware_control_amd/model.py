@@ -563,7 +563,20 @@ class SVGConvModel(nn.Module):
         """`forward_sequence_maps` needs per-step row ranges that are whole 128-row tiles at every resolution."""
         return self.training and bool(self._config.last_frame_skip) and (batch * (height // 8) * (width // 8)) % 128 == 0
 
+    def _encoder_extent(self) -> int:
+        """Flat-buffer element index behind the encoder's last parameter (the encoder is registered first)."""
+        return max(p._rac_off + p.numel() for p in self.encoder.parameters())
+
     def _encode(self, image, mask, heatmap, zero_mask, n_updates, groups):
+        gate = ops.PARAM_GATE  # a sharded optimiser's parameter all-gather still in flight (optim.ShardedAdam)
+        if gate is not None:
+            gate.wait_params(upto=self._encoder_extent())
+        out = self._encode_now(image, mask, heatmap, zero_mask, n_updates, groups)
+        if gate is not None:
+            gate.wait_params()  # everything behind the encoder's parameters: waited for under the encoder's kernels
+        return out
+
+    def _encode_now(self, image, mask, heatmap, zero_mask, n_updates, groups):
         cf = self._config
         image = image.contiguous()
         mask_planes = None

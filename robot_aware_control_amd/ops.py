@@ -506,10 +506,16 @@ def _wp_upload(jobs, device):
     return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
 
 
+# optim.ShardedAdam while the all-gather of the updated parameters is in flight: `ready(param)` says whether a parameter's
+# buckets have been waited for (its new values may be read by kernels enqueued now).  _wp_refresh leaves the others stale.
+PARAM_GATE = None
+
+
 def _wp_refresh(device):
     """Bring every registered weight of `device` whose parameter changed up to date."""
     st = _wp_state(device)
     stale, n_live = [], 0
+    gate = PARAM_GATE
     for ent in list(_WP_ENTRIES.values()):
         if ent.device != device:
             continue
@@ -517,6 +523,10 @@ def _wp_refresh(device):
         if w is None:
             continue
         src = getattr(w, "_rac_pad_source", None)
+        if gate is not None:  # (a padded copy, a merged head view: judged by the parameter memory they alias)
+            base = src[0]() if src is not None else w
+            if base is not None and not gate.ready(base):
+                continue
         if src is not None:  # a zero-padded copy of a parameter: rebuild the copy first
             param = src[0]()
             if param is None:
@@ -710,6 +720,12 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
         ent.parts[transposed] = parts
         ent.tag = None
     if ent.tag != _wp_tag(weight):
+        gate = PARAM_GATE
+        if gate is not None:  # this weight's new values may still be travelling (a sharded optimiser's all-gather)
+            src = getattr(weight, "_rac_pad_source", None)
+            base = src[0]() if src is not None else weight
+            if base is not None and not gate.ready(base):
+                gate.wait_params()
         _wp_refresh(weight.device)
     return ent.parts[transposed], ent.slot
 

@@ -88,8 +88,9 @@ class ShardedAdam(FusedAdam):
       step       1 / world scale and Adam on the owned slices only: 1 / world of the 6.7 GB Adam traffic, exp_avg /
                  exp_avg_sq exist only for the owned 1 / world of the parameters;
       next step  all-gather of the updated parameter buckets, asynchronous and in the order the forward pass needs the
-                 weights; `wait_params()` is called before the first kernel that reads a parameter (today: the start of
-                 the next train step, and any state_dict / evaluation in between).
+                 weights; the model waits for the encoder's buckets before its first kernel and for the rest behind the
+                 encoder's forward pass (`SVGConvModel._encode`: `wait_params(upto=...)`, then `wait_params()`), so the
+                 ConvLSTM weights' 90 % of the bytes travel under the encoder; state_dict waits for everything.
 
     The conv weights' split-precision operand parts are refreshed lazily after the all-gather (ops._wp_refresh: one
     absmax + one fragment-split launch over all weights) -- the fused Adam + parts pass needs the whole updated weight.
@@ -113,10 +114,30 @@ class ShardedAdam(FusedAdam):
             self._vs = torch.zeros(n_own, device=device, dtype=torch.float32)
         return self._ms, self._vs
 
-    def wait_params(self):
-        for w in self._pending:
-            w.wait()
-        self._pending = []
+    def wait_params(self, upto: int = None):
+        """Make the current stream (gloo: the host) wait for the parameter all-gather: every bucket, or the buckets that
+        hold flat elements [0, upto) -- the collectives complete in issue order, so the rest stays in flight behind the
+        kernels enqueued next (the encoder's forward pass runs under the ConvLSTM weights' all-gather)."""
+        keep = []
+        for start, size, work in self._pending:
+            if upto is None or start < upto:
+                work.wait()
+            else:
+                keep.append((start, size, work))
+        self._pending = keep
+        if not keep and ops.PARAM_GATE is self:
+            ops.PARAM_GATE = None
+
+    def ready(self, t: torch.Tensor) -> bool:
+        """Have the buckets overlapping the parameter memory `t` been waited for?"""
+        if not self._pending:
+            return True
+        flat, _ = self._model.flat_parameters()
+        lo = (t.data_ptr() - flat.data_ptr()) // 4
+        if lo < 0 or lo >= flat.numel():
+            return True  # not a view of the flat parameter buffer
+        hi = lo + t.numel()
+        return all(not (start < hi and lo < start + size) for start, size, _ in self._pending)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -126,6 +147,7 @@ class ShardedAdam(FusedAdam):
         buckets, world, rank = self.plan()
         g = self.param_groups[0]
         self._steps += 1
+        self.wait_params()  # (normally long done: the model waited before it read the parameters)
         if ops._STALE:
             ops.finish_grads()
         n_own = sum(size // world for _, size in buckets)
@@ -151,9 +173,11 @@ class ShardedAdam(FusedAdam):
         # the updated slices travel to every rank, bucket by bucket in forward order, while the host moves on
         for start, size in buckets:
             n = size // world
-            self._pending.append(dist.all_gather_into_tensor(flat[start:start + size], flat[start + rank * n:start + (rank + 1) * n],
-                                                             async_op=True))
+            work = dist.all_gather_into_tensor(flat[start:start + size], flat[start + rank * n:start + (rank + 1) * n],
+                                               async_op=True)
+            self._pending.append((start, size, work))
         ops.PARAM_EPOCH += 1  # caches derived from the parameters (padded copies, operand parts) are stale
+        ops.PARAM_GATE = self  # ... and are refreshed bucket by bucket as the all-gather is waited for (ops._wp_refresh)
 
     # torch.optim.Adam-compatible state: the full moments are assembled from all ranks' slices
     def _moments(self):

@@ -275,8 +275,8 @@ class PredictionTrainer(object):
             batch_weight = (cf.movement_weight * mv).to(f32)
             batch_weight[~mv.bool()] = 1.0
 
-        if isinstance(self.optimizer, ShardedAdam):
-            self.optimizer.wait_params()  # the previous step's parameter all-gather (host-side: nothing is enqueued yet)
+        # (a sharded optimiser's parameter all-gather of the previous step is waited for inside the model: the encoder's
+        # buckets before its first kernel, the rest behind the encoder's forward pass -- SVGConvModel._encode)
         ops.begin_step(x.device)
         self._mark("start")
         # (lazy: the large conv weights' gradients are written, not added to zeros, by their one launch per step)

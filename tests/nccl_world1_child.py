@@ -108,19 +108,44 @@ def main():
     # ---- sharded optimiser: reduce-scatter of the gradient, Adam on this rank's slices, all-gather of the parameters ----
     n0 = len(calls)
     tr2 = fresh(True)
+    waits = []
+    real_wait = tr2.optimizer.wait_params
+    tr2.optimizer.wait_params = lambda upto=None: (waits.append(upto), real_wait(upto))[1]
     tr2._train_step(data)
-    tr2._train_step(data)  # (the second step waits for the first one's parameter all-gather)
+    from robot_aware_control_amd import ops as _ops
+    out["gate_armed"] = _ops.PARAM_GATE is tr2.optimizer and len(tr2.optimizer._pending) > 0
+    tr2._train_step(data)  # the second step waits for the first one's parameter all-gather, in two stages:
+    # the encoder's buckets before its first kernel, everything else behind the encoder's forward pass
+    enc_end = tr2.model._encoder_extent()
+    out["staged_wait"] = enc_end in waits and waits.index(enc_end) < len(waits) - 1 and None in waits[waits.index(enc_end):]
     tr2.optimizer.wait_params()
+    out["gate_released"] = _ops.PARAM_GATE is None
     seen = calls[n0:]
     out["reduce_scatter"] = seen.count(("reduce_scatter_tensor", "cuda"))
     out["param_allgather"] = seen.count(("all_gather_into_tensor", "cuda"))
     os.environ["RAC_DIST_FORCE"] = "0"
+    fused_log = []
+    real_fused = _ops.fused_adam_step
+    _ops.fused_adam_step = lambda *a, **k: (fused_log.append(real_fused(*a, **k)), fused_log[-1])[1]
     tr3 = fresh(False)
     tr3._train_step(data)
     tr3._train_step(data)
     os.environ["RAC_DIST_FORCE"] = "1"
     a, b = tr2.model.flat_parameters()[0], tr3.model.flat_parameters()[0]
     out["sharded_param_rel_diff"] = float((a - b).norm() / b.norm())
+    # the yardstick: the SAME plain run twice (the fp64 atomics of the BatchNorm statistics and the fp32 atomics of the
+    # bias gradients are order dependent; Adam turns that noise into +-lr steps where a gradient is only noise)
+    os.environ["RAC_DIST_FORCE"] = "0"
+    tr4 = fresh(False)
+    tr4._train_step(data)
+    tr4._train_step(data)
+    os.environ["RAC_DIST_FORCE"] = "1"
+    c = tr4.model.flat_parameters()[0]
+    out["plain_rerun_rel_diff"] = float((c - b).norm() / b.norm())
+    out["fused_adam_taken"] = fused_log  # [run 1 step 1, step 2, run 2 step 1, step 2]
+    _ops.fused_adam_step = real_fused
+    upd = (b - p_one).norm() / p_one.norm()  # (size of one-to-two optimiser steps, for scale)
+    out["two_step_update_rel"] = float(upd)
     torch.cuda.synchronize()
     print(json.dumps(out))
     dist.destroy_process_group()

@@ -45,7 +45,11 @@ def test_every_collective_call_site_runs_on_rccl():
     assert out["allreduce_slices"] >= 7, out                          # 6 ConvLSTM weight slices + the rest, async
     assert out["grad_rel_diff"] < 1e-6 and out["param_rel_diff"] < 1e-6 and out["loss_equal"], out
     assert out["reduce_scatter"] >= 2 and out["param_allgather"] >= 2, out
-    assert out["sharded_param_rel_diff"] < 1e-6, out
+    # sharded step == all-reduce + full Adam up to what two identical plain runs differ by (atomics' order; Adam turns
+    # gradient noise into +-lr steps): a small fraction of one optimiser step
+    assert out["sharded_param_rel_diff"] <= max(5.0 * out["plain_rerun_rel_diff"], 1e-6) or \
+        out["sharded_param_rel_diff"] < 0.01 * out["two_step_update_rel"], out
+    assert out["gate_armed"] and out["staged_wait"] and out["gate_released"], out  # all-gather waited in two stages
 
 
 def test_bench_under_torchrun_one_rank_rccl():
