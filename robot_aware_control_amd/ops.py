@@ -1506,10 +1506,11 @@ class TileCat(torch.autograd.Function):
         c1 = m1.shape[3] if m1 is not None else 0
         ct = sum(ns) + c0 + c1
         pad = pad4(ct)
-        hw = H * W
-        whole = hw <= 128 and ((128 // hw) * hw) % 16 == 0  # whole-image tiles exist
-        if SPLIT_GEMM and ct >= 128 and whole and c0 % 32 == 0:
-            pad = (-ct) % 32  # whole 32-channel chunks: the consumer conv runs split-precision
+        # whole 32-channel chunks where the consumer conv can then run split-precision: maps that fit a tile, and (round 4)
+        # the larger maps of the rows kernels too -- the 16x16 latents of a 128x128 model ran their three input convs on
+        # the exact-fp32 pipe (21 ms of a 106 ms cfg5 step: rac_conv2d fwd / dgrad / wgrad at 157 TFLOP/s peak)
+        if SPLIT_GEMM and ct >= 128 and c0 % 32 == 0 and split_supported(H, W, 3, ct + (-ct) % 32, 128, 0):
+            pad = (-ct) % 32
         out = torch.empty((B, H, W, ct + pad), device=m0.device, dtype=torch.float32)
         slot = amax_slot(m0.device, B if frozen else 1)
         call("rac_tilecat_fwd", ptr(vs[0]), ns[0], ptr(vs[1]), ns[1], ptr(vs[2]), ns[2], ptr(m0), c0, ptr(m1), c1, pad,
@@ -1694,10 +1695,9 @@ def recurrent_core_ok(h_all, g: int, z: int, nv: int, cells, head, frame_conv) -
     _, H, W, gg = h_all.shape
     if gg != g or g % 32 or z % 4 or head is None or not gauss_head_ok((1, H, W, g), head[0]):
         return False
-    hw = H * W
     ct = nv + g + z
     cpad = ct + (-ct) % 32
-    if not (ct >= 128 and hw <= 128 and ((128 // hw) * hw) % 16 == 0):  # TileCat's whole-chunk padding rule
+    if not (ct >= 128 and split_supported(H, W, 3, cpad, 128, 0)):  # TileCat's whole-chunk padding rule
         return False
     if not split_supported(H, W, frame_conv.weight.shape[2], cpad, frame_conv.weight.shape[0], 0):
         return False
