@@ -111,7 +111,31 @@ struct Conv16P {
   int lstm_g;
   int per_image;  // a_amax0 / a_amax1 / out_amax are arrays of B slots, one per image: every image is scaled by its OWN
                   // maximum, so its result cannot depend on what else is in the batch (the frozen model's rollouts)
+  // 2-D tiles of the unrolled 3x3 rows kernels (0: tiles of whole image rows): a tile is seg_h image rows x seg_w pixels
+  // (= 128 pixels; seg_w a multiple of 16, so a 16-row block lies inside one tile row) with a one-pixel halo all round:
+  // (seg_h + 2)(seg_w + 2) staged pixels instead of (rows + 2) W -- 180 instead of 264 on a 64-wide map -- and maps wider
+  // than a whole-row tile's halo allows (128x128) get a tile at all.  seg_tx tiles per image row, seg_tpi per image.
+  int seg_w, seg_h, seg_tx, seg_tpi;
 };
+
+// origin of 2-D tile `bx`: image, first row, first column, and the pixel index of (y0, x0)
+struct SegOrigin {
+  int img, y0, x0, m0;
+};
+__device__ __forceinline__ SegOrigin seg_origin(const Conv16P& p, int bx) {
+  SegOrigin o;
+  o.img = bx / p.seg_tpi;
+  const int r = bx - o.img * p.seg_tpi;
+  const int ty = r / p.seg_tx;
+  o.y0 = ty * p.seg_h;
+  o.x0 = (r - ty * p.seg_tx) * p.seg_w;
+  o.m0 = (o.img * p.H + o.y0) * p.W + o.x0;
+  return o;
+}
+// pixel index of tile row `r16` (a multiple of 16) of the tile at m0: consecutive pixels from there up to the block's end
+__device__ __forceinline__ int seg_row_pixel(const Conv16P& p, int m0, int r16) {
+  return p.seg_w ? m0 + (r16 / p.seg_w) * p.W + r16 % p.seg_w : m0 + r16;
+}
 
 // LDS image of the tile kernel: CHUNK-major [part 2][8-channel group 4][row 144][16 B]; rows 128..143 are zeros.
 // The 16 lanes of a ds_read_b128 group touch 16 distinct rows mod 16 = 16 distinct bank slots; a tap shift is one
@@ -166,7 +190,7 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int rl = 4 * lq + r;
-        const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : m0 + (mb0 + mb) * 16 + rl;
+        const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : seg_row_pixel(p, m0, (mb0 + mb) * 16) + rl;
         const bool ok = nok & (m < p.M);
         float v = acc[mb][nb][r] * iav[mb][r] * iw + bias;  // two exact steps: ia * iw alone may underflow
         const float vs = ok ? v : 0.f;
@@ -216,7 +240,7 @@ __device__ __forceinline__ void conv16_epilogue(const Conv16P& p, const f32x4 (&
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = 4 * lq + r;
-          const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : m0 + (mb0 + mb) * 16 + rl;
+          const int m = ym_hw ? m0 + (rl >> 3) * ym_hw + (mb0 + mb) * 8 + (rl & 7) : seg_row_pixel(p, m0, (mb0 + mb) * 16) + rl;
           if ((n < NS) & (m < p.M)) dst[(long)m * NS + n] = acc[mb][nb][r] * ia * iw;
         }
       }
@@ -881,7 +905,10 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int wn = wid % WN, wm = wid / WN;
   const int TM = p.tile_m;
   const int nmb = TM >> 4;
-  const int m0 = bx * TM, n0 = by * BNW;
+  const bool seg = FAST && p.seg_w;  // 2-D tile (unrolled 3x3 form only)
+  SegOrigin so{};
+  if (seg) so = seg_origin(p, bx);
+  const int m0 = seg ? so.m0 : bx * TM, n0 = by * BNW;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   const int img = p.per_image ? m0 / p.HW : 0;  // a tile is R rows of ONE image: one scale, one output slot
@@ -890,13 +917,16 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
   const float sa = pow2f(ka);
   const int halo = p.pad * p.W;
-  const int nrows = TM + 2 * halo;       // staged pixel rows (a multiple of 16)
+  // staged pixel rows: the tile's image rows + the halo rows (a multiple of 16); 2-D tile: the (seg_h + 2) x (seg_w + 2) halo tile
+  const int nrows = seg ? (p.seg_h + 2) * (p.seg_w + 2) : TM + 2 * halo;
   // FAST (3 x 3): every staged image row sits in W + 2 LDS rows, a zero row either side, so a horizontal tap that leaves
   // the image reads zeros by address: no per-lane validity mask / compare / select per (tap, block) -- as the tile
-  // kernel's padded segments.  Otherwise: the staged rows + 16 zero rows that the select points at.
-  const int WP = p.W + 2;
+  // kernel's padded segments.  (2-D tile: the halo columns are staged like any other pixel, zeros outside the image.)
+  // Otherwise: the staged rows + 16 zero rows that the select points at.
+  const int WD = seg ? p.seg_w : p.W;  // pixels of a tile row
+  const int WP = WD + 2;
   // one 8-channel group; (FAST) rounded to 256 B: the four k-groups of a read must start on the same 16-byte slot
-  const int cplane = FAST ? (((nrows / p.W) * WP + 15) & ~15) * 16 : (nrows + 16) * 16;
+  const int cplane = FAST ? (((seg ? nrows : (nrows / p.W) * WP) + 15) & ~15) * 16 : (nrows + 16) * 16;
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;           // one buffer
   if constexpr (FAST) {
@@ -919,6 +949,14 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     const int g = v / nrows, row = v - g * nrows;
     s_grp[i] = g;
     s_row[i] = row;
+    if (seg) {  // staged slot `row` = halo-tile position (row / WP, row % WP) = image pixel (y0 - 1 + .., x0 - 1 + ..)
+      s_off[i] = g < 4 ? g * cplane + row * 16 : -1;
+      const int y = so.y0 - 1 + row / WP, x = so.x0 - 1 + row % WP;
+      s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+      s_row[i] = (so.img * p.H + y) * p.W + x;  // (2-D tile: s_row holds the source PIXEL; s_pix its half-resolution twin)
+      s_pix[i] = (so.img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
+      continue;
+    }
     s_off[i] = g < 4 ? g * cplane + (FAST ? (row / p.W) * WP + 1 + row % p.W : row) * 16 : -1;
     const int y = y_tile - p.pad + row / p.W;
     s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
@@ -943,7 +981,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
   for (int t = 0; t < MB; ++t) {
     const int r0 = (wm * MB + t) * 16;
-    ablk[t] = lq * cplane + ((1 + r0 / p.W) * WP + 1 + r0 % p.W + lr) * 16;
+    ablk[t] = lq * cplane + ((1 + r0 / WD) * WP + 1 + r0 % WD + lr) * 16;
   }
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
@@ -954,7 +992,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.w_nchunks * 2048u : 0u) + (unsigned)lane * 16u;
   }
   auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
-    const int so = kc * 2048;
+    const int wo = kc * 2048;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -962,7 +1000,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
           rb[(j * 2 + part) * 2 + nb] = __builtin_bit_cast(
-              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), so, 0));
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), wo, 0));
   };
   u32x4 ra[2 * NV];
   auto issue_a = [&](int cc) {
@@ -975,7 +1013,8 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
                                     (unsigned)((long)(up ? p.P >> 2 : p.P) * Cs * 4));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const unsigned oa = (unsigned)((up ? s_pix[i] : m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      const int px = up ? s_pix[i] : (seg ? s_row[i] : m0 - halo + s_row[i]);
+      const unsigned oa = (unsigned)(px * Cs + cl + s_grp[i] * 8) * 4u;
       ra[2 * i] = load16(a_rsrc, s_ok[i] ? oa : OOB);
       ra[2 * i + 1] = load16(a_rsrc, s_ok[i] ? oa + 16u : OOB);
     }
@@ -1186,9 +1225,11 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   const int kc_begin = 0, kc_end = p.nchunks;  // (never K-split: the short-K layers)
   const int kw = scale_exp(*p.w_amax);
   const int halo = p.W;
-  const int nrows = TM + 2 * halo;
-  const int WP = p.W + 2;  // padded rows, as conv16_rows_kernel's unrolled form: a zero LDS row either side of an image row
-  const int cplane = (((nrows / p.W) * WP + 15) & ~15) * 16;  // (a multiple of 256 B, as there)
+  const bool seg = p.seg_w != 0;  // 2-D tiles (see Conv16P): seg_h rows x seg_w pixels + a one-pixel halo all round
+  const int nrows = seg ? (p.seg_h + 2) * (p.seg_w + 2) : TM + 2 * halo;
+  const int WD = seg ? p.seg_w : p.W;
+  const int WP = WD + 2;  // padded rows, as conv16_rows_kernel's unrolled form: a zero LDS row either side of an image row
+  const int cplane = (((seg ? nrows : (nrows / p.W) * WP) + 15) & ~15) * 16;  // (a multiple of 256 B, as there)
   const int pplane = 4 * cplane;
   const int abuf = 2 * pplane;
   for (int o = tid * 16; o < 2 * abuf; o += 4096) *reinterpret_cast<u32x4*>(lds_raw + o) = u32x4{0u, 0u, 0u, 0u};
@@ -1201,14 +1242,14 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
     const int g = v / nrows, row = v - g * nrows;
     s_grp[i] = g;
     s_row[i] = row;
-    s_off[i] = g < 4 ? g * cplane + ((row / p.W) * WP + 1 + row % p.W) * 16 : -1;
+    s_off[i] = g < 4 ? g * cplane + (seg ? row : (row / p.W) * WP + 1 + row % p.W) * 16 : -1;
   }
   const int lq = lane >> 4;
   int ablk[MB];
 #pragma unroll
   for (int t = 0; t < MB; ++t) {
     const int r0 = (wm * MB + t) * 16;
-    ablk[t] = lq * cplane + ((1 + r0 / p.W) * WP + 1 + r0 % p.W + lr) * 16;
+    ablk[t] = lq * cplane + ((1 + r0 / WD) * WP + 1 + r0 % WD + lr) * 16;
   }
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
@@ -1219,7 +1260,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
     b_off[j] = (ntile * 32 < p.N ? (unsigned)ntile * (unsigned)p.w_nchunks * 2048u : 0u) + (unsigned)lane * 16u;
   }
   auto load_b = [&](u32x4(&rb)[4 * NT], int kc) {
-    const int so = kc * 2048;
+    const int wo = kc * 2048;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -1227,16 +1268,19 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
           rb[(j * 2 + part) * 2 + nb] = __builtin_bit_cast(
-              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), so, 0));
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + nb * 1024u), wo, 0));
   };
   // per-tile state: the tile being multiplied (cur) and the one whose first chunk is in flight (nxt)
   struct TileState {
     int m0, ka;
     bool ok[NV];
-    int pix[NV];
+    int pix[NV];   // source pixel of the first source (half resolution under a0_up)
+    int pix1[NV];  // 2-D tiles: the full-resolution pixel (the second source's, and the first's without a0_up)
   };
   auto setup = [&](int bx, TileState& t) {
-    t.m0 = bx * TM;
+    SegOrigin so{};
+    if (seg) so = seg_origin(p, bx);
+    t.m0 = seg ? so.m0 : bx * TM;
     const int img = p.per_image ? t.m0 / p.HW : 0;
     unsigned am = p.a_amax0[img];
     if (p.a_amax1) am = max(am, p.a_amax1[img]);
@@ -1245,9 +1289,17 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int row = s_row[i];
+      if (seg) {
+        const int y = so.y0 - 1 + row / WP, x = so.x0 - 1 + row % WP;
+        t.ok[i] = (s_grp[i] < 4) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+        t.pix1[i] = (so.img * p.H + y) * p.W + x;
+        t.pix[i] = p.a0_up ? (so.img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1) : t.pix1[i];
+        continue;
+      }
       const int y = y_tile - 1 + row / p.W;
       t.ok[i] = (s_grp[i] < 4) & ((unsigned)y < (unsigned)p.H) & (t.m0 - halo + row < p.M);
       t.pix[i] = t.m0 - halo + row;
+      t.pix1[i] = t.pix[i];
       if (p.a0_up && t.ok[i]) {
         const int im = t.pix[i] / p.HW, x = row % p.W;
         t.pix[i] = (im * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
@@ -1265,7 +1317,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
                                     (unsigned)((long)(up ? p.P >> 2 : p.P) * Cs * 4));
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const unsigned oa = (unsigned)((up ? t.pix[i] : t.m0 - halo + s_row[i]) * Cs + cl + s_grp[i] * 8) * 4u;
+      const unsigned oa = (unsigned)((up ? t.pix[i] : t.pix1[i]) * Cs + cl + s_grp[i] * 8) * 4u;
       ra[2 * i] = load16(a_rsrc, t.ok[i] ? oa : OOB);
       ra[2 * i + 1] = load16(a_rsrc, t.ok[i] ? oa + 16u : OOB);
     }
@@ -2239,7 +2291,8 @@ extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, i
   const int HW = H * W;
   if (HW <= 128) return ((128 / HW) * HW) % 16 == 0;
   const int tm = W <= 128 ? rows_tile_m(H, W) : 0;
-  return tm && (tm + 2 * (ksize / 2) * W) * 4 <= 1024;
+  if (tm && (tm + 2 * (ksize / 2) * W) * 4 <= 1024) return 1;
+  return ksize == 3 && W >= 64 && W % 16 == 0 && H % 8 == 0;  // 2-D tiles of the unrolled 3x3 form
 }
 
 static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1, int64_t w_part_stride,
@@ -2298,9 +2351,26 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   static const char* xg = getenv("RAC_XCD_GROUP");
   const bool want_xcd = xg ? atoi(xg) != 0 : true;
   if (p.HW > 128) {
-    p.tile_m = rows_tile_m(a->H, a->W);
+    // 2-D tiles (8 image rows x 16 pixels + a one-pixel halo: 180 staged pixels per 128) for the unrolled 3x3 form on
+    // maps 64 or more pixels wide: a whole-row tile stages (rows + 2) W pixels -- 264 per 128 on a 64-wide map -- and has
+    // no room at all for a 128-wide one (its halo alone is 256 pixels).  RAC_ROWS_TILE2D=0: whole-row tiles only.
+    const char* no2d = getenv("RAC_ROWS_TILE2D");
+    const bool rows_fit = a->W <= 128 && rows_tile_m(a->H, a->W) && (rows_tile_m(a->H, a->W) + 2 * p.pad * a->W) * 4 <= 1024;
+    bool tile2d = a->ksize == 3 && a->W >= 64 && a->W % 16 == 0 && a->H % 8 == 0 && !(no2d && atoi(no2d) == 0 && rows_fit);
+    if (tile2d && p.cps % 9 != 0) {
+      if (rows_fit)
+        tile2d = false;  // a K split that cuts a channel chunk: the generic loop on whole-row tiles
+      else
+        p.cps = cdiv(p.cps, 9) * 9;  // (only whole chunks per split; the last splits may be short or empty)
+    }
+    RAC_REQUIRE(tile2d || rows_fit, "rac_conv2d_fwd_split: this map needs 2-D tiles (3x3, W %% 16 == 0, H %% 8 == 0)");
+    if (tile2d) {
+      p.seg_w = 16, p.seg_h = 8;
+      p.seg_tx = a->W / 16, p.seg_tpi = (a->H / 8) * p.seg_tx;
+    }
+    p.tile_m = tile2d ? 128 : rows_tile_m(a->H, a->W);
     RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
-    const int nrows = p.tile_m + 2 * p.pad * a->W;
+    const int nrows = tile2d ? 10 * 18 : p.tile_m + 2 * p.pad * a->W;
     const int nv = cdiv(nrows * 4, 256) < 2 ? 2 : cdiv(nrows * 4, 256);
     RAC_REQUIRE(nv <= 4, "rac_conv2d_fwd_split: halo too large for the LDS image");
     typedef void (*rows_fn)(Conv16P);
@@ -2334,11 +2404,13 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
     static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
     rows_fn fn = fns[width][nv - 2];
-    const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] && !(nofast && atoi(nofast));
+    const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] &&
+                      (tile2d || !(nofast && atoi(nofast)));
+    RAC_REQUIRE(fast || !tile2d, "rac_conv2d_fwd_split: 2-D tiles need the unrolled 3x3 form");
     if (fast) {
       fn = fast_fns[width][nv - 2];
-      // padded rows: W + 2 LDS rows per image row, the plane rounded to 256 B
-      lds_rows = (size_t)2 * 2 * 4 * ((((nrows / a->W) * (a->W + 2)) + 15) & ~15) * 16;
+      // padded rows: W + 2 LDS rows per image row (2-D tile: the halo tile itself), the plane rounded to 256 B
+      lds_rows = (size_t)2 * 2 * 4 * (((tile2d ? nrows : (nrows / a->W) * (a->W + 2)) + 15) & ~15) * 16;
     }
     // narrow layers (64 / 32 columns), unsplit K, many more tiles than the chip holds: persistent workgroups that walk
     // the tiles and request the next tile's first chunk under the current tile's last one

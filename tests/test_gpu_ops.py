@@ -672,6 +672,62 @@ def test_conv_split_rows_kernel(dev, case):
     assert relerr(got, xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,C0,C1,Cout,up", [(3, 64, 64, 64, 0, 64, False), (2, 64, 64, 64, 64, 64, True),
+                                                  (1, 64, 128, 32, 32, 128, False), (600, 64, 64, 64, 0, 64, False),
+                                                  (2, 64, 64, 128, 0, 128, False)])
+def test_rows_kernel_2d_tiles_are_the_same_bits(dev, B, H, W, C0, C1, Cout, up, monkeypatch):
+    """The unrolled 3x3 rows kernels with 2-D tiles (8 image rows x 16 pixels + a one-pixel halo, maps >= 64 wide) against
+    the same kernels with whole-row tiles (RAC_ROWS_TILE2D=0): the arithmetic of an output pixel is untouched -- same K
+    order, same operands -- so the results are bit-equal; forward with a fused epilogue and per-image scales, a second
+    source, the decoder's half-resolution first source (a0_up), the persistent form (600 images), and the data gradient."""
+    from robot_aware_control_amd import ops
+    h, w_ = (H // 2, W // 2) if up else (H, W)
+    x0 = to_map(rnd(51, B, C0, h, w_), dev)
+    x1 = to_map(rnd(52, B, C1, H, W), dev) if C1 else None
+    wt = cl_weight(rnd(53, Cout, C0 + C1, 3, 3) * 0.05).to(dev)
+    scale, shift = (rnd(54, Cout).abs() + 0.5).to(dev), rnd(55, Cout, scale=0.2).to(dev)
+    gy = to_map(rnd(56, B, Cout, H, W), dev)
+
+    def run():
+        y = ops.conv_forward_split(x0, x1, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift, x0_up=up, per_image=True)
+        raw = None if up else ops.conv_forward_split(x0, x1, wt, None)  # tensor-wide scale, no epilogue
+        d0, d1 = (None, None) if up else ops.conv_dgrad_split(gy, wt, C0, C1)
+        return y, ops.amax_tag(y).clone(), raw, d0, d1
+    monkeypatch.setenv("RAC_ROWS_TILE2D", "1")
+    got = run()
+    monkeypatch.setenv("RAC_ROWS_TILE2D", "0")
+    want = run()
+    for a, b in zip(got, want):
+        assert (a is None and b is None) or torch.equal(a, b)
+    src = F.interpolate(from_map(x0).double(), scale_factor=2, mode="nearest") if up else from_map(x0).double()
+    xin = torch.cat([src] + ([from_map(x1).double()] if C1 else []), 1)
+    ref = F.leaky_relu(F.conv2d(xin, wt.cpu().double(), None, 1, 1) * scale.cpu().double().view(1, -1, 1, 1)
+                       + shift.cpu().double().view(1, -1, 1, 1), 0.2)
+    assert relerr(from_map(got[0]), ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout", [(1, 64, 64), (2, 128, 64)])
+def test_rows_kernel_takes_128_wide_maps(dev, B, Cin, Cout):
+    """128x128 maps (the 64-channel layers of a 128x128 model, BASELINE configs[4]): no whole-row tile exists (a row's halo
+    alone is 256 pixels), the 2-D tiles take them -- forward, data gradient and weight gradient on the split pipe, against
+    fp64."""
+    from robot_aware_control_amd import ops
+    H = W = 128
+    assert ops.split_supported(H, W, 3, Cin, Cout, 0)
+    x, w = rnd(61, B, Cin, H, W), rnd(62, Cout, Cin, 3, 3) * (1.0 / np.sqrt(Cin * 9))
+    xd, wd = to_map(x, dev), cl_weight(w).to(dev)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    assert relerr(from_map(ops.conv_forward_split(xd, None, wd)), ref) < 2e-6
+    gy = rnd(63, B, Cout, H, W)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.conv2d(xr, wr, None, 1, 1).backward(gy.double())
+    d0, _ = ops.conv_dgrad_split(to_map(gy, dev), wd, Cin, 0)
+    assert relerr(from_map(d0), xr.grad) < 2e-6
+    wd.grad = torch.zeros_like(wd)
+    ops.conv_wgrad_split_acc(to_map(gy, dev), xd, None, wd)
+    assert relerr(wd.grad.cpu(), wr.grad) < 2e-6
+
+
 @pytest.mark.parametrize("case", [(2, 8, 8, 128, 128, 256, 5), (3, 8, 8, 128, 0, 160, 3), (1, 16, 16, 64, 0, 96, 3),
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3),
                                   (2, 32, 32, 64, 64, 64, 3), (3, 16, 16, 128, 0, 64, 5), (2, 8, 8, 64, 0, 48, 3),
