@@ -2356,7 +2356,8 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     // no room at all for a 128-wide one (its halo alone is 256 pixels).  RAC_ROWS_TILE2D=0: whole-row tiles only.
     const char* no2d = getenv("RAC_ROWS_TILE2D");
     const bool rows_fit = a->W <= 128 && rows_tile_m(a->H, a->W) && (rows_tile_m(a->H, a->W) + 2 * p.pad * a->W) * 4 <= 1024;
-    bool tile2d = a->ksize == 3 && a->W >= 64 && a->W % 16 == 0 && a->H % 8 == 0 && !(no2d && atoi(no2d) == 0 && rows_fit);
+    static const int min_w2d = [] { const char* e = getenv("RAC_ROWS_TILE2D_MINW"); return e ? atoi(e) : 64; }();
+    bool tile2d = a->ksize == 3 && a->W >= min_w2d && a->W % 16 == 0 && a->H % 8 == 0 && !(no2d && atoi(no2d) == 0 && rows_fit);
     if (tile2d && p.cps % 9 != 0) {
       if (rows_fit)
         tile2d = false;  // a K split that cuts a channel chunk: the generic loop on whole-row tiles
