@@ -921,6 +921,90 @@ WGRAD_PRESPLIT_MIN_READERS = int(os.environ.get("RAC_WGRAD_PRESPLIT_MIN", "32"))
 WGRAD_ALLKY = os.environ.get("RAC_WGRAD_ALLKY", "1") == "1"
 
 
+# The recurrent core's time-batched weight gradients (5.4 ms of matrix-pipe work at cfg2: 90 % of the parameters) do not
+# wait for the end of the backward pass: their operands are complete when the core's backward is, so they are launched
+# there on a SIDE STREAM and run under the rest of the backward pass (the encoder's: BatchNorm passes, pooling, small
+# convs -- memory-bound kernels whose workgroups fit beside the weight-gradient kernels' two per CU).  The main stream
+# waits for them before anything reads a gradient (all-reduce, Adam).  RAC_WGRAD_STREAM=0: on the main stream, at the end.
+WGRAD_STREAM = os.environ.get("RAC_WGRAD_STREAM", "1") == "1"
+_SIDE = {"stream": None, "done": None, "keep": [], "on_ready": None}
+
+
+def _amax_reserve(device, n: int) -> None:
+    """Make sure `n` more amax slots fit the current arena (a fresh arena is zero-filled by a kernel on the CURRENT stream:
+    it must not be created while a side stream is current and then be used by the main stream's kernels)."""
+    if _AMAX["buf"] is None or _AMAX["buf"].device != torch.device(device) or _AMAX["used"] + n > _AMAX_SLOTS:
+        _amax_take(device, 0)
+        if _AMAX["used"] + n > _AMAX_SLOTS:
+            _AMAX["buf"] = torch.zeros(_AMAX_SLOTS, device=device, dtype=torch.int32)
+            _AMAX["used"] = 0
+
+
+def flush_deferred_wgrads_early(weights=None) -> None:
+    """Launch the recorded (deferred) weight gradients of `weights` (None: all recorded so far), and the bias column sums
+    recorded so far, NOW on the side stream.  Called where their last operand was produced (RecurrentCore.backward)."""
+    if _DEFERRED is None or not WGRAD_STREAM:
+        return
+    if weights is None:  # everything recorded so far (each record's operands exist: they were produced in program order)
+        items = list(_DEFERRED.values())
+        _DEFERRED.clear()
+    else:
+        items = [_DEFERRED.pop(id(w)) for w in weights if id(w) in _DEFERRED]
+    if not items:
+        return
+    dev = items[0][0].device
+    _amax_reserve(dev, 8192)
+    main = torch.cuda.current_stream()
+    if _SIDE["stream"] is None or _SIDE["stream"].device != dev:
+        _SIDE["stream"] = torch.cuda.Stream(device=dev)
+    side = _SIDE["stream"]
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)  # everything enqueued so far (the operands) precedes the side stream's launches
+    bias_pending = dict(_DEFERRED_BIAS)
+    with torch.cuda.stream(side):
+        for weight, its in sorted(items, key=lambda wi: (-wi[0].numel(), wi[0].data_ptr())):
+            _wgrad_split_batch(its, weight)
+            if _SIDE["on_ready"] is not None:
+                _SIDE["on_ready"](weight)  # (a collective started here orders itself behind the side stream)
+        _flush_bias_grads()
+        done = torch.cuda.Event()
+        done.record(side)
+    # the operands were allocated on the main stream: they stay referenced until the main stream has been made to wait
+    # for `done` (deferred_wgrad's exit) -- only then may the allocator hand their memory to later main-stream kernels
+    _SIDE["keep"].append((items, bias_pending))
+    _SIDE["done"] = done
+
+
+def wgrad_on_side_stream(launch, operands, need_amax=True) -> None:
+    """Run one layer's weight-gradient launch(es) on the side stream (inside `deferred_wgrad()` only: its exit is where the
+    main stream waits): the data-gradient chain of the backward pass goes on without them.  `operands`: the tensors the
+    launch reads -- their operand maxima are taken on the main stream first (a reduction launched on the side stream
+    would leave a tag the main stream may consume unordered), and they stay referenced until the main stream has waited."""
+    if _DEFERRED is None or not WGRAD_STREAM or not operands[0].is_cuda:
+        launch()
+        return
+    if need_amax:
+        for t in operands:
+            if t is not None:
+                amax_for(t)
+    _amax_reserve(operands[0].device, 64)
+    main = torch.cuda.current_stream()
+    dev = operands[0].device
+    if _SIDE["stream"] is None or _SIDE["stream"].device != dev:
+        _SIDE["stream"] = torch.cuda.Stream(device=dev)
+    side = _SIDE["stream"]
+    ready = torch.cuda.Event()
+    ready.record(main)
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        launch()
+        done = torch.cuda.Event()
+        done.record(side)
+    _SIDE["keep"].append(operands)
+    _SIDE["done"] = done
+
+
 @contextlib.contextmanager
 def deferred_wgrad(on_ready=None):
     """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
@@ -930,6 +1014,7 @@ def deferred_wgrad(on_ready=None):
         yield
         return
     _DEFERRED = {}
+    _SIDE["on_ready"] = on_ready
     try:
         yield
         pending, _DEFERRED = _DEFERRED, None
@@ -943,6 +1028,11 @@ def deferred_wgrad(on_ready=None):
     finally:
         _DEFERRED = None
         _DEFERRED_BIAS.clear()
+        if _SIDE["done"] is not None:  # (also on an exception: nothing may outlive the side stream's reads)
+            torch.cuda.current_stream().wait_event(_SIDE["done"])
+            _SIDE["done"] = None
+        _SIDE["keep"].clear()
+        _SIDE["on_ready"] = None
 
 
 def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
@@ -1380,16 +1470,21 @@ class VggLayer(torch.autograd.Function):
                 dx0, dx1 = conv_dgrad(draw, wuse, C0, C1)
         if weight.requires_grad:
             Bq, Hq, Wq, _ = draw.shape
-            if (ctx.padded and x1 is None and weight.shape[1] <= 8 and Cout == 64 and weight.shape[2] == 3
-                    and Hq % 16 == 0 and Wq % 16 == 0):
-                # first encoder layer: 64 x 9 x (3..8) sums over all pixels, straight into the unpadded gradient
-                thin_wgrad_acc(draw, x0, weight.shape[1], weight)
-            elif ctx.split:
-                conv_wgrad_split_acc(draw, x0, x1, weight)  # un-pads into weight.grad where x0 carries pad channels
-            elif ctx.padded:
-                wgrad_padded_acc(draw, x0, weight)
-            else:
-                conv_wgrad_acc(draw, x0, x1, weight)
+            split, padded = ctx.split, ctx.padded
+
+            def wgrad():
+                if (padded and x1 is None and weight.shape[1] <= 8 and Cout == 64 and weight.shape[2] == 3
+                        and Hq % 16 == 0 and Wq % 16 == 0):
+                    # first encoder layer: 64 x 9 x (3..8) sums over all pixels, straight into the unpadded gradient
+                    thin_wgrad_acc(draw, x0, weight.shape[1], weight)
+                elif split:
+                    conv_wgrad_split_acc(draw, x0, x1, weight)  # un-pads into weight.grad where x0 carries pad channels
+                elif padded:
+                    wgrad_padded_acc(draw, x0, weight)
+                else:
+                    conv_wgrad_acc(draw, x0, x1, weight)
+            # (the layer's weight gradient leaves the data-gradient chain: side stream, see deferred_wgrad)
+            wgrad_on_side_stream(wgrad, (draw, x0, x1), need_amax=split)
         return dx0, dx1, None, None, None, None, None, None, None, None, None
 
 
@@ -1866,6 +1961,9 @@ class RecurrentCore(torch.autograd.Function):
             p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
             grad_sum([p0], d_prior_all[t], g, slot_prior)
             tape[t] = None  # (launches are stream ordered: what this step allocated may be reused by the next)
+        # every operand of the core's weight gradients exists now: they start on the side stream, under the encoder's backward
+        # (and of whatever else was recorded before: the prior's heads)
+        flush_deferred_wgrads_early(None)
         ctx.tape = ctx.plan = None
         flat = lambda t_: t_.view((T * B, H, W, g))
         d_prior_all, d_post_all = tag_amax(flat(d_prior_all), slot_prior), tag_amax(flat(d_post_all), slot_post)
