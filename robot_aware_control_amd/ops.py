@@ -927,6 +927,7 @@ WGRAD_ALLKY = os.environ.get("RAC_WGRAD_ALLKY", "1") == "1"
 # convs -- memory-bound kernels whose workgroups fit beside the weight-gradient kernels' two per CU).  The main stream
 # waits for them before anything reads a gradient (all-reduce, Adam).  RAC_WGRAD_STREAM=0: on the main stream, at the end.
 WGRAD_STREAM = os.environ.get("RAC_WGRAD_STREAM", "1") == "1"
+WGRAD_CHAIN_FLUSH = os.environ.get("RAC_WGRAD_CHAIN_FLUSH", "1") == "1"  # per ConvLSTM chain (0: once, behind the core)
 _SIDE = {"stream": None, "done": None, "keep": [], "on_ready": None}
 
 
@@ -943,7 +944,7 @@ def _amax_reserve(device, n: int) -> None:
 def flush_deferred_wgrads_early(weights=None) -> None:
     """Launch the recorded (deferred) weight gradients of `weights` (None: all recorded so far), and the bias column sums
     recorded so far, NOW on the side stream.  Called where their last operand was produced (RecurrentCore.backward)."""
-    if _DEFERRED is None or not WGRAD_STREAM:
+    if _DEFERRED is None or not WGRAD_STREAM or (weights is not None and not WGRAD_CHAIN_FLUSH):
         return
     if weights is None:  # everything recorded so far (each record's operands exist: they were produced in program order)
         items = list(_DEFERRED.values())
@@ -1929,6 +1930,11 @@ class RecurrentCore(torch.autograd.Function):
             carry[L][l] = None if first else (dc_prev, _src(slabs, n, cin, g))
             return _src(slabs, n, cin, 0)
 
+        # Three passes over time, one per ConvLSTM chain (the posterior's step t needs only dz_t of the frame predictor's
+        # step t; the prior's nothing of the others), each followed by the launch of ITS weight gradients on the side
+        # stream: the frame predictor's run under the posterior's and the prior's backward, not only under the encoder's.
+        chain_ws = lambda L, extra: [c.gates.weight for c in cells[L]] + extra
+        dcats = [None] * T
         for t in range(T - 1, -1, -1):
             rec = tape[t]
             # frame predictor: layer 1 (its h feeds the decoder), layer 0, then the input conv over cat[v | h_t | z_t]
@@ -1942,6 +1948,12 @@ class RecurrentCore(torch.autograd.Function):
             conv_wgrad_split_acc(dy_f, rec["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
             bias_grad_acc(dy_f, fconv.bias)
             grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
+            dcats[t] = (dcat, n_c)
+        flush_deferred_wgrads_early(chain_ws("fp", [fconv.weight]))
+        for t in range(T - 1, -1, -1):
+            rec = tape[t]
+            dcat, n_c = dcats[t]
+            dcats[t] = None
             # posterior: reparameterisation + KL gradients -> merged head -> layer 1, layer 0 -> its input conv's output
             dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
             slot = amax_slot(dev)
@@ -1955,6 +1967,9 @@ class RecurrentCore(torch.autograd.Function):
             q1 = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
             q0 = cell_bwd("post", 0, rec["post0"], [q1])
             grad_sum([q0], d_post_all[t], g, slot_post)
+        flush_deferred_wgrads_early(chain_ws("post", [head_w]))
+        for t in range(T - 1, -1, -1):
+            rec = tape[t]
             # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
             ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
             p1 = cell_bwd("prior", 1, rec["prior1"], ext)
