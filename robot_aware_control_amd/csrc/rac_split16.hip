@@ -61,6 +61,13 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
 
+// timing builds of the persistent rows kernel (tools/build_variant.sh ... -DRAC_EXP_PERSIST=<bits>; results are WRONG):
+// 1 epilogue without its stores, 2 no epilogue, 4 staging with one conversion instead of the split, 8 fragment reads at tap 0
+// only, 16 no weight loads inside the loop, 32 the next tile = this tile (no per-tile index arithmetic, staging loads hit L2)
+#ifndef RAC_EXP_PERSIST
+#define RAC_EXP_PERSIST 0
+#endif
+
 // eight fp32 values (two 16-byte vectors) * scale -> two fp16 parts, packed as 16-byte MFMA operand vectors
 __device__ __forceinline__ void split8h(u32x4 lo, u32x4 hi, float s, u32x4 (&q)[2]) {
   const unsigned w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
@@ -70,7 +77,7 @@ __device__ __forceinline__ void split8h(u32x4 lo, u32x4 hi, float s, u32x4 (&q)[
     const float v = __builtin_bit_cast(float, w[j]) * s;
     const _Float16 a = (_Float16)v;
     h1[j] = a;
-    h2[j] = (_Float16)(v - (float)a);
+    h2[j] = (RAC_EXP_PERSIST & 4) ? a : (_Float16)(v - (float)a);
   }
   q[0] = __builtin_bit_cast(u32x4, h1);
   q[1] = __builtin_bit_cast(u32x4, h2);
@@ -200,7 +207,7 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
         v = v > 0.f ? v : slope * v;
         if (SIG) v = sigmoid_acc(v);
         if (ok) {
-          p.out0[(long)m * NS + n] = v;
+          if (!(RAC_EXP_PERSIST & 1)) p.out0[(long)m * NS + n] = v;
           mxb[mb] = max(mxb[mb], absbits(v));
         }
       }
@@ -1352,6 +1359,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   issue_a(0, cur_t);
   load_b(bs[0], kc_begin);
   load_b(bs[1], min(kc_begin + 1, kc_end - 1));
+  if (RAC_EXP_PERSIST & 16) load_b(bs[2], min(kc_begin + 2, kc_end - 1));
   int cur = 0;
   // A fragments rotate through the tap in halves: the second half's reads are issued before the first half's MFMAs, the NEXT
   // tap's first half before the second half's MFMAs, pinned with scheduling barriers.  (Left alone, the scheduler issued
@@ -1373,7 +1381,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < HB; ++t) read_frag(t, 0, cur * abuf);
-    if (has_next) setup(next_bx, nxt_t);
+    if (has_next) {
+      if (RAC_EXP_PERSIST & 32)
+        nxt_t = cur_t;
+      else
+        setup(next_bx, nxt_t);
+    }
     f32x4 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -1391,7 +1404,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
         // the ring wraps to taps 0 and 1 of chunk 0 behind the last chunk: the next tile multiplies the same weights
         int knext = kc0 + tap + 2;
         knext = knext >= kc_end ? knext - kc_end : knext;
-        load_b(bs[(tap + 2) % 3], knext);
+        if (!(RAC_EXP_PERSIST & 16)) load_b(bs[(tap + 2) % 3], knext);
         __builtin_amdgcn_sched_barrier(0);
         f16x8 fb[NB][2];
 #pragma unroll
@@ -1401,8 +1414,10 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
 #pragma unroll
             for (int part = 0; part < 2; ++part)
               fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, bs[tap % 3][(j2 * 2 + part) * 2 + nb]);
+        if (!(RAC_EXP_PERSIST & 8) || tap == 0) {
 #pragma unroll
-        for (int t = HB; t < MB; ++t) read_frag(t, tap, cur * abuf);
+          for (int t = HB; t < MB; ++t) read_frag(t, tap, cur * abuf);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < HB; ++t)
@@ -1414,7 +1429,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
           __syncthreads();
           cur ^= 1;
         }
-        if (tap < 8 || more) {
+        if ((tap < 8 || more) && (!(RAC_EXP_PERSIST & 8) || tap == 8)) {
 #pragma unroll
           for (int t = 0; t < HB; ++t) read_frag(t, (tap + 1) % 9, cur * abuf);
         }
@@ -1426,8 +1441,19 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
       }
     }
     const int img = p.per_image ? cur_t.m0 / p.HW : 0;
-    conv16_epilogue(p, acc, cur_t.m0, wm * MB, nmb, n0 + wn * NT * 32, 0, pow2f(-cur_t.ka), pow2f(-kw), pre, nullptr,
-                    p.out_amax ? p.out_amax + img : nullptr);
+    if (RAC_EXP_PERSIST & 2) {
+      unsigned mx = 0;
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = max(mx, absbits(acc[i][j][r]));
+      if (p.out_amax) amax_commit(mx, p.out_amax + img);
+    } else {
+      conv16_epilogue(p, acc, cur_t.m0, wm * MB, nmb, n0 + wn * NT * 32, 0, pow2f(-cur_t.ka), pow2f(-kw), pre, nullptr,
+                      p.out_amax ? p.out_amax + img : nullptr);
+    }
     if (!has_next) break;
     // the next tile's first chunk goes to the buffer nobody reads any more (the last chunk sits in `cur`)
     cur ^= 1;
@@ -1564,6 +1590,8 @@ __global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_fra
   const int taps = q.ksize * q.ksize, cch = q.Cin >> 5;
   const int half = threadIdx.x >> 7;
   const long cell = (blockIdx.x - q.block_begin) * 2 + half;  // ((nt * cch + cc) * taps + tap)
+  // (walking the cells along the input channels first -- consecutive workgroups on consecutive 256-byte pieces of the same
+  // weight rows, the fragment writes then 50 KB apart -- measured 2.02 ms against 1.85 for this order)
   const bool active = cell < (long)(q.Cout >> 5) * cch * taps;
   const int tap = (int)(cell % taps);
   const int cc = (int)((cell / taps) % cch);
