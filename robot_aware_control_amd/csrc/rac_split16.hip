@@ -349,6 +349,9 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOZERO
 #define RAC_EXP_ROWS_NOZERO 0
 #endif
+#ifndef RAC_EXP_TILE  // timing builds of the tile kernel (wrong results): 1 = activations requested for the first chunk only, 2 = every chunk requests the FIRST chunk's addresses (L2 hits)
+#define RAC_EXP_TILE 0
+#endif
 #ifndef RAC_EXP_ROWS_NOSTORE
 #define RAC_EXP_ROWS_NOSTORE 0
 #endif
@@ -380,11 +383,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
   constexpr int CP = YM ? T16Y_CP : T16_CP, PP = 4 * CP, ABUF = 2 * PP;
-  const int srow = tid & 127, sch = tid >> 7;  // staging: row, chunks sch and sch + 2
+  const int srow = tid & 127;  // (the tile row whose per-image scale this thread publishes)
   // the accumulator row of the staged pixel: its tile row, or (YM) 16 y + 8 image + x ...
   const int lrow = (YM && srow < TM) ? ((srow % p.HW) >> 3) * 16 + (srow / p.HW) * 8 + (srow & 7) : srow;
-  // ... and its LDS row: the same, or (YM) 32 y + 16 image + 4 + x (padded segments)
-  const int srow_lds = YM ? ((srow % p.HW) >> 3) * T16Y_PITCH + (srow / p.HW ? T16Y_S1 : T16Y_S0) + (srow & 7) : srow;
   __shared__ float ia_sh[128];  // per-image scales: 1 / scale of every tile row's image
   unsigned am;
   if (p.per_image) {  // the scale of the image this thread's staged row belongs to
@@ -397,7 +398,29 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     if (p.a_amax1) am = max(am, *p.a_amax1);
   }
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
-  const float sa = pow2f(ka);
+  // Staging roles: thread t requests 32 contiguous bytes (8 channels) of tile rows t / 4 and t / 4 + 64 -- four lanes cover
+  // a pixel's 128-byte chunk row, a wave's request touches 16 cache lines.  (Rounds 1-3 gave a wave 64 consecutive ROWS of
+  // one 8-channel group: 64 lines per request, each line fetched again by the three other waves' requests behind 64 KB of
+  // weight traffic per step -- the vector memory pipe, not HBM, paid for it: see profiles/r04_tile_staging.md.)
+  const int agrp = tid & 3;
+  int arow_lds[2];
+  bool a_ok2[2], a_slot[2];
+  float sa2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = (tid >> 2) + 64 * i;
+    // LDS row of tile row r: r itself, or (YM) 36 y + (2 | 26) + x (padded segments)
+    arow_lds[i] = YM ? ((r % p.HW) >> 3) * T16Y_PITCH + (r / p.HW ? T16Y_S1 : T16Y_S0) + (r & 7) : r;
+    a_ok2[i] = (r < TM) & (m0 + r < p.M);
+    a_slot[i] = !YM || r < TM;  // (YM: a row past the tile has no slot of its own)
+    unsigned am_i = am;
+    if (p.per_image) {
+      const int img = min((m0 + r) / p.HW, p.B - 1);
+      am_i = p.a_amax0[img];
+      if (p.a_amax1) am_i = max(am_i, p.a_amax1[img]);
+    }
+    sa2[i] = pow2f(scale_exp(am_i));
+  }
   if constexpr (YM) {  // everything: the padding slots (and the rows of a short tile) are never written again
 #pragma unroll
     for (int i = 0; i < 2 * ABUF / (256 * 16); ++i)  // (2 * ABUF = 18 * 4096)
@@ -409,7 +432,6 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
                               (128 + r) * 16) = u32x4{0u, 0u, 0u, 0u};
   }
 
-  const bool a_ok = (srow < TM) & (m0 + srow < p.M);
   unsigned amask[RB];  // per 16-row block: one bit per tap for the shifted pixel's validity
 #pragma unroll
   for (int t = 0; t < RB; ++t) {
@@ -457,20 +479,20 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned oa = (unsigned)((m0 + srow) * Cs + cl + (sch + 2 * i) * 8) * 4u;
-      ra[2 * i] = load16(a_rsrc, a_ok ? oa : OOB);
-      ra[2 * i + 1] = load16(a_rsrc, a_ok ? oa + 16u : OOB);
+      const unsigned oa = (unsigned)((m0 + (tid >> 2) + 64 * i) * Cs + cl + agrp * 8) * 4u;
+      ra[2 * i] = load16(a_rsrc, a_ok2[i] ? oa : OOB);
+      ra[2 * i + 1] = load16(a_rsrc, a_ok2[i] ? oa + 16u : OOB);
     }
   };
   auto store_a = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       u32x4 q[2];
-      split8h(ra[2 * i], ra[2 * i + 1], sa, q);
+      split8h(ra[2 * i], ra[2 * i + 1], sa2[i], q);
 #pragma unroll
       for (int part = 0; part < 2; ++part)
-        if (!YM || srow < TM)  // (YM: a row past the tile has no slot of its own)
-          *reinterpret_cast<u32x4*>(lds_raw + buf * ABUF + part * PP + (sch + 2 * i) * CP + srow_lds * 16) = q[part];
+        if (a_slot[i])
+          *reinterpret_cast<u32x4*>(lds_raw + buf * ABUF + part * PP + agrp * CP + arow_lds[i] * 16) = q[part];
     }
   };
 
@@ -485,7 +507,6 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     int tap = kc_begin - cc * p.taps;
     int ky = tap / p.ks, kx = tap - ky * p.ks;
     int cur = 0;
-    bool fresh = true;
     // weights two steps ahead in three register sets.  (Measured alternatives, M = 1024 / 64 000 gate GEMM: A fragments
     // double-buffered in registers with two weight sets 428-440 / 473 TF, with three sets (spills) 390 / 447; skipping
     // the MFMAs of row blocks that are all padding for a tap (10 % of a 5x5 conv on 8x8 maps) through three step
@@ -501,12 +522,21 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     load_b(b1, kc_begin + 1);
     store_a(0);
     __syncthreads();
+    // The next chunk's activations are requested where the previous chunk's have just been converted -- here and behind the
+    // conversion at a chunk's last step -- never at the START of a step: between that request and its conversion every path
+    // then passes at least one step's 8 weight loads, and the compiler's wait-counter model can prove it (`s_waitcnt
+    // vmcnt(11)` ... `(8)` in front of the conversion).  Rounds 1-3 requested "when a chunk's first step begins" and converted
+    // "when its last step ends", two run-time conditions of the same step body: the model had to assume the conversion may
+    // follow the request directly, `vmcnt(3)` ... `(0)`, and since loads return in order that also drained the 16 weight loads
+    // in flight for the next two steps -- an exposed L2 round trip per chunk (9 steps of a 3x3 conv, 25 of a 5x5).
+    auto request_a = [&](int c) {
+      if (!(RAC_EXP_TILE & 1) && c * p.taps < kc_end) issue_a((RAC_EXP_TILE & 2) ? kc_begin / p.taps : c);
+    };
+    request_a(cc + 1);
 
     auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
       const bool last_tap = tap == p.taps - 1;
       const bool more = kc + 1 < kc_end;
-      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
-      fresh = false;
       const int drow = (ky - p.pad) * (YM ? T16Y_PITCH : p.W) + (kx - p.pad);
       const int shift = drow * 16 + cur * ABUF + abase;
       // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
@@ -549,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         store_a(cur ^ 1);
         __syncthreads();
         cur ^= 1;
-        fresh = true;
+        request_a(cc + 2);
       }
       cc = last_tap ? cc + 1 : cc;
       tap = last_tap ? 0 : tap + 1;
@@ -1133,19 +1163,19 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     int tap = kc_begin - cc * p.taps;
     int ky = tap / p.ks, kx = tap - ky * p.ks;
     int cur = 0;
-    bool fresh = true;
     u32x4 bs[D][4 * NT];
     issue_a(cc);
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load_b(bs[j], kc_begin + j);
     store_a(0);
     __syncthreads();
+    // (the next chunk's activations are requested right behind a conversion, never at the start of a step: see
+    // conv16_tile_kernel -- the wait in front of the conversion then leaves the weight ring in flight)
+    if ((cc + 1) * p.taps < kc_end) issue_a(cc + 1);
 
     auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
       const bool last_tap = tap == p.taps - 1;
       const bool more = kc + 1 < kc_end;
-      if (fresh && (cc + 1) * p.taps < kc_end) issue_a(cc + 1);
-      fresh = false;
       const int drow = (ky - p.pad) * p.W + (kx - p.pad);
       const int shift = drow * 16 + cur * abuf + abase;
       const int zr = zrow + cur * abuf + ((lr + halo + drow) & 15) * 16;  // the zero row on this lane's own bank slot
@@ -1183,7 +1213,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
         store_a(cur ^ 1);
         __syncthreads();
         cur ^= 1;
-        fresh = true;
+        if ((cc + 2) * p.taps < kc_end) issue_a(cc + 2);
       }
       cc = last_tap ? cc + 1 : cc;
       tap = last_tap ? 0 : tap + 1;

@@ -10,7 +10,9 @@ export TMPDIR=/tmp
 T="--workload train --steps 5 --warmup 2 --no-cpu-baseline --no-exact --no-side"
 C="--workload cem --cem-iters 1 --cem-warmup 1 --no-cpu-baseline --no-exact --no-cem-ra --cem-opt-iter 1"
 echo "[profiles] kernel trace + stats, train" >&2
-RAC_SHAPE_LOG=$out/train_shapes.json rocprofv3 --kernel-trace --stats -d "$out/stats_train" -o run --output-format csv -- python3 bench.py $T > "$out/stats_train.json" 2> "$out/stats_train.err"
+# (per-kernel durations: weight gradients IN ORDER on the main stream -- on the side stream they overlap other kernels, and
+# both sides of an overlap report longer durations than they have alone; the step itself is timed by bench.py with streams on)
+RAC_WGRAD_STREAM=0 RAC_SHAPE_LOG=$out/train_shapes.json rocprofv3 --kernel-trace --stats -d "$out/stats_train" -o run --output-format csv -- python3 bench.py $T > "$out/stats_train.json" 2> "$out/stats_train.err"
 echo "[profiles] kernel trace + stats, cem" >&2
 RAC_SHAPE_LOG=$out/cem_shapes.json rocprofv3 --kernel-trace --stats -d "$out/stats_cem" -o run --output-format csv -- python3 bench.py $C > "$out/stats_cem.json" 2> "$out/stats_cem.err"
 G1="python3 tools/bench_gemm.py fwd 16 512 5 3"

@@ -1,0 +1,7 @@
+out=gpurun_out/r04c; mkdir -p $out; export RAC_BENCH_SPLIT=1
+RAC_HIP_LIB=robot_aware_control_amd/variants/librac_new.so python -m pytest tests/test_gpu_ops.py -x -q 2>&1 | tail -n 2
+for r in 1 2; do for v in old new; do for k in 3 5; do
+  echo -n "$v k=$k M=64000: "; RAC_HIP_LIB=robot_aware_control_amd/variants/librac_$v.so python tools/bench_gemm.py fwd 1000 512 $k 5 2>&1 | grep -i "kernel only" | head -n 1
+  echo -n "$v k=$k M=1024: "; RAC_HIP_LIB=robot_aware_control_amd/variants/librac_$v.so python tools/bench_gemm.py fwd 16 512 $k 20 2>&1 | grep -i "kernel only" | head -n 1
+done; done; done > $out/tile_exp3.log 2>&1
+cat $out/tile_exp3.log
