@@ -355,7 +355,8 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOSTORE
 #define RAC_EXP_ROWS_NOSTORE 0
 #endif
-template <int WM, bool FULL, bool YM = false>
+// KU = 3: the 9 taps of a 3x3 conv's chunk unrolled (K ranges are whole chunks): tap constants, and every wait exact.
+template <int WM, bool FULL, bool YM = false, int KU = 0>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   constexpr int WN = 4 / WM;   // waves along the columns
   constexpr int RB = 8 / WM;   // 16-row blocks per wave
@@ -534,9 +535,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     };
     request_a(cc + 1);
 
-    auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
-      const bool last_tap = tap == p.taps - 1;
-      const bool more = kc + 1 < kc_end;
+    auto stepk = [&](const u32x4(&rb)[4 * NT], int tap, int ky, int kx) {
       const int drow = (ky - p.pad) * (YM ? T16Y_PITCH : p.W) + (kx - p.pad);
       const int shift = drow * 16 + cur * ABUF + abase;
       // pixels outside the image read one of the 16 zero rows: the one on the bank slot this lane's shifted row
@@ -575,6 +574,78 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
             acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
           }
       }
+    };
+    if constexpr (KU == 3) {
+      // (p.ks == 3, p.pad == 1, whole chunks: the launcher's condition)
+      const int c_end = kc_end / 9;
+      for (; cc < c_end; ++cc) {
+        const bool more = cc + 1 < c_end;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          if (t9 == 0) load_b(b2, cc * 9 + 2);
+          if (t9 % 3 == 1) load_b(b0, cc * 9 + t9 + 2);
+          if (t9 % 3 == 2) load_b(b1, cc * 9 + t9 + 2);
+          if (t9 % 3 == 0 && t9) load_b(b2, cc * 9 + t9 + 2);
+          stepk(t9 % 3 == 0 ? b0 : (t9 % 3 == 1 ? b1 : b2), t9, t9 / 3, t9 % 3);
+        }
+        if (more) {
+          store_a(cur ^ 1);
+          __syncthreads();
+          cur ^= 1;
+          request_a(cc + 2);
+        }
+      }
+    } else if constexpr (KU == 5) {
+      // 25 taps per chunk, ring of 3: a chunk's first step sits at ring phase (25 x chunks so far) mod 3 = chunks mod 3.  One
+      // instance of the chunk per phase, three chunks per trip; inside an instance the phase is static: 8 groups of 3 steps
+      // (a run-time loop whose iterations all leave the ring in the same registers) + the 25th step.
+      const int c_end = kc_end / 25;
+      auto chunk5 = [&](auto phase, int c) {
+        constexpr int P = decltype(phase)::value;
+        const bool more = c + 1 < c_end;
+        const int kc0 = c * 25;
+        u32x4(&s0)[4 * NT] = P == 0 ? b0 : (P == 1 ? b1 : b2);
+        u32x4(&s1)[4 * NT] = P == 0 ? b1 : (P == 1 ? b2 : b0);
+        u32x4(&s2)[4 * NT] = P == 0 ? b2 : (P == 1 ? b0 : b1);
+        int t = 0, y = 0, x = 0;
+        auto adv = [&] {
+          ++t;
+          x = x == 4 ? 0 : x + 1;
+          y = x == 0 ? y + 1 : y;
+        };
+        for (int g8 = 0; g8 < 8; ++g8) {
+          load_b(s2, kc0 + t + 2);
+          stepk(s0, t, y, x);
+          adv();
+          load_b(s0, kc0 + t + 2);
+          stepk(s1, t, y, x);
+          adv();
+          load_b(s1, kc0 + t + 2);
+          stepk(s2, t, y, x);
+          adv();
+        }
+        load_b(s2, kc0 + 26);
+        stepk(s0, 24, 4, 4);
+        if (more) {
+          store_a(cur ^ 1);
+          __syncthreads();
+          cur ^= 1;
+          request_a(c + 2);
+        }
+      };
+      while (cc < c_end) {
+        chunk5(std::integral_constant<int, 0>{}, cc);
+        if (++cc >= c_end) break;
+        chunk5(std::integral_constant<int, 1>{}, cc);
+        if (++cc >= c_end) break;
+        chunk5(std::integral_constant<int, 2>{}, cc);
+        ++cc;
+      }
+    } else {
+    auto step = [&](const u32x4(&rb)[4 * NT], int kc) {
+      const bool last_tap = tap == p.taps - 1;
+      const bool more = kc + 1 < kc_end;
+      stepk(rb, tap, ky, kx);
       if (last_tap && more) {
         store_a(cur ^ 1);
         __syncthreads();
@@ -601,6 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         load_b(b1, kc + 4);
         step(b2, kc + 2);
       }
+    }
     }
   }
 
@@ -2511,13 +2583,25 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   static const char* noym = getenv("RAC_TILE_YMAJOR");
   const bool ym = a->W == 8 && p.tile_m == 2 * p.HW && !(noym && atoi(noym) == 0);  // 8x8 / 6x8 maps: skip vertical padding
   typedef void (*tile_fn)(Conv16P);
-  const tile_fn fn = p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true> : (tile_fn)conv16_tile_kernel<2, true>)
-                                     : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>);
+  // 3x3 convs whose K ranges are whole chunks: the unrolled-tap instance (RAC_TILE_UNROLL3=0: the generic loop)
+  static const char* nou3 = getenv("RAC_TILE_UNROLL3");
+  const bool u3 = a->ksize == 3 && p.cps % 9 == 0 && !(nou3 && atoi(nou3) == 0);
+  static const char* nou5 = getenv("RAC_TILE_UNROLL5");
+  const bool u5 = a->ksize == 5 && p.cps % 25 == 0 && !(nou5 && atoi(nou5) == 0);
+  const tile_fn fn =
+      u5 ? (p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true, 5> : (tile_fn)conv16_tile_kernel<2, true, false, 5>)
+                            : (ym ? (tile_fn)conv16_tile_kernel<2, false, true, 5> : (tile_fn)conv16_tile_kernel<2, false, false, 5>)) :
+      u3 ? (p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true, 3> : (tile_fn)conv16_tile_kernel<2, true, false, 3>)
+                            : (ym ? (tile_fn)conv16_tile_kernel<2, false, true, 3> : (tile_fn)conv16_tile_kernel<2, false, false, 3>))
+         : (p.tile_m == 128 ? (ym ? (tile_fn)conv16_tile_kernel<2, true, true> : (tile_fn)conv16_tile_kernel<2, true>)
+                            : (ym ? (tile_fn)conv16_tile_kernel<2, false, true> : (tile_fn)conv16_tile_kernel<2, false>));
   if (ym) {
     lds_tile = 2 * T16Y_ABUF;  // 73,728 B (+ 512 B static): two workgroups per CU
     static bool ym_attr = false;
     if (!ym_attr) {
-      for (tile_fn f : {(tile_fn)conv16_tile_kernel<2, true, true>, (tile_fn)conv16_tile_kernel<2, false, true>}) {
+      for (tile_fn f : {(tile_fn)conv16_tile_kernel<2, true, true>, (tile_fn)conv16_tile_kernel<2, false, true>,
+                        (tile_fn)conv16_tile_kernel<2, true, true, 3>, (tile_fn)conv16_tile_kernel<2, false, true, 3>,
+                        (tile_fn)conv16_tile_kernel<2, true, true, 5>, (tile_fn)conv16_tile_kernel<2, false, true, 5>}) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            2 * T16Y_ABUF);
         if (e != hipSuccess) {
