@@ -355,6 +355,18 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOSTORE
 #define RAC_EXP_ROWS_NOSTORE 0
 #endif
+#ifndef RAC_EXP_ROWS_NOB
+#define RAC_EXP_ROWS_NOB 0
+#endif
+#ifndef RAC_ROWS_REFILL  // the rows kernel's weight sets refilled in place, quarter by quarter (0: one set kept free for the requests)
+#define RAC_ROWS_REFILL 1
+#endif
+#ifndef RAC_ROWS_REFILL_PIN  // scheduling barriers around a quarter's refill request: 1 = before, 2 = behind
+#define RAC_ROWS_REFILL_PIN 3
+#endif
+#ifndef RAC_ROWS_RING3  // three weight register sets in the 128-column rows kernel too (needs its registers freed elsewhere)
+#define RAC_ROWS_RING3 0
+#endif
 // KU = 3: the 9 taps of a 3x3 conv's chunk unrolled (K ranges are whole chunks): tap constants, and every wait exact.
 template <int WM, bool FULL, bool YM = false, int KU = 0>
 __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
@@ -1168,7 +1180,14 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       // MFMAs that read it: each tap then waited out an L2 round trip (seen in the ISA: s_waitcnt vmcnt(7) straight after
       // eight loads).  Nine taps are odd, so with two sets the set of a tap alternates between chunks: the chunk body exists
       // for both parities.  The narrower forms keep three sets, two taps ahead.
-      constexpr int R = NT == 2 ? 2 : 3, AHEAD = R - 1;
+      // RAC_ROWS_REFILL: no set is kept free for the requests -- all R sets are in flight, and a set is refilled IN PLACE, one
+      // 16-column quarter (two 16-byte loads) at a time, as soon as the MFMAs that read that quarter have been issued
+      // (the MFMAs of a tap run column-block-major for this): the quarter for tap t + R is requested 1/4 .. 4/4 of the way
+      // through tap t and first read the same way through tap t + R -- R - 1/4 taps of cover for every quarter instead
+      // of R - 1, from the same registers.  +2-3 % on the 16x16 256-channel layers, ~1 % on the 32x32 ones; a SIX-set ring on
+      // the 64-column form (16 VGPRs per set) measured exactly the three-set time: L2 latency is covered, what the weight
+      // stream costs these kernels (a timing build without it: +12 % here, +33 % before the refill) is not waiting time.
+      constexpr int R = (NT == 2 && !RAC_ROWS_RING3) ? 2 : 3, AHEAD = RAC_ROWS_REFILL ? R : R - 1;
       u32x4 bs[R][4 * NT];
       issue_a(c_begin);
 #pragma unroll
@@ -1176,6 +1195,13 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       store_a(0);
       __syncthreads();
       int cur = 0;
+      auto load_b_quarter = [&](u32x4(&rb)[4 * NT], int nb, int kc) {
+        const int j = nb >> 1, h = nb & 1;
+#pragma unroll
+        for (int part = 0; part < 2; ++part)
+          rb[(j * 2 + part) * 2 + h] = __builtin_bit_cast(
+              u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + h * 1024u), kc * 2048, 0));
+      };
       auto chunk = [&](auto par, int cc) {
         constexpr int P = decltype(par)::value;
         const bool more = cc + 1 < c_end;
@@ -1185,7 +1211,9 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
           const int ky = tap / 3, kx = tap % 3;
+#if !(RAC_EXP_ROWS_NOB) && !RAC_ROWS_REFILL  // (timing build: the weight fragments loaded once per workgroup)
           load_b(bs[(tap + AHEAD + P) % R], min(kc0 + tap + AHEAD, kc_end - 1));
+#endif
 #if RAC_ROWS_PIN
           // pin the requests here: in this one large basic block the scheduler otherwise moves them towards their use.
           // (Also pinning a tap's fragment reads before its MFMAs, or rotating them through the tap in halves as
@@ -1209,10 +1237,27 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
             for (int part = 0; part < 2; ++part)
               fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
           }
+#if RAC_ROWS_REFILL
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int t = 0; t < MB; ++t) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
+#if RAC_ROWS_REFILL_PIN & 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#if !(RAC_EXP_ROWS_NOB)
+            load_b_quarter(bs[(tap + P) % R], nb, min(kc0 + tap + R, kc_end - 1));
+#endif
+#if RAC_ROWS_REFILL_PIN & 2
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+#else
 #pragma unroll
           for (int t = 0; t < MB; ++t)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
+#endif
         }
         if (more) {
           store_a(cur ^ 1);
@@ -1226,6 +1271,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
         }
       } else {
+        static_assert(9 % R == 0, "ring phase");
         for (int cc = c_begin; cc < c_end; ++cc) chunk(std::integral_constant<int, 0>{}, cc);
       }
     }
