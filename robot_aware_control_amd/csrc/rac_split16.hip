@@ -547,6 +547,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     };
     request_a(cc + 1);
 
+    // (Refilling the weight sets in place by 16-column quarters, as conv16_rows_kernel does -- all three sets in flight,
+    // 2 3/4 steps of cover -- needs the MFMAs column-block-major with the requests pinned between the blocks: measured
+    // 12.18 -> 12.93 ms on the 5x5 gate GEMM at M = 64 000, 4.79 -> 4.95 on the 3x3: the order costs more than the cover gains.)
     auto stepk = [&](const u32x4(&rb)[4 * NT], int tap, int ky, int kx) {
       const int drow = (ky - p.pad) * (YM ? T16Y_PITCH : p.W) + (kx - p.pad);
       const int shift = drow * 16 + cur * ABUF + abase;
