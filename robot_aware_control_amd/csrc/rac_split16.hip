@@ -411,17 +411,23 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     if (p.a_amax1) am = max(am, *p.a_amax1);
   }
   const int ka = scale_exp(am), kw = scale_exp(*p.w_amax);
-  // Staging roles: thread t requests 32 contiguous bytes (8 channels) of tile rows t / 4 and t / 4 + 64 -- four lanes cover
-  // a pixel's 128-byte chunk row, a wave's request touches 16 cache lines.  (Rounds 1-3 gave a wave 64 consecutive ROWS of
+  // Staging roles: a thread requests 32 contiguous bytes (8 channels) of two tile rows 64 apart; a wave covers 16 rows x 4
+  // groups: four of its lanes cover a pixel's 128-byte chunk row, its request touches 16 cache lines.  (Rounds 1-3 gave a wave 64 consecutive ROWS of
   // one 8-channel group: 64 lines per request, each line fetched again by the three other waves' requests behind 64 KB of
   // weight traffic per step -- the vector memory pipe, not HBM, paid for it: see profiles/r04_tile_staging.md.)
-  const int agrp = tid & 3;
+  // Lane order inside a wave: 8 consecutive rows of ONE group per 8 lanes -- an LDS store retires 8 lanes per clock into 32
+  // banks (profiles/r04_lds_conflicts.md), and the planes of the four groups start on the same bank: 8 rows of one plane
+  // are 128 contiguous bytes (conflict free), one row's four groups would be 4 lanes on one 16-byte slot.  The request
+  // still touches 16 lines: which lanes of the instruction share a line does not matter.  (Skewing the planes by 32 bytes
+  // instead made every fragment READ conflict: SQ_LDS_BANK_CONFLICT 49 % of the LDS-active cycles.)
+  const int agrp = (tid >> 3) & 3;
+  const int arow0 = 16 * (tid >> 6) + (tid & 7) + 8 * ((tid >> 5) & 1);
   int arow_lds[2];
   bool a_ok2[2], a_slot[2];
   float sa2[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int r = (tid >> 2) + 64 * i;
+    const int r = arow0 + 64 * i;
     // LDS row of tile row r: r itself, or (YM) 36 y + (2 | 26) + x (padded segments)
     arow_lds[i] = YM ? ((r % p.HW) >> 3) * T16Y_PITCH + (r / p.HW ? T16Y_S1 : T16Y_S0) + (r & 7) : r;
     a_ok2[i] = (r < TM) & (m0 + r < p.M);
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     const rsrc_t a_rsrc = make_rsrc(first ? (const void*)p.a0 : (const void*)p.a1, (unsigned)((long)p.P * Cs * 4));
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const unsigned oa = (unsigned)((m0 + (tid >> 2) + 64 * i) * Cs + cl + agrp * 8) * 4u;
+      const unsigned oa = (unsigned)((m0 + arow0 + 64 * i) * Cs + cl + agrp * 8) * 4u;
       ra[2 * i] = load16(a_rsrc, a_ok2[i] ? oa : OOB);
       ra[2 * i + 1] = load16(a_rsrc, a_ok2[i] ? oa + 16u : OOB);
     }
