@@ -349,6 +349,9 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOZERO
 #define RAC_EXP_ROWS_NOZERO 0
 #endif
+#ifndef RAC_WGRAD_ROLL  // weight-gradient kernel: input fragments rolled through the taps in halves (0: read per tap, then wait)
+#define RAC_WGRAD_ROLL 1
+#endif
 #ifndef RAC_EXP_TILE  // timing builds of the tile kernel (wrong results): 1 = activations requested for the first chunk only, 2 = every chunk requests the FIRST chunk's addresses (L2 hits)
 #define RAC_EXP_TILE 0
 #endif
@@ -2045,6 +2048,37 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int part = 0; part < 2; ++part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
+      if constexpr (NU == 2 && RAC_WGRAD_ROLL) {
+        // The input fragments roll through the taps in halves: the 16-ci block u of tap k + 1 is read into the registers of
+        // block u of tap k as soon as that block's 12 MFMAs are issued, under the 12 MFMAs of the other block -- every tap's
+        // fragments are in flight for half a tap before their first use instead of being waited for in front of it (the ISA
+        // of the plain loop: 8 reads, s_waitcnt lgkmcnt(0), 24 MFMAs, five times per step).  No registers added.  Reads are
+        // unconditional (a tap that leaves the image row reads a stale slot), only its MFMAs are skipped.
+        f16x8 fb[2][2];
+        auto read_fb = [&](int u, int k) {
+          int sl = sm + k - PAD;
+          sl += sl < 0 ? NR : 0;
+          sl -= sl >= NR ? NR : 0;
+#pragma unroll
+          for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
+        };
+        read_fb(0, 0);
+        read_fb(1, 0);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          const bool valid = (unsigned)(c + k - PAD) < (unsigned)p.W;  // uniform: the tap stays inside the image row
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (valid) {
+#pragma unroll
+              for (int t = 0; t < 4; ++t) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < KS) read_fb(u, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < KS; ++k) {
         if ((unsigned)(c + k - PAD) >= (unsigned)p.W) continue;  // uniform: the tap leaves the image row
@@ -2060,6 +2094,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int u = 0; u < NU; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+      }
       }
       if (more_dy) store_dy((s + 1) & 1);
       if (more_x) {
