@@ -61,6 +61,9 @@ __host__ __device__ __forceinline__ int scale_exp(unsigned amax_bits) {
 }
 __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float, (unsigned)(k + 127) << 23); }
 
+#ifndef RAC_EPILOGUE_FAST  // the conv kernels' predicate-free epilogue with buffer stores (0: the general path always)
+#define RAC_EPILOGUE_FAST 1
+#endif
 // timing builds of the persistent rows kernel (tools/build_variant.sh ... -DRAC_EXP_PERSIST=<bits>; results are WRONG):
 // 1 epilogue without its stores, 2 no epilogue, 4 staging with one conversion instead of the split, 8 fragment reads at tap 0
 // only, 16 no weight loads inside the loop, 32 the next tile = this tile (no per-tile index arithmetic, staging loads hit L2)
@@ -179,6 +182,44 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
     mxb[mb] = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) iav[mb][r] = ia_rows ? ia_rows[min((mb0 + mb) * 16 + 4 * lq + r, 127)] : ia;
+  }
+  // FAST PATH (wave-uniform; every tile but a ragged last one, every layer whose columns fill the wave's blocks; not the
+  // training pass's statistics): no per-value row / column predicates, and the stores are buffer stores -- one base per
+  // 16-row block (scalar), four lane offsets for the lane's four rows computed once, the column block as the instruction's
+  // immediate -- instead of a 64-bit address per value.  Same arithmetic on every value: the same bits.  (The per-tile fixed
+  // costs of the narrow layers' kernels add up, profiles/r04_persist_decomposition.md: this is the largest of them.)
+  const int blk_last = min(mb0 + MBLK, nmb) - 1;  // the wave's last live block
+  const int m_last = ym_hw ? m0 + ym_hw + blk_last * 8 + 7 : seg_row_pixel(p, m0, blk_last * 16) + 15;
+  if (RAC_EPILOGUE_FAST && !p.stats && blk_last >= mb0 && m_last < p.M && ncol0 + NBLK * 16 <= NS &&
+      (long)p.M * NS * 4 < (1l << 32)) {
+    unsigned voff[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rl = 4 * lq + r;
+      voff[r] = (unsigned)(((ym_hw ? (rl >> 3) * ym_hw + (rl & 7) : rl) * NS + lr) * 4);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MBLK; ++mb) {
+      if (mb0 + mb >= nmb) continue;  // wave-uniform: past the tile's rows
+      const int mblk = __builtin_amdgcn_readfirstlane(ym_hw ? m0 + (mb0 + mb) * 8 : seg_row_pixel(p, m0, (mb0 + mb) * 16));
+      const rsrc_t dst = make_rsrc(p.out0 + (long)mblk * NS + ncol0, (unsigned)(((long)(p.M - mblk) * NS - ncol0) * 4));
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb) {
+        const float bias = pre ? pre[nb][0] : (p.bias ? p.bias[ncol0 + nb * 16 + lr] : 0.f);
+        const float sc = pre ? pre[nb][1] : (p.scale ? p.scale[ncol0 + nb * 16 + lr] : 1.f);
+        const float sh = pre ? pre[nb][2] : (p.scale ? p.shift[ncol0 + nb * 16 + lr] : 0.f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[mb][nb][r] * iav[mb][r] * iw + bias;
+          v = v * sc + sh;
+          v = v > 0.f ? v : slope * v;
+          if (SIG) v = sigmoid_acc(v);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst, (int)voff[r] + nb * 64, 0, 0);
+          mxb[mb] = max(mxb[mb], absbits(v));
+        }
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int nb = 0; nb < NBLK; ++nb) {
