@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 6
+#define RAC_ABI_VERSION 7
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -67,7 +67,9 @@ typedef struct rac_conv_args {
   const float* a1;    /* second source of the virtual concat, or NULL */
   const float* w;     /* FWD/DGRAD: weights [Cout][k][k][Cin]; WGRAD: dy NHWC [.,Cout] */
   float* out0;        /* FWD: [.,Cout]; DGRAD: [.,Cin or o_split]; WGRAD: dw [Cout][k][k][Cin] */
-  float* out1;        /* DGRAD second destination or NULL */
+  float* out1;        /* DGRAD second destination or NULL.  rac_conv2d_fwd_split: optional [B][H/2][W/2][Cout] -- the 2 x 2
+                         max pool of the activated output, written by the same epilogue (MaxPool2d(2) behind a vgg_layer,
+                         vgg_64.py:104-129); only where rac_conv2d_fwd_split_pool_ok says so */
   const float* bias;  /* [N] added first, or NULL */
   const float* scale; /* [N] v = v*scale + shift (folded eval BatchNorm), or NULL */
   const float* shift;
@@ -152,6 +154,12 @@ int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, int32_t Cin,
  * rows zero-padded to the next multiple of 32; only Cout columns are computed into the output (row stride Cout). */
 int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,
                          int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax, void* stream);
+/* 1 if rac_conv2d_fwd_split with these arguments can also write a->out1, the 2 x 2 max pool of its activated output
+ * (ConvEncoder's `mp` behind the last vgg_layer of c1 / c2 / c3, vgg_64.py:104-129, frozen model): the unrolled 3x3 kernels
+ * on maps larger than a tile, full 128-pixel tiles and column blocks, split_k 1, no statistics, an output below 4 GiB, a
+ * 16-row block and the block under it held by one wave (W = 16, 32, or 2-D tiles).  0 otherwise: call rac_maxpool2_fwd.
+ * Nothing is launched.  The pooled tensor's maximum is bounded by the output's (out_amax): no separate slot. */
+int rac_conv2d_fwd_split_pool_ok(const rac_conv_args* a, int32_t w_cin);
 /* The FROZEN model's ConvLSTM cell in one launch (lstm.py:129-149 without a tape): the gate conv of
  * rac_conv2d_fwd_split with the cell arithmetic in its epilogue,
  *   (i, f, o, g) = conv([a0 | a1]) + bias;  c = sig(f) c_prev + sig(i) tanh(g);  h = sig(o) tanh(c),

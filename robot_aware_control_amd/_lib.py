@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 6  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 7  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -87,6 +87,7 @@ _SIGS = {
     "rac_weight_frag_split_multi": [vp, i32, i64, vp],
     "rac_conv2d_split_supported": [i32, i32, i32, i32, i32, i32],
     "rac_conv2d_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp],
+    "rac_conv2d_fwd_split_pool_ok": [C.POINTER(ConvArgs), i32],
     "rac_convlstm_cell_fwd_split": [C.POINTER(ConvArgs), vp, vp, i64, i32, vp, vp, vp, vp, vp],
     "rac_conv2d_wgrad_split": [C.POINTER(WgradArgs), vp],
     "rac_split_steps": [C.POINTER(vp), C.POINTER(vp), i32, i64, C.POINTER(vp), i32, vp],

@@ -126,6 +126,11 @@ struct Conv16P {
   // (seg_h + 2)(seg_w + 2) staged pixels instead of (rows + 2) W -- 180 instead of 264 on a 64-wide map -- and maps wider
   // than a whole-row tile's halo allows (128x128) get a tile at all.  seg_tx tiles per image row, seg_tpi per image.
   int seg_w, seg_h, seg_tx, seg_tpi;
+  // 2 x 2 max pooling of the activated output in the same epilogue (unrolled 3x3 rows kernels, full tiles only: the
+  // launcher's conditions): pool_out[B][H/2][W/2][n_store]; pool_bpr = 16-row blocks per tile row (1 or 2): the block
+  // under block b is b + pool_bpr, both held by one wave; a lane's four rows are four consecutive pixels of one image row.
+  float* pool_out;
+  int pool_bpr;
 };
 
 // origin of 2-D tile `bx`: image, first row, first column, and the pixel index of (y0, x0)
@@ -197,6 +202,56 @@ __device__ __forceinline__ void conv16_epilogue_body(const Conv16P& p, const f32
     for (int r = 0; r < 4; ++r) {
       const int rl = 4 * lq + r;
       voff[r] = (unsigned)(((ym_hw ? (rl >> 3) * ym_hw + (rl & 7) : rl) * NS + lr) * 4);
+    }
+    if (p.pool_out && !ym_hw) {
+      // with the 2 x 2 max pool: per column block the values of all row blocks first, then every (block, block below) pair
+      // gives the lane two pooled pixels (its four rows are pixels x .. x + 3 of one image row)
+      const int Hp = p.H >> 1, Wp = p.W >> 1;
+      rsrc_t dst[MBLK], pdst[MBLK];
+#pragma unroll
+      for (int mb = 0; mb < MBLK; ++mb) {
+        const int mblk = __builtin_amdgcn_readfirstlane(seg_row_pixel(p, m0, (mb0 + mb) * 16));
+        dst[mb] = make_rsrc(p.out0 + (long)mblk * NS + ncol0, (unsigned)(((long)(p.M - mblk) * NS - ncol0) * 4));
+        const int img = mblk / p.HW, rem = mblk - img * p.HW;
+        const int y = rem / p.W, x0 = rem - y * p.W;
+        const int pf = (img * Hp + (y >> 1)) * Wp + (x0 >> 1);  // (used for the upper block of a pair: y even)
+        pdst[mb] = make_rsrc(p.pool_out + (long)pf * NS + ncol0, (unsigned)(((long)((p.M >> 2) - pf) * NS - ncol0) * 4));
+      }
+      const unsigned pvoff = (unsigned)((2 * lq * NS + lr) * 4);
+#pragma unroll
+      for (int nb = 0; nb < NBLK; ++nb) {
+        const float bias = pre ? pre[nb][0] : (p.bias ? p.bias[ncol0 + nb * 16 + lr] : 0.f);
+        const float sc = pre ? pre[nb][1] : (p.scale ? p.scale[ncol0 + nb * 16 + lr] : 1.f);
+        const float sh = pre ? pre[nb][2] : (p.scale ? p.shift[ncol0 + nb * 16 + lr] : 0.f);
+        float vv[MBLK][4];
+#pragma unroll
+        for (int mb = 0; mb < MBLK; ++mb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[mb][nb][r] * iav[mb][r] * iw + bias;
+            v = v * sc + sh;
+            v = v > 0.f ? v : slope * v;
+            if (SIG) v = sigmoid_acc(v);
+            vv[mb][r] = v;
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), dst[mb], (int)voff[r] + nb * 64, 0, 0);
+            mxb[mb] = max(mxb[mb], absbits(v));
+          }
+#pragma unroll
+        for (int mb = 0; mb < MBLK; ++mb) {
+          // upper blocks of the pairs: tile rows 0, 2, ... = blocks with (mb / bpr) even
+          const bool up = p.pool_bpr == 2 ? ((mb >> 1) & 1) == 0 : (mb & 1) == 0;
+          if (!up) continue;  // (wave-uniform)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {  // as rac_maxpool2_fwd: max(max(top pair), max(bottom pair))
+            const float a = fmaxf(vv[mb][2 * j], vv[mb][2 * j + 1]);
+            const float b = p.pool_bpr == 2 ? fmaxf(vv[(mb + 2) % MBLK][2 * j], vv[(mb + 2) % MBLK][2 * j + 1])
+                                            : fmaxf(vv[(mb + 1) % MBLK][2 * j], vv[(mb + 1) % MBLK][2 * j + 1]);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, fmaxf(a, b)), pdst[mb],
+                                                  (int)pvoff + j * NS * 4 + nb * 64, 0, 0);
+          }
+        }
+      }
+      return;
     }
 #pragma unroll
     for (int mb = 0; mb < MBLK; ++mb) {
@@ -2558,7 +2613,9 @@ extern "C" int rac_conv2d_split_supported(int32_t H, int32_t W, int32_t ksize, i
 
 static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1, int64_t w_part_stride,
                          int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax, const float* lstm_c_prev, float* lstm_h,
-                         float* lstm_c, void* stream) {
+                         float* lstm_c, void* stream, bool pool_query = false) {
+  // pool_query: nothing is launched; the return value says whether this conv can write its own 2 x 2 max-pooled output
+  // (1) or not (0) -- rac_conv2d_fwd_split_pool_ok
   RAC_REQUIRE(a && a->mode == RAC_CONV_FWD, "rac_conv2d_fwd_split: forward mode only");
   RAC_REQUIRE(a->B > 0 && a->H > 0 && a->W > 0 && a->Cin > 0 && a->Cout > 0 && a->a0 && a->w && (a->out0 || lstm_h) && a_amax0 &&
                   w_amax,
@@ -2674,6 +2731,21 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
       // padded rows: W + 2 LDS rows per image row (2-D tile: the halo tile itself), the plane rounded to 256 B
       lds_rows = (size_t)2 * 2 * 4 * (((tile2d ? nrows : (nrows / a->W) * (a->W + 2)) + 15) & ~15) * 16;
     }
+    {
+      // The 2 x 2 max pool in the epilogue (out1): the epilogue's predicate-free path must be the one every wave takes
+      // (full tiles, full column blocks, no statistics, offsets inside 4 GiB), a 16-row block must lie in one image row
+      // with the block under it in the same wave (blocks per tile row 1 or 2, an even number of tile rows per wave), and the
+      // tile's first image row must be even.
+      const int bpr = (tile2d ? 16 : a->W) / 16, mb_wave = width == 2 ? 2 : 4, bnw = width == 2 ? 32 : (width == 1 ? 64 : 128);
+      const bool pool_ok = fast && p.split_k == 1 && !a->stats && !lstm_h && a->H % 2 == 0 && a->W % 16 == 0 &&
+                           (bpr == 1 || bpr == 2) && mb_wave % (2 * bpr) == 0 && (p.tile_m / (16 * bpr)) % 2 == 0 &&
+                           p.M % p.tile_m == 0 && a->Cout % bnw == 0 && (long)p.M * a->Cout * 4 < (1l << 32) && RAC_EPILOGUE_FAST;
+      if (pool_query) return pool_ok ? 1 : 0;
+      if (a->out1) {
+        RAC_REQUIRE(pool_ok, "rac_conv2d_fwd_split: this conv cannot pool in its epilogue (rac_conv2d_fwd_split_pool_ok)");
+        p.pool_out = a->out1, p.pool_bpr = bpr;
+      }
+    }
     // narrow layers (64 / 32 columns), unsplit K, many more tiles than the chip holds: persistent workgroups that walk
     // the tiles and request the next tile's first chunk under the current tile's last one
     static const rows_fn persist_fns[2][3] = {
@@ -2705,6 +2777,8 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     hipLaunchKernelGGL(fn, grid, dim3(256), lds_rows, reinterpret_cast<hipStream_t>(stream), p);
     return check_launch("rac_conv2d_fwd_split(image rows)");
   }
+  if (pool_query) return 0;
+  RAC_REQUIRE(!a->out1, "rac_conv2d_fwd_split: maps that fit a tile do not pool in the epilogue");
   p.tile_m = (128 / p.HW) * p.HW;  // whole images per workgroup
   RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
   dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
@@ -2751,6 +2825,16 @@ extern "C" int rac_conv2d_fwd_split(const rac_conv_args* a, const uint32_t* a_am
                                     int64_t w_part_stride, int32_t w_cin, const uint32_t* w_amax, uint32_t* out_amax,
                                     void* stream) {
   return conv16_launch(a, a_amax0, a_amax1, w_part_stride, w_cin, w_amax, out_amax, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int rac_conv2d_fwd_split_pool_ok(const rac_conv_args* a, int32_t w_cin) {
+  static const uint32_t one = 0x3F800000u;  // (argument checks only: nothing is read or launched)
+  if (!a || a->mode != RAC_CONV_FWD || !a->a0 || !a->w || !a->out0) return 0;
+  const int n_rows = (a->Cout + 31) / 32 * 32;
+  const long taps = (long)a->ksize * a->ksize;
+  const int r = conv16_launch(a, &one, nullptr, (int64_t)n_rows * taps * (w_cin > 0 ? w_cin : a->Cin), w_cin, &one, nullptr,
+                              nullptr, nullptr, nullptr, nullptr, true);
+  return r == 1 ? 1 : 0;
 }
 
 extern "C" int rac_convlstm_cell_fwd_split(const rac_conv_args* a, const uint32_t* a_amax0, const uint32_t* a_amax1,

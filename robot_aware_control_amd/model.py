@@ -102,12 +102,22 @@ class _Encoder(nn.Module):
     def forward(self, x, n_updates=1, groups=1, first_done=False):
         """`first_done`: x is already the output of c1[0] (the frozen model's direct first-layer kernel)."""
         skips = []
+        frozen = not self.training and not torch.is_grad_enabled()
+        pooled = None
         for i, name in enumerate(("c1", "c2", "c3", "c4")):
             if i:
-                x = ops.MaxPool2.apply(x)
-            for j, layer in enumerate(getattr(self, name)):
+                x = pooled if pooled is not None else ops.MaxPool2.apply(x)
+                pooled = None
+            layers = getattr(self, name)
+            for j, layer in enumerate(layers):
                 if first_done and i == 0 and j == 0:
                     continue
+                if frozen and i < 3 and j == len(layers) - 1:
+                    # the frozen model: the block's last layer also writes the pooled map the next block reads
+                    both = ops.vgg_pool_frozen(x, layer.main[0].weight, *layer.folded())
+                    if both is not None:
+                        x, pooled = both
+                        continue
                 x = layer(x, None, n_updates, groups)
             skips.append(x)
         return x, skips

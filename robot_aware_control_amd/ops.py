@@ -732,11 +732,15 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
 
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
                   shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0, a0_up=0,
-                  per_image=False):
+                  per_image=False, pool=None):
+    """`pool`: None, a [B, H/2, W/2, Cout] tensor the same launch fills with the 2 x 2 max pool of its output, or "query"
+    (nothing launched: can this conv pool in its epilogue?  -> bool)."""
     args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
                     a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
-                    out1=None, bias=ptr(bias), scale=ptr(scale), shift=ptr(shift), stats=ptr(stats),
-                    stats_rows=stats_rows, a0_up=a0_up, amax_per_image=1 if per_image else 0)
+                    out1=None if isinstance(pool, str) else ptr(pool), bias=ptr(bias), scale=ptr(scale), shift=ptr(shift),
+                    stats=ptr(stats), stats_rows=stats_rows, a0_up=a0_up, amax_per_image=1 if per_image else 0)
+    if isinstance(pool, str):
+        return bool(_lib.load().rac_conv2d_fwd_split_pool_ok(C.byref(args), w_cin))
     prof = PROFILE
     timed = prof is not None and prof["match"] == (FWD, k, Cin, Cout)
     if timed:
@@ -766,8 +770,12 @@ def per_image_ok(H: int, W: int) -> bool:
 SLAB_STATS = os.environ.get("RAC_SLAB_STATS", "1") == "1"  # split-K combine + BatchNorm statistics in one pass
 
 
+POOL_FUSED = os.environ.get("RAC_POOL_FUSED", "1") == "1"  # frozen encoder: MaxPool2d in the producing conv's epilogue
+_POOL_OK = {}  # (B, H, W, C0, C1, Cout, k, per_image) -> can this conv pool in its epilogue?
+
+
 def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, shift=None, stats=None,
-                       want_slabs=False, groups=1, x0_up=False, per_image=False):
+                       want_slabs=False, groups=1, x0_up=False, per_image=False, pool=False):
     """FWD conv over [x0 | x1] on the fp16 matrix pipe with fp32-level accuracy (see include/rac_hip.h).
     `want_slabs`: raw split-K partial sums (slabs, n_slabs, slab_stride) for the ConvLSTM cell kernel.
     An all-zero x1 (`is_zero`) is skipped: the conv runs over the x0 channels of the same weight parts.
@@ -804,6 +812,21 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
     split = 1 if (fused or per_image) else plan_split_k(M, Cout, k * k * _cdiv(Cin, 32), tile128_only=True)
     # the kernel that writes `out` also leaves its max |v| (per image: maxima) for the next conv
     slot = amax_slot(x0.device, B if per_image else 1)
+    if pool:
+        # (out, MaxPool2d(2)(out)) -- vgg_64.py:104-129 -- the pool written by the conv's own epilogue where the kernel can
+        # (one read of `out` and one launch less), by rac_maxpool2_fwd otherwise: the same bits either way
+        assert split == 1 and stats is None and not x0_up
+        key = (B, H, W, C0, C1, Cout, k, per_image, w_cin)
+        ok = _POOL_OK.get(key)
+        if ok is None:
+            ok = _POOL_OK[key] = POOL_FUSED and _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale,
+                                                               shift=shift, out_amax=slot, pool="query", **kw)
+        pooled = torch.empty((B, H // 2, W // 2, Cout), device=x0.device, dtype=torch.float32)
+        _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, out_amax=slot,
+                      pool=pooled if ok else None, **kw)
+        if not ok:
+            call("rac_maxpool2_fwd", ptr(out), ptr(pooled), B, H, W, Cout, stream_ptr())
+        return tag_amax(out, slot), tag_amax(pooled, slot)  # max |pooled| <= max |out|: the same slot(s) bound both
     if split == 1:
         _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, stats=stats,
                       stats_rows=(M // groups if (groups > 1 and stats is not None) else 0), out_amax=slot, **kw)
@@ -1552,6 +1575,17 @@ class FirstVggLayer(torch.autograd.Function):
 def first_layer_train_ok(img, mask, weight) -> bool:
     return (FIRST_TRAIN_MFMA and FIRST_MFMA and SPLIT_GEMM and not img.requires_grad and first_layer_ok(img, mask, weight)
             and img.shape[0] * (img.shape[-2] // 16) * (img.shape[-1] // 16) > 0)
+
+
+def vgg_pool_frozen(x0, weight, scale, shift):
+    """(y, MaxPool2d(2)(y)) of a FROZEN vgg layer (vgg_64.py:8-18 + the `mp` of ConvEncoder.forward, :104-129; BatchNorm
+    folded): one launch where the conv kernel pools in its epilogue.  None when the layer does not run split-precision."""
+    Cout = weight.shape[0]
+    if not (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT and x0.shape[3] == weight.shape[1] and x0.shape[1] % 2 == 0
+            and x0.shape[2] % 2 == 0 and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, 0)):
+        return None
+    return conv_forward_split(x0, None, weight, None, act=ACT_LEAKY, scale=scale, shift=shift,
+                              per_image=per_image_ok(x0.shape[1], x0.shape[2]), pool=True)
 
 
 class MaxPool2(torch.autograd.Function):

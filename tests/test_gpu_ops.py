@@ -706,6 +706,43 @@ def test_rows_kernel_2d_tiles_are_the_same_bits(dev, B, H, W, C0, C1, Cout, up, 
     assert relerr(from_map(got[0]), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,fused", [
+    (3, 64, 64, 64, 64, True),      # 2-D tiles, 64 columns
+    (600, 64, 64, 64, 64, True),    # the persistent form
+    (2, 64, 64, 128, 128, True),    # 2-D tiles, 128 columns
+    (4, 32, 32, 128, 128, True),    # whole rows, two 16-pixel blocks per image row
+    (4, 32, 32, 64, 32, False),     # 32-column kernel: two row blocks per wave cannot hold both rows of a pair
+    (8, 16, 16, 256, 256, True),    # whole rows, one block per image row, two column tiles
+    (8, 16, 16, 128, 96, False),    # 96 columns do not fill the column blocks: separate pass
+    (3, 8, 8, 256, 512, False),     # a map that fits a tile: separate pass
+])
+def test_conv_pools_in_its_epilogue_with_the_same_bits(dev, B, H, W, Cin, Cout, fused, monkeypatch):
+    """conv_forward_split(pool=True) = (y, MaxPool2d(2)(y)) of a frozen vgg layer (vgg_64.py:8-18, 104-129): where the conv
+    kernel can pool in its epilogue (rac_conv2d_fwd_split_pool_ok) the pooled map comes out of the same launch, elsewhere
+    from rac_maxpool2_fwd -- the same bits either way, y untouched, and the pooled map is tagged with y's per-image maxima."""
+    from robot_aware_control_amd import _lib, ops
+    x = to_map(rnd(71, B, Cin, H, W), dev)
+    wt = cl_weight(rnd(72, Cout, Cin, 3, 3) * 0.05).to(dev)
+    scale, shift = (rnd(73, Cout).abs() + 0.5).to(dev), rnd(74, Cout, scale=0.2).to(dev)
+    launches = []
+    real = _lib.call
+    monkeypatch.setattr(ops, "call", lambda name, *a: (launches.append(name), real(name, *a))[1])
+    ops._POOL_OK.clear()
+    y, yp = ops.conv_forward_split(x, None, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift, per_image=True, pool=True)
+    assert ("rac_maxpool2_fwd" not in launches) == fused, launches
+    y0 = ops.conv_forward_split(x, None, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift, per_image=True)
+    want = ops.MaxPool2.apply(y0)
+    assert torch.equal(y, y0) and torch.equal(yp, want)
+    assert torch.equal(ops.amax_tag(yp), ops.amax_tag(y)) and torch.equal(ops.amax_tag(y), ops.amax_tag(y0))
+    ref = F.max_pool2d(from_map(y0), 2)
+    assert torch.equal(from_map(yp), ref)
+    monkeypatch.setattr(ops, "POOL_FUSED", False)  # the switch: always the separate pass
+    ops._POOL_OK.clear()
+    y2, yp2 = ops.conv_forward_split(x, None, wt, None, act=ops.ACT_LEAKY, scale=scale, shift=shift, per_image=True, pool=True)
+    assert torch.equal(y2, y0) and torch.equal(yp2, want)
+    ops._POOL_OK.clear()
+
+
 @pytest.mark.parametrize("B,Cin,Cout", [(1, 64, 64), (2, 128, 64)])
 def test_rows_kernel_takes_128_wide_maps(dev, B, Cin, Cout):
     """128x128 maps (the 64-channel layers of a 128x128 model, BASELINE configs[4]): no whole-row tile exists (a row's halo
