@@ -678,7 +678,10 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
           const int mb = 4 * h + t;
           if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
 #if !RAC_TILE_READ_ALL  // (reading dead blocks too -- straight-line LDS traffic, exact waits -- measured +0 % on 5x5, +1 % on 3x3)
-          if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;  // the tap leaves the image: no work
+          // the tap leaves the image: no work.  (Dropping the test for the taps of the kernel's centre row, which never leave
+          // -- a compile-time fact in the unrolled instances -- merges such a step's four row blocks into one basic block of 48
+          // MFMAs, and the compiler's schedule of that block is SLOWER: 12.55 -> 13.2 ms on the 5x5 gate GEMM at M = 64 000.)
+          if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;
 #endif
           const int ao = YM ? shift + mb * (16 * T16Y_PITCH) : ((amask[mb] & bit) ? shift + mb * 256 : zr);
 #pragma unroll
