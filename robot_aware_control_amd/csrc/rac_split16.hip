@@ -457,6 +457,9 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOB
 #define RAC_EXP_ROWS_NOB 0
 #endif
+#ifndef RAC_ROWS_GENERIC_SEG
+#define RAC_ROWS_GENERIC_SEG 1
+#endif
 #ifndef RAC_ROWS_REFILL  // the rows kernel's weight sets refilled in place, quarter by quarter (0: one set kept free for the requests)
 #define RAC_ROWS_REFILL 1
 #endif
@@ -1431,12 +1434,16 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
             fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
         }
 #pragma unroll
-        for (int t = 0; t < HB; ++t)
+        for (int t = 0; t < HB; ++t) {
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             if (wm * MB + HB * h + t >= nmb) continue;
             acc[HB * h + t][nb] = mma3(fa[t], fb[nb], acc[HB * h + t][nb]);
           }
+#if RAC_ROWS_GENERIC_SEG
+          __builtin_amdgcn_sched_barrier(0);  // one row block's MFMAs at a time (see the tile kernel's note on block branches)
+#endif
+        }
       }
       if (last_tap && more) {
         store_a(cur ^ 1);
