@@ -822,8 +822,15 @@ def conv_forward_split(x0, x1, weight, bias=None, *, act=ACT_NONE, scale=None, s
             ok = _POOL_OK[key] = POOL_FUSED and _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale,
                                                                shift=shift, out_amax=slot, pool="query", **kw)
         pooled = torch.empty((B, H // 2, W // 2, Cout), device=x0.device, dtype=torch.float32)
-        _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, out_amax=slot,
-                      pool=pooled if ok else None, **kw)
+        try:
+            _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, out_amax=slot,
+                          pool=pooled if ok else None, **kw)
+        except _lib.RacError as e:
+            # the library's tile plan changed under the cached answer (an A/B switch flipped in this process): separate pass
+            if not ok or "cannot pool" not in str(e):
+                raise
+            ok = _POOL_OK[key] = False
+            _split_launch(x0, x1, a0, a1, pw, wslot, out, act=act, bias=bias, scale=scale, shift=shift, out_amax=slot, **kw)
         if not ok:
             call("rac_maxpool2_fwd", ptr(out), ptr(pooled), B, H, W, Cout, stream_ptr())
         return tag_amax(out, slot), tag_amax(pooled, slot)  # max |pooled| <= max |out|: the same slot(s) bound both
