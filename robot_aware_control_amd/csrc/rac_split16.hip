@@ -66,7 +66,7 @@ __device__ __forceinline__ float pow2f(int k) { return __builtin_bit_cast(float,
 #endif
 // timing builds of the persistent rows kernel (tools/build_variant.sh ... -DRAC_EXP_PERSIST=<bits>; results are WRONG):
 // 1 epilogue without its stores, 2 no epilogue, 4 staging with one conversion instead of the split, 8 fragment reads at tap 0
-// only, 16 no weight loads inside the loop, 32 the next tile = this tile (no per-tile index arithmetic, staging loads hit L2)
+// only, 16 no weight loads inside the loop, 32 the next tile = this tile (no per-tile index arithmetic, staging loads hit L2), 64 the arithmetic done but this tile's addresses used
 #ifndef RAC_EXP_PERSIST
 #define RAC_EXP_PERSIST 0
 #endif
@@ -1652,6 +1652,11 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
         nxt_t = cur_t;
       else
         setup(next_bx, nxt_t);
+      if (RAC_EXP_PERSIST & 64) {  // the arithmetic is done, the addresses are this tile's again (loads hit L2)
+        const int keep = nxt_t.m0 ^ nxt_t.pix[0];
+        nxt_t = cur_t;
+        if (keep == 0x7fffffff) nxt_t.ka += 1;  // (keeps setup() alive)
+      }
     }
     f32x4 acc[MB][NB];
 #pragma unroll
