@@ -457,6 +457,12 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_EXP_ROWS_NOB
 #define RAC_EXP_ROWS_NOB 0
 #endif
+#ifndef RAC_TILE_A_BEHIND  // tile kernel's unrolled instances: activations requested behind a chunk's first weight request
+#define RAC_TILE_A_BEHIND 1
+#endif
+#ifndef RAC_A_REQUEST_TAP  // the tap of a chunk behind whose weight request the next chunk's activations are requested
+#define RAC_A_REQUEST_TAP 0
+#endif
 #ifndef RAC_ROWS_GENERIC_SEG
 #define RAC_ROWS_GENERIC_SEG 1
 #endif
@@ -653,7 +659,9 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     auto request_a = [&](int c) {
       if (!(RAC_EXP_TILE & 1) && c * p.taps < kc_end) issue_a((RAC_EXP_TILE & 2) ? kc_begin / p.taps : c);
     };
-    request_a(cc + 1);
+    if (!(KU != 0 && RAC_TILE_A_BEHIND)) request_a(cc + 1);
+    // (unrolled instances: the request sits behind the weight request of a chunk's FIRST step instead -- loads return in order,
+    // and the first weight set that has to wait for the activations is then the one read three steps from the request, not two)
 
     // (Refilling the weight sets in place by 16-column quarters, as conv16_rows_kernel does -- all three sets in flight,
     // 2 3/4 steps of cover -- needs the MFMAs column-block-major with the requests pinned between the blocks: measured
@@ -709,6 +717,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #pragma unroll
         for (int t9 = 0; t9 < 9; ++t9) {
           if (t9 == 0) load_b(b2, cc * 9 + 2);
+          if (RAC_TILE_A_BEHIND && t9 == 0 && more) request_a(cc + 1);
           if (t9 % 3 == 1) load_b(b0, cc * 9 + t9 + 2);
           if (t9 % 3 == 2) load_b(b1, cc * 9 + t9 + 2);
           if (t9 % 3 == 0 && t9) load_b(b2, cc * 9 + t9 + 2);
@@ -718,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
           store_a(cur ^ 1);
           __syncthreads();
           cur ^= 1;
-          request_a(cc + 2);
+          if (!RAC_TILE_A_BEHIND) request_a(cc + 2);
         }
       }
     } else if constexpr (KU == 5) {
@@ -741,6 +750,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         };
         for (int g8 = 0; g8 < 8; ++g8) {
           load_b(s2, kc0 + t + 2);
+          if (RAC_TILE_A_BEHIND && g8 == 0 && more) request_a(c + 1);
           stepk(s0, t, y, x);
           adv();
           load_b(s0, kc0 + t + 2);
@@ -756,7 +766,7 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
           store_a(cur ^ 1);
           __syncthreads();
           cur ^= 1;
-          request_a(c + 2);
+          if (!RAC_TILE_A_BEHIND) request_a(c + 2);
         }
       };
       while (cc < c_end) {
@@ -1665,10 +1675,6 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
       for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int cc = 0; cc < c_end; ++cc) {
       const bool more = cc + 1 < c_end;
-      if (more)
-        issue_a(cc + 1, cur_t);
-      else if (has_next)
-        issue_a(0, nxt_t);
       const int kc0 = cc * 9;
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
@@ -1676,6 +1682,15 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
         int knext = kc0 + tap + 2;
         knext = knext >= kc_end ? knext - kc_end : knext;
         if (!(RAC_EXP_PERSIST & 16)) load_b(bs[(tap + 2) % 3], knext);
+        if (tap == RAC_A_REQUEST_TAP) {
+          // the next chunk's activations are requested BEHIND this tap's weight request: loads return in order, so the first
+          // weight set that has to wait for them is the one requested at the next tap and read three taps from here (requested
+          // in front of this tap's, it was the one read two taps from here)
+          if (more)
+            issue_a(cc + 1, cur_t);
+          else if (has_next)
+            issue_a(0, nxt_t);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f16x8 fb[NB][2];
 #pragma unroll
