@@ -489,7 +489,24 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   const int wm = wid / WN, wn = wid % WN;
   const int lr = lane & 15, lq = lane >> 4;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.xcd_group) {
+  if (p.xcd_group == 3) {
+    // many M-tiles, K unsplit (the planner's shapes): an XCD owns the column tiles x, x + 8, ... and walks the M-tiles with
+    // the column tile as the FAST index -- the workgroups that read one activation tile run back to back on one L2 (one HBM
+    // fetch per line instead of one per column tile of the XCD), the XCD's weight slabs stream side by side
+    const int mt = gridDim.x, nt = gridDim.y, npx = nt >> 3;
+    const int lin = bx + mt * by;
+    const int xcd = lin & 7, s = lin >> 3;
+    bx = s / npx;
+    by = xcd + 8 * (s - bx * npx);
+  } else if (p.xcd_group == 4) {
+    // the same idea for layers with FEW column tiles (2 or 4; M-tiles a multiple of 8): an XCD owns the M-tiles x, x + 8, ...
+    // and runs each one's column tiles back to back
+    const int mt = gridDim.x, nt = gridDim.y;
+    const int lin = bx + mt * by;
+    const int xcd = lin & 7, s = lin >> 3;
+    by = s % nt;
+    bx = (s / nt) * 8 + xcd;
+  } else if (p.xcd_group) {
     const int mt = gridDim.x, nt = gridDim.y;
     const int lin = bx + mt * (by + nt * bz);
     const int xcd = lin & 7, s = lin >> 3;
@@ -1138,7 +1155,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 15, lq = lane >> 4;
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if (p.xcd_group) {
+  if (p.xcd_group == 1) {
     const int mt = gridDim.x, nt = gridDim.y;
     const int lin = bx + mt * (by + nt * bz);
     const int xcd = lin & 7, s = lin >> 3;
@@ -1146,6 +1163,21 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     bx = s % mt;
     by = grp % nt;
     bz = grp / nt;
+  }
+  if (p.xcd_group == 2) {
+    // two column tiles, K unsplit: the two workgroups of an M-tile read the same activations.  Hardware order sends
+    // consecutive workgroup ids to consecutive XCDs (8 L2s) and, with the column tile as the slow grid index, runs the two half
+    // a launch apart: every activation line comes from HBM twice.  Here ids 16 q + 8 n + x become (M-tile 8 q + x, column tile
+    // n): the pair runs on ONE XCD, 8 ids apart -- one HBM fetch per line, the second reader finds it in (or on its way to) L2.
+    const int mt = gridDim.x, lin = bx + mt * by;
+    if (lin < ((2 * mt) & ~15)) {
+      bx = ((lin >> 4) << 3) | (lin & 7);
+      by = (lin >> 3) & 1;
+    } else {  // (the last < 16 ids: M-tiles 8 q' .. mt - 1 in the natural order)
+      const int r = lin - ((2 * mt) & ~15), base = ((2 * mt) & ~15) >> 1;
+      bx = base + (r >> 1);
+      by = r & 1;
+    }
   }
   const int wn = wid % WN, wm = wid / WN;
   const int TM = p.tile_m;
@@ -2751,6 +2783,8 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     const int width = p.N <= 32 ? 2 : (p.N <= 64 ? 1 : 0);
     dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, width == 2 ? 32 : (width == 1 ? 64 : 128)), p.split_k);
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+    static const char* nopair = getenv("RAC_ROWS_PAIR_XCD");  // (=0: hardware order for the two-column-tile layers)
+    if (!p.xcd_group && grid.y == 2 && grid.z == 1 && grid.x >= 64 && !(nopair && atoi(nopair) == 0)) p.xcd_group = 2;
     static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
     rows_fn fn = fns[width][nv - 2];
     const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] &&
@@ -2813,6 +2847,14 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   RAC_REQUIRE(p.stats_rows % p.tile_m == 0, "rac_conv2d_fwd_split: stats_rows must be a multiple of the tile rows");
   dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, SBN), p.split_k);
   p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
+  // many M-tiles, K unsplit: the workgroups that share an activation tile run back to back on one XCD (RAC_TILE_PAIR_XCD=0:
+  // the weight-slab grouping above / hardware order)
+  static const char* pairn = getenv("RAC_TILE_PAIR_XCD");
+  const bool pair_ok = want_xcd && grid.z == 1 && grid.x >= 64 && !(pairn && atoi(pairn) == 0);
+  if (pair_ok && p.xcd_group && grid.y % 8 == 0 && grid.y > 8)
+    p.xcd_group = 3;
+  else if (pair_ok && !p.xcd_group && (grid.y == 2 || grid.y == 4) && grid.x % 8 == 0)
+    p.xcd_group = 4;
   size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
   // waves 2 x 2 (template argument 2); the 1 x 4 arrangement of the same kernel measured 10 % slower
   static const char* noym = getenv("RAC_TILE_YMAJOR");
