@@ -1164,6 +1164,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     by = grp % nt;
     bz = grp / nt;
   }
+  if (p.xcd_group == 6) {
+    // one column tile, K unsplit: consecutive tiles share halo rows; an XCD takes runs of 8 consecutive tiles (ids 64 q + 8 j
+    // + x -> tile 64 q + 8 x + j), so a halo line's second reader finds it in its own L2
+    const int mt = gridDim.x;
+    if (bx < (mt & ~63)) bx = (bx & ~63) | ((bx & 7) << 3) | ((bx >> 3) & 7);
+  }
   if (p.xcd_group == 2) {
     // two column tiles, K unsplit: the two workgroups of an M-tile read the same activations.  Hardware order sends
     // consecutive workgroup ids to consecutive XCDs (8 L2s) and, with the column tile as the slow grid index, runs the two half
@@ -1661,6 +1667,13 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_persist_kernel(Conv16P p) 
   const int c_end = kc_end / 9;
   TileState cur_t, nxt_t;
   int bx = blockIdx.x;
+  if (p.xcd_group == 5) {
+    // neighbouring tiles share their halo pixels (180 staged per 128): workgroup ids go to the XCDs round robin, so with tile =
+    // id the two readers of a halo pixel sit on different L2s.  Here an XCD's gridDim.x / 8 workgroups take CONSECUTIVE
+    // tiles (whole images' worth): a halo line is fetched from HBM once, its second reader finds it in L2.
+    const int per = gridDim.x >> 3;
+    bx = (bx & 7) * per + (bx >> 3);
+  }
   if (bx >= n_tiles) return;
   setup(bx, cur_t);
   u32x4 bs[3][4 * NT];
@@ -2785,6 +2798,9 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
     static const char* nopair = getenv("RAC_ROWS_PAIR_XCD");  // (=0: hardware order for the two-column-tile layers)
     if (!p.xcd_group && grid.y == 2 && grid.z == 1 && grid.x >= 64 && !(nopair && atoi(nopair) == 0)) p.xcd_group = 2;
+    static const char* nohalo1 = getenv("RAC_ROWS_HALO_XCD");  // (=0: hardware order for the one-column-tile layers)
+    if (want_xcd && !p.xcd_group && grid.y == 1 && grid.z == 1 && grid.x >= 128 && !(nohalo1 && atoi(nohalo1) == 0))
+      p.xcd_group = 6;
     static const char* nofast = getenv("RAC_ROWS_GENERIC");  // A/B switch: always the generic loop
     rows_fn fn = fns[width][nv - 2];
     const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] &&
@@ -2833,7 +2849,8 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
         }
         persist_attr = true;
       }
-      p.xcd_group = 0;
+      static const char* nohalo = getenv("RAC_PERSIST_HALO_XCD");  // (=0: tile = workgroup id)
+      p.xcd_group = (want_xcd && persist_wgs % 8 == 0 && !(nohalo && atoi(nohalo) == 0)) ? 5 : 0;
       hipLaunchKernelGGL(persist_fns[width - 1][nv - 2], dim3(persist_wgs, grid.y, 1), dim3(256), lds_rows,
                          reinterpret_cast<hipStream_t>(stream), p);
       return check_launch("rac_conv2d_fwd_split(image rows, persistent)");
