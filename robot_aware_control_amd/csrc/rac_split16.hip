@@ -1175,11 +1175,19 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
     // consecutive workgroup ids to consecutive XCDs (8 L2s) and, with the column tile as the slow grid index, runs the two half
     // a launch apart: every activation line comes from HBM twice.  Here ids 16 q + 8 n + x become (M-tile 8 q + x, column tile
     // n): the pair runs on ONE XCD, 8 ids apart -- one HBM fetch per line, the second reader finds it in (or on its way to) L2.
+    // (... and, as in mode 6, an XCD takes RUNS of 8 consecutive M-tiles -- ids 128 q + 16 j + 8 n + x -> M-tile
+    // 64 q + 8 x + j -- so that the halo rows two neighbouring tiles share come from one L2 as well)
     const int mt = gridDim.x, lin = bx + mt * by;
-    if (lin < ((2 * mt) & ~15)) {
-      bx = ((lin >> 4) << 3) | (lin & 7);
-      by = (lin >> 3) & 1;
-    } else {  // (the last < 16 ids: M-tiles 8 q' .. mt - 1 in the natural order)
+    const int big = (2 * mt) & ~127;
+    if (lin < big) {
+      const int s = lin >> 3;
+      bx = ((s >> 4) << 6) | ((lin & 7) << 3) | ((s >> 1) & 7);
+      by = s & 1;
+    } else if (lin < ((2 * mt) & ~15)) {
+      const int l2 = lin - big;
+      bx = (big >> 1) + (((l2 >> 4) << 3) | (l2 & 7));
+      by = (l2 >> 3) & 1;
+    } else {  // (the last < 16 ids: the remaining M-tiles in the natural order)
       const int r = lin - ((2 * mt) & ~15), base = ((2 * mt) & ~15) >> 1;
       bx = base + (r >> 1);
       by = r & 1;
