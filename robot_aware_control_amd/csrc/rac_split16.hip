@@ -498,14 +498,6 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     const int xcd = lin & 7, s = lin >> 3;
     bx = s / npx;
     by = xcd + 8 * (s - bx * npx);
-  } else if (p.xcd_group == 4) {
-    // the same idea for layers with FEW column tiles (2 or 4; M-tiles a multiple of 8): an XCD owns the M-tiles x, x + 8, ...
-    // and runs each one's column tiles back to back
-    const int mt = gridDim.x, nt = gridDim.y;
-    const int lin = bx + mt * by;
-    const int xcd = lin & 7, s = lin >> 3;
-    by = s % nt;
-    bx = (s / nt) * 8 + xcd;
   } else if (p.xcd_group) {
     const int mt = gridDim.x, nt = gridDim.y;
     const int lin = bx + mt * (by + nt * bz);
@@ -2876,10 +2868,10 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
   // the weight-slab grouping above / hardware order)
   static const char* pairn = getenv("RAC_TILE_PAIR_XCD");
   const bool pair_ok = want_xcd && grid.z == 1 && grid.x >= 64 && !(pairn && atoi(pairn) == 0);
-  if (pair_ok && p.xcd_group && grid.y % 8 == 0 && grid.y > 8)
-    p.xcd_group = 3;
-  else if (pair_ok && !p.xcd_group && (grid.y == 2 || grid.y == 4) && grid.x % 8 == 0)
-    p.xcd_group = 4;
+  if (pair_ok && p.xcd_group && grid.y % 8 == 0 && grid.y > 8) p.xcd_group = 3;
+  // (Layers with 2 or 4 column tiles keep the hardware order: running an M-tile's column tiles back to back on one XCD
+  // puts all their weight slabs -- 4 x 2.4 MB for the planner's 8x8 vgg layers -- through one 4 MB L2 at once: measured
+  // 0.402 -> 0.433 ms on 256 -> 512.)
   size_t lds_tile = 2 * T16_ABUF;  // 36,864 B
   // waves 2 x 2 (template argument 2); the 1 x 4 arrangement of the same kernel measured 10 % slower
   static const char* noym = getenv("RAC_TILE_YMAJOR");
