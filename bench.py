@@ -1,6 +1,7 @@
 """bench.py -- SVG train frames/sec + CEM candidate-rollouts/sec on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W      (N > 1: starts its own ranks as a child torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -22,12 +23,46 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _launch_ranks_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: this process is not a rank.  It starts
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same arguments>` as a CHILD process (never
+    an exec), lets the child's rank 0 print the one JSON line on the shared stdout, and exits with the child's return code.
+    Runs before torch or the HIP library is imported: nothing in this process ever touches the GPU."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:]):
+        if a == "--gpus" and i + 2 < len(sys.argv):
+            n = int(sys.argv[i + 2])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks as a child torch.distributed.run", file=sys.stderr,
+          flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+if __name__ == "__main__":
+    _launch_ranks_if_needed()
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 from robot_aware_control_amd import ops, synthetic as syn  # noqa: E402
 from robot_aware_control_amd.cem import CEMPolicy  # noqa: E402
@@ -507,6 +542,8 @@ def main():
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + Adam on 1/N slices + parameter all-gather (optim.ShardedAdam) instead of "
                          "all-reduce + the fused Adam pass on every rank (not the default: unmeasured on multi-GPU hardware)")
+    ap.add_argument("--no-ddp-modes", action="store_true",
+                    help="N > 1: time only the chosen gradient-exchange mode (default: both, reported under `ddp_modes`)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[4] per-GPU side line (`side.cfg5`)")
     ap.add_argument("--side-steps", type=int, default=5, help="timed steps of the configs[4] per-GPU side line")
     ap.add_argument("--group-norm", action="store_true",
@@ -518,7 +555,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     # (RAC_DIST_FORCE=1: a one-rank process group -- every collective of the path runs through RCCL on a one-GPU box)
     distributed = world > 1 or os.environ.get("RAC_DIST_FORCE", "0") == "1"
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} in the environment (run `python bench.py "
+                         f"--gpus {args.gpus}` with no WORLD_SIZE set and it starts its own ranks, or launch it with "
+                         f"torch.distributed.run --nproc-per-node {args.gpus})")
     backend = os.environ.get("RAC_DIST_BACKEND", "nccl")  # "gloo" + RAC_BENCH_ONE_GPU=1: rehearse N ranks on one GPU
     if os.environ.get("RAC_BENCH_ONE_GPU") == "1":
         local = 0
@@ -540,9 +580,28 @@ def main():
            "vs_baseline": None, "data": "synthetic",
            "dtype": "fp32 (conv operands as two fp16 parts = 22 significant bits, fp32 accumulate; see fp32_exact)"}
     train = cem = None
+    ddp_modes = None
     if args.workload in ("both", "train"):
         train = bench_train(args, dev, rank, world, distributed)
         torch.cuda.empty_cache()
+        if distributed and not args.no_ddp_modes:
+            # both gradient-exchange designs on the same ranks, same workload: all-reduce + the full fused Adam on every
+            # rank, and reduce-scatter + Adam on 1/N slices + parameter all-gather.  The headline is the mode
+            # the flags chose (all-reduce unless --shard-optimizer); a failure of the other mode is recorded, not fatal.
+            def mode_line(t):
+                ph = t["phases"] or {}
+                return {"ms_per_step": t["ms_per_step"], "frames_per_s": t["frames_per_s"],
+                        "allreduce_exposed": ph.get("allreduce_exposed"), "adam": ph.get("adam"),
+                        "rank_ms_per_step": t["rank_ms_per_step"]}
+            this, other = ("sharded", "allreduce") if args.shard_optimizer else ("allreduce", "sharded")
+            ddp_modes = {this: mode_line(train), "headline": this}
+            oa = argparse.Namespace(**vars(args))
+            oa.shard_optimizer = not args.shard_optimizer
+            try:
+                ddp_modes[other] = mode_line(bench_train(oa, dev, rank, world, distributed))
+            except Exception as e:  # noqa: BLE001  (every rank takes the same branch: the failure is deterministic)
+                ddp_modes[other] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     cem_ra = None
     if args.workload in ("both", "cem"):
         cem = bench_cem(args, dev, rank, world, distributed)
@@ -600,6 +659,11 @@ def main():
         out["time_breakdown_ms"] = train["phases"]
         if distributed:
             out["ranks"] = {"train_ms_per_step": train["rank_ms_per_step"]}
+        if ddp_modes is not None:
+            out["ddp_modes"] = ddp_modes
+        # the SCALE record's per-N fields: the driver computes efficiency from the per-N values itself
+        out["per_gpu_value"] = train["frames_per_s"] / world
+        out["efficiency_vs_n1"] = None
     if cem is not None:
         k = cem["kernel"]
         if k is None:
@@ -618,7 +682,8 @@ def main():
                               "shared_start_frame": not args.no_cem_shared_start},
                    "achieved_tflops_per_gpu": cem["tflops_per_gpu"],
                    "frac_of_split_peak": cem["tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
-                   "gate_gemm": gate, "get_action": cem["get_action"]}
+                   "gate_gemm": gate, "get_action": cem["get_action"],
+                   "per_gpu_value": cem["rollouts_per_s"] / world, "efficiency_vs_n1": None}
         if distributed:
             cem_obj["ranks"] = {"s_per_iteration": cem["rank_s_per_iter"], "cost_allgather_ms": cem["cost_allgather_ms"]}
         if train is None:

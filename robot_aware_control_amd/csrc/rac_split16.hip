@@ -2797,7 +2797,7 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     dim3 grid(cdiv(p.M, p.tile_m), cdiv(p.N, width == 2 ? 32 : (width == 1 ? 64 : 128)), p.split_k);
     p.xcd_group = want_xcd && grid.x > 1 && (grid.y * grid.z) % 8 == 0;
     static const char* nopair = getenv("RAC_ROWS_PAIR_XCD");  // (=0: hardware order for the two-column-tile layers)
-    if (!p.xcd_group && grid.y == 2 && grid.z == 1 && grid.x >= 64 && !(nopair && atoi(nopair) == 0)) p.xcd_group = 2;
+    if (want_xcd && !p.xcd_group && grid.y == 2 && grid.z == 1 && grid.x >= 64 && !(nopair && atoi(nopair) == 0)) p.xcd_group = 2;
     static const char* nohalo1 = getenv("RAC_ROWS_HALO_XCD");  // (=0: hardware order for the one-column-tile layers)
     if (want_xcd && !p.xcd_group && grid.y == 1 && grid.z == 1 && grid.x >= 128 && !(nohalo1 && atoi(nohalo1) == 0))
       p.xcd_group = 6;

@@ -74,7 +74,9 @@ def shard_plan(total: int, world: int, bucket_elems: int):
     forward pass first uses the weights), every size a multiple of 4 * world so that the `world` slices of a bucket are
     equal and 16-byte aligned.  `total` must itself be such a multiple (SVGConvModel pads its flat buffers to 1024)."""
     q = 4 * world
-    assert total % q == 0, (total, world)
+    if total % q:
+        raise ValueError("sharded optimiser step: %d flat elements do not cut into %d equal 16-byte-aligned slices "
+                         "(the flat buffers are padded to 1024 elements: the world size must divide 256)" % (total, world))
     step = max(q, bucket_elems // q * q)
     return [(s, min(step, total - s)) for s in range(0, total, step)]
 
@@ -96,8 +98,14 @@ class ShardedAdam(FusedAdam):
     absmax + one fragment-split launch over all weights) -- the fused Adam + parts pass needs the whole updated weight.
     Same arithmetic per element as FusedAdam (`rac_adam_step` on slices), so a one-rank group reproduces it bit for bit."""
 
+    @staticmethod
+    def supports(model, world: int) -> bool:
+        return model.flat_parameters()[0].numel() % (4 * world) == 0
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, bucket_mb: int = 64):
         super().__init__(model, lr=lr, betas=betas, eps=eps)
+        if dist.is_available() and dist.is_initialized():
+            shard_plan(model.flat_parameters()[0].numel(), dist.get_world_size(), 1)  # a clear error now, not in step 1
         self.bucket_elems = max(1, int(bucket_mb)) * (1 << 20) // 4
         self._pending = []   # async all-gather works of the last step's parameters
         self._adam = None    # tests on the CPU inject a torch Adam here; the product path is the HIP kernel

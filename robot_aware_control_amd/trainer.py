@@ -164,7 +164,14 @@ class PredictionTrainer(object):
             dist.broadcast(self.model.flat_parameters()[0], src=0)
         if cf.optimizer != "adam":
             raise ValueError("Unknown optimizer on the HIP path: %s" % cf.optimizer)
-        if getattr(cf, "ddp_shard_optimizer", False) and _dist_on():
+        shard = getattr(cf, "ddp_shard_optimizer", False) and _dist_on()
+        if shard and not ShardedAdam.supports(self.model, dist.get_world_size()):
+            # equal 16-byte-aligned slices need the flat buffers (padded to 1024 elements) to divide by 4 * world
+            import warnings
+            warnings.warn("--ddp_shard_optimizer needs a world size that divides 256 (got %d): "
+                          "using all-reduce + the full Adam step instead" % dist.get_world_size())
+            shard = False
+        if shard:
             self.optimizer = ShardedAdam(self.model, lr=cf.lr, betas=(cf.beta1, 0.999),
                                          bucket_mb=getattr(cf, "ddp_bucket_mb", 64))
         else:
@@ -670,14 +677,21 @@ class PredictionTrainer(object):
         return D.get_batch(train_loader, self._device), test_loader
 
     def _save_checkpoint(self):
-        """trainer.py:829-837."""
+        """trainer.py:829-837.  Rank 0 writes the file; with the sharded optimiser EVERY rank first joins the collectives
+        that assemble the full Adam moments (ShardedAdam.state_dict: all-gathers) and waits for the parameter all-gather of
+        the last step, so that the parameters rank 0 clones are the updated ones."""
+        opt_sd = None
+        if isinstance(self.optimizer, ShardedAdam):
+            opt_sd = self.optimizer.state_dict()  # collective: before the rank check
         if _dist_on() and dist.get_rank() != 0:
             return
         os.makedirs(self._config.log_dir, exist_ok=True)
         path = os.path.join(self._config.log_dir, f"ckpt_{self._step}.pt")
         sd = {k: v.detach().clone().contiguous() if v.dim() != 4 else v.detach().clone()
               for k, v in self.model.state_dict().items()}
-        torch.save({"model": sd, "optimizer": self.optimizer.state_dict(), "step": self._step}, path)
+        if opt_sd is None:
+            opt_sd = self.optimizer.state_dict()
+        torch.save({"model": sd, "optimizer": opt_sd, "step": self._step}, path)
         return path
 
     def _load_checkpoint(self, ckpt_path=None):

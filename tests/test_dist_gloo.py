@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -215,3 +216,78 @@ def test_sharded_optimizer_equals_allreduce_adam_world2():
         assert p.exitcode == 0
     assert all(r[1] for r in res), [r[:2] for r in res]
     assert res[0][2] == res[1][2]
+
+
+def _ckpt_worker(rank, world, port, q, log_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import argparse
+
+    from robot_aware_control_amd.optim import ShardedAdam
+    from robot_aware_control_amd.trainer import PredictionTrainer, ShardReducer
+    total, sizes = 4096, [700, 1400, 37, 1000]
+
+    def trainer():  # PredictionTrainer's checkpoint methods over the flat-buffer contract (its constructor needs the GPU)
+        tr = PredictionTrainer.__new__(PredictionTrainer)
+        tr._config = argparse.Namespace(log_dir=log_dir, experiment="train_robonet")
+        tr._device, tr._step = torch.device("cpu"), 0
+        tr.model = _FlatModel(sizes, total)
+        tr.optimizer = ShardedAdam(tr.model, lr=1e-2, betas=(0.9, 0.999))
+        tr.optimizer.bucket_elems, tr.optimizer._adam = 1024, _torch_adam
+        return tr
+
+    tr = trainer()
+    torch.manual_seed(0)
+    tr.model._flat.copy_(torch.randn(total))
+    grads = torch.randn(2, world, total)
+    for t in range(2):
+        tr.optimizer.wait_params()
+        tr.model._grad.copy_(grads[t, rank])
+        buckets, w, r = tr.optimizer.plan()
+        red = ShardReducer(tr.model._grad, buckets, w, r)
+        red.finish()
+        tr.optimizer.step()
+        tr._step += 1
+    # the parameter all-gather of the last step is still pending here: the save must wait for it on every rank and
+    # every rank must join the moment all-gathers, or rank 0 hangs in them (the path `train()` takes)
+    path = tr._save_checkpoint()
+    dist.barrier()
+    ok = (path is not None) == (rank == 0) and os.path.exists(os.path.join(log_dir, "ckpt_2.pt"))
+    tr2 = trainer()
+    step = tr2._load_checkpoint(None)
+    ok = ok and step == 2 and tr2.optimizer._steps == 2
+    inside = torch.zeros(total, dtype=torch.bool)  # (alignment gaps between parameters are not part of a checkpoint)
+    for p in tr.model.parameters():
+        inside[p._rac_off:p._rac_off + p.numel()] = True
+    buckets, w, r = tr.optimizer.plan()
+    own = torch.cat([inside[s + r * (n // w):s + (r + 1) * (n // w)] for s, n in buckets])
+    ok = ok and torch.equal(tr2.model._flat[inside], tr.model._flat[inside])
+    ok = ok and torch.equal(tr2.optimizer._ms[own], tr.optimizer._ms[own])
+    ok = ok and torch.equal(tr2.optimizer._vs[own], tr.optimizer._vs[own])
+    q.put((rank, bool(ok), tr.model._flat.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_checkpoint_through_the_trainer_world2(tmp_path):
+    """PredictionTrainer._save_checkpoint / _load_checkpoint with the sharded optimiser: every rank joins the collectives
+    that assemble the Adam moments (rank 0 alone would hang in them), rank 0 writes, every rank resumes with its slices."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), [r[:2] for r in res]
+    assert res[0][2] == res[1][2]
+
+
+def test_shard_plan_rejects_world_sizes_that_do_not_divide_the_buffers():
+    from robot_aware_control_amd.optim import shard_plan
+    with pytest.raises(ValueError, match="world size must divide 256"):
+        shard_plan(4096, 3, 1024)
+    assert sum(n for _, n in shard_plan(4096, 8, 1000)) == 4096

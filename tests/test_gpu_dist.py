@@ -187,10 +187,10 @@ def test_ranks_sharing_one_gpu(world):
 
 
 def test_bench_two_ranks_rehearsal():
-    """`bench.py --gpus 2` end to end, launched the way the driver launches it (torch.distributed.run, one process per
-    rank), before an 8-GPU node ever runs it: both ranks share this box's one MI355X and gloo stands in for RCCL
-    (RAC_BENCH_ONE_GPU / RAC_DIST_BACKEND, the script's own rehearsal switches).  A fresh child process tree: nothing
-    that has touched the GPU re-launches itself."""
+    """Plain `python bench.py --gpus 2` end to end (no WORLD_SIZE in the environment: the script starts its own ranks as a
+    child torch.distributed.run before it touches the GPU -- the same launch the driver's explicit torchrun command ends
+    in), before an 8-GPU node ever runs it: both ranks share this box's one MI355X and gloo stands in for RCCL
+    (RAC_BENCH_ONE_GPU / RAC_DIST_BACKEND, the script's own rehearsal switches).  Both gradient-exchange modes are timed."""
     import json
     import subprocess
     import sys
@@ -200,8 +200,7 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, RAC_DIST_BACKEND="gloo", RAC_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--cem-candidates", "64", "--cem-batch", "64", "--cem-iters", "1", "--cem-opt-iter", "2",
            "--exact-steps", "2", "--side-steps", "1"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
@@ -213,6 +212,11 @@ def test_bench_two_ranks_rehearsal():
     assert out["config"]["parallelism"] == "ddp2" and out["config"]["global_batch"] == 32
     assert len(out["ranks"]["train_ms_per_step"]) == 2 and all(v > 0 for v in out["ranks"]["train_ms_per_step"])
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and "allreduce_exposed" in out["time_breakdown_ms"]
+    assert abs(out["per_gpu_value"] * 2 - out["value"]) < 1e-6 * out["value"] and out["efficiency_vs_n1"] is None
+    modes = out["ddp_modes"]
+    assert modes["headline"] == "allreduce" and modes["allreduce"]["ms_per_step"] == out["ms_per_step"]
+    assert modes["sharded"].get("ms_per_step", 0) > 0, modes["sharded"]
+    assert modes["sharded"]["allreduce_exposed"] is not None and len(modes["sharded"]["rank_ms_per_step"]) == 2
     cem = out["cem"]
     assert cem["config"]["parallelism"] == "candidate-shard2" and cem["config"]["candidates"] == 128
     assert cem["ranks"]["cost_allgather_ms"] is not None and len(cem["ranks"]["s_per_iteration"]) == 2
