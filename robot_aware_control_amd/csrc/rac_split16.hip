@@ -448,6 +448,12 @@ __device__ __forceinline__ void conv16_lstm_epilogue(const Conv16P& p, const f32
 #ifndef RAC_WGRAD_ROLL  // weight-gradient kernel: input fragments rolled through the taps in halves (0: read per tap, then wait)
 #define RAC_WGRAD_ROLL 1
 #endif
+#ifndef RAC_WGRAD_LATE_BLOCKS  // 5x5 128-co weight gradient on operand parts: MFMA blocks in front of the last one that take store pieces
+#define RAC_WGRAD_LATE_BLOCKS 2
+#endif
+#ifndef RAC_EXP_WGRAD  // timing builds of the weight-gradient kernel (wrong results): 1 = no barrier inside the loop, 2 = no global loads inside the loop, 4 = no LDS stores inside the loop
+#define RAC_EXP_WGRAD 0
+#endif
 #ifndef RAC_EXP_TILE  // timing builds of the tile kernel (wrong results): 1 = activations requested for the first chunk only, 2 = every chunk requests the FIRST chunk's addresses (L2 hits)
 #define RAC_EXP_TILE 0
 #endif
@@ -2052,10 +2058,39 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* lds, int addr) {
 
 // WMW = waves along the output channels: 2 -> workgroup 128 co x 64 ci, waves 64 co x 32 ci; 1 -> 64 co x 64 ci, waves
 // 64 co x 16 ci (64-channel layers: no all-zero half tile; its dy tile is staged by the first two waves only).
-template <int KS, int WMW = 2>
+// PRE: the operand pointers are fp16 part pairs [2][elements] (rac_split_steps), already scaled: staging is a copy.
+//
+// Round 5: the column step is straight-line code.  (Round 4's SQ counters: 0.9-1.3 other vector instructions per MFMA and
+// the matrix pipe 43-48 % busy; its ISA re-derived every step's addresses from the cursors -- a scalar and a vector
+// division, 64-bit multiplies, a descriptor from the pointer table with its s_load + wait -- branched on the run-time
+// `presplit` flag around every load and store, and added a run-time slot offset to every fragment address.)  Now:
+//   * the step loop is unrolled over the NR ring phases (NR = 2 PAD + 2 is even, so the dy buffer is a phase constant
+//     too): every LDS address of a step is a lane constant plus an instruction immediate;
+//   * a lane's global offset is constant for a whole 32-row group (its row and channels), the column walks in the
+//     buffer instructions' SCALAR offset (+ one pixel per step), and the descriptor, the lane's validity (rows past the
+//     tensor, vertical taps outside the image -> the OOB offset, which reads zeros) and the group's scalar base are set up
+//     once per group (every W steps) under a uniform branch;
+//   * the operand format is a template parameter.
+template <int N>
+struct StepPhase {
+  static constexpr int v = N;
+};
+constexpr unsigned OOBV = 0xFFFFFF00u;  // past every range (tensors are < 0xFFFFFF00 bytes) and OOBV + immediate does not wrap
+
+__device__ __forceinline__ u32x4 load16s(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
+template <int KS, int WMW, bool PRE>
 __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   constexpr int PAD = KS / 2, NR = 2 * PAD + 2;
+  // AHEAD = column steps between an operand request and its LDS stores.  2: a second set of staging registers; the
+  // stores of the set requested a step ago are spread over this step's MFMA blocks from the first one on.  1 (the 5x5
+  // 128-co form sits at 256 registers): requested at the top of the step, stored between its later blocks.
+  constexpr int AHEAD = (KS == 5 && WMW == 2) ? 1 : 2;
   constexpr int DYB = 16384, XSLOT = 8192, X_BASE = 2 * DYB;
+  constexpr unsigned EB = PRE ? 2u : 4u;  // bytes per operand element in memory
+  static_assert(NR % 2 == 0, "the dy buffer index is a function of the ring phase");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -2068,14 +2103,18 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int Cs = first ? p.C0 : p.Cin - p.C0;
   const int cl0 = first ? ci0 : ci0 - p.C0;
 
-  unsigned amd = 0, amx = 0;
-  for (int t = 0; t < p.T; ++t) {
-    amd = max(amd, *p.dy_amax[t]);
-    amx = max(amx, *p.x0_amax[t]);
-    if (p.x1_amax[t]) amx = max(amx, *p.x1_amax[t]);
+  float sd = 1.f, sx = 1.f;
+  int kd, kxs;
+  {
+    unsigned amd = 0, amx = 0;
+    for (int t = 0; t < p.T; ++t) {
+      amd = max(amd, *p.dy_amax[t]);
+      amx = max(amx, *p.x0_amax[t]);
+      if (p.x1_amax[t]) amx = max(amx, *p.x1_amax[t]);
+    }
+    kd = scale_exp(amd), kxs = scale_exp(amx);
+    sd = pow2f(kd), sx = pow2f(kxs);
   }
-  const int kd = scale_exp(amd), kxs = scale_exp(amx);
-  const float sd = pow2f(kd), sx = pow2f(kxs);
 
   const int g_skip = first ? 0 : p.x1_skip * p.G;
   const int NG = p.T * p.G;
@@ -2088,7 +2127,7 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int skk = tid >> 3, ssub = tid & 7;
   const int ssw = wg_swz(skk);
   // dy roles of the 64-co form: threads 0..127 (waves 0 and 1), row tid >> 2, 16-channel segment tid & 3
-  const bool dy_role = WMW == 2 || tid < 128;
+  const bool dy_role = WMW == 2 || wid < 2;  // (wave-uniform)
   const int dkk = WMW == 2 ? skk : (tid >> 2) & 31, dsub = WMW == 2 ? ssub : tid & 3;
   const int dsw = wg_swz(dkk);
   const int dy_lds = dkk * 256 + ((dsub ^ dsw) * 32);                       // + buf * DYB + part * 8192
@@ -2103,74 +2142,115 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
   const int x_lds = X_BASE + skk * 256 + (((ssub >> 1) ^ ssw) * 32) + (ssub & 1) * 16;  // part 1: segment ^ 4 -> ^ 128
   const bool dy_ch_ok = co0 + dsub * 16 < p.Cout;
   const bool x_ch_ok = cl0 + ssub * 8 < Cs;
-  // loader cursors (uniform): dy column e_d, x column e_x, as (group, column) pairs
-  int dg = g_begin, dc = 0, xg = g_begin, xc = 0;
-  u32x4 rd[4], rx[2];
-  auto issue_dy = [&]() {
-    if (dy_role) {  // (wave-uniform)
-      const int t = dg / p.G, gr = dg - t * p.G;
-      const int r = gr * 32 + dkk;
-      const bool ok = (r < p.R) & dy_ch_ok;
-      if (p.presplit) {  // 16 channels = 32 bytes per part: rd[0..1] part 0, rd[2..3] part 1
-        const unsigned pbytes = (unsigned)((long)p.R * p.W * p.Cout * 2);
-        const rsrc_t rs = make_rsrc(p.dy[t], 2u * pbytes);
-        const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 2u;
-        rd[0] = load16(rs, ok ? off + dflip : OOB);           // (the half this thread stores first)
-        rd[1] = load16(rs, ok ? off + (dflip ^ 16u) : OOB);
-        rd[2] = load16(rs, ok ? off + pbytes + dflip : OOB);
-        rd[3] = load16(rs, ok ? off + pbytes + (dflip ^ 16u) : OOB);
+
+  // ---- loaders: (time step, 32-row group, column) cursors; the dy cursor runs one column ahead of the MFMAs, the x
+  //      cursor PAD + 1 columns.  Memory offset of (row r = 32 G + kk, column c, channel ch) = ((r W + c) C + ch) EB is
+  //      split three ways: the DESCRIPTOR's base carries the group (32 G W C EB, + the step's pointer), the lane offset
+  //      carries (kk W C + ch) EB -- a constant of the lane -- and the instruction's SCALAR offset carries the column
+  //      (c C EB).  A descriptor of (rows left in the tensor) W C EB bytes zero-fills the rows past the tensor's end
+  //      (gfx950 range-checks lane + scalar offset against it: measured -- a part-1 load through the part-0 descriptor
+  //      with the part stride as its scalar offset returns zeros; operand parts therefore get a descriptor each), and
+  //      lanes that are invalid for the whole launch (channels past the tensor; vertical taps outside the image when 32
+  //      rows are whole images) carry the out-of-range offset as their constant: entering a group is scalar work. ----
+  const unsigned dy_col = (unsigned)p.Cout * EB, dy_row = (unsigned)p.W * dy_col, dy_grp = 32u * dy_row;
+  const unsigned dy_part = PRE ? (unsigned)((long)p.R * dy_row) : 0u;
+  const unsigned dy_lane = ((unsigned)(dkk * p.W) * (unsigned)p.Cout + (unsigned)(co0 + dsub * 16)) * EB;
+  // fp32: four 16-byte pieces at {0, 16, 32, 48} ^ 2 dflip (channels 8..15 first for half of the lanes) = two lane
+  // offsets + the immediate 16; parts: the 32 bytes of a part as two halves, in the lane's order, part 1 = scalar + part
+  const unsigned d_v0 = dy_ch_ok ? dy_lane + (PRE ? dflip : 2u * dflip) : OOBV;
+  const unsigned d_v1 = dy_ch_ok ? dy_lane + (PRE ? (dflip ^ 16u) : (32u ^ (2u * dflip))) : OOBV;
+  const unsigned x_col = (unsigned)Cs * EB, x_row = (unsigned)p.W * x_col, x_grp = 32u * x_row;
+  const unsigned x_part = PRE ? (unsigned)((long)p.R * x_row) : 0u;
+  const unsigned x_lane = ((unsigned)(skk * p.W) * (unsigned)Cs + (unsigned)(cl0 + ssub * 8)) * EB;
+  // the vertical tap moves the descriptor's base by ky - PAD image rows: the row a lane reads is r + ky - PAD, valid iff
+  // its image row y = r mod H + ky - PAD stays inside the image (which also keeps it inside the tensor)
+  const long x_shift = (long)(ky - PAD) * (long)x_row;
+  const bool h32 = __builtin_amdgcn_readfirstlane((32 % p.H) == 0 ? 1 : 0) != 0;  // a lane's image row is then the same in every group
+  const bool y_ok0 = (unsigned)(skk % p.H + ky - PAD) < (unsigned)p.H;
+  const float* const* xsrc = first ? p.x0 : p.x1;
+
+  int dT = g_begin / p.G, dG = g_begin - dT * p.G, dC = 0;
+  int xT = dT, xG = dG, xC = 0;
+  rsrc_t d_rs = make_rsrc(p.dy[0], 0u), x_rs = d_rs, d_rs1 = d_rs, x_rs1 = d_rs;  // (rs1: the second parts)
+  unsigned d_so = 0, x_so = 0;
+  unsigned x_v = (x_ch_ok & (y_ok0 | !h32)) ? x_lane : OOBV;
+  u32x4 rdS[AHEAD][4], rxS[AHEAD][2];
+  auto issue_dy = [&](u32x4 (&rd)[4]) {
+    if (dC == 0) {  // (uniform) entering a group
+      const char* base = reinterpret_cast<const char*>(p.dy[dT]) + (long)dG * dy_grp;
+      d_rs = make_rsrc(base, (unsigned)(p.R - dG * 32) * dy_row);
+      if constexpr (PRE) d_rs1 = make_rsrc(base + dy_part, (unsigned)(p.R - dG * 32) * dy_row);
+      d_so = 0;
+    }
+    if (dy_role) {
+      if constexpr (PRE) {
+        rd[0] = load16s(d_rs, d_v0, d_so);
+        rd[1] = load16s(d_rs, d_v1, d_so);
+        rd[2] = load16s(d_rs1, d_v0, d_so);
+        rd[3] = load16s(d_rs1, d_v1, d_so);
       } else {
-        const rsrc_t rs = make_rsrc(p.dy[t], (unsigned)((long)p.R * p.W * p.Cout * 4));
-        const unsigned off = (unsigned)(((long)r * p.W + dc) * p.Cout + co0 + dsub * 16) * 4u;
-#pragma unroll
-        for (int v = 0; v < 4; ++v) rd[v] = load16(rs, ok ? off + ((16u * v) ^ (2u * dflip)) : OOB);  // channels 8..15 first
+        rd[0] = load16s(d_rs, d_v0, d_so);
+        rd[1] = load16s(d_rs, d_v0 + 16u, d_so);
+        rd[2] = load16s(d_rs, d_v1, d_so);
+        rd[3] = load16s(d_rs, d_v1 + 16u, d_so);
       }
     }
-    if (++dc == p.W) dc = 0, ++dg;
+    d_so += dy_col;
+    if (++dC == p.W) {
+      dC = 0;
+      if (++dG == p.G) dG = 0, ++dT;
+    }
   };
-  auto issue_x = [&]() {
-    const int t = xg / p.G, gr = xg - t * p.G;
-    const int r = gr * 32 + skk;
-    const int y = r % p.H + ky - PAD;
-    const bool ok = (r < p.R) & ((unsigned)y < (unsigned)p.H) & x_ch_ok;
-    if (p.presplit) {  // 8 channels = 16 bytes per part: rx[0] part 0, rx[1] part 1
-      const unsigned pbytes = (unsigned)((long)p.R * p.W * Cs * 2);
-      const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], 2u * pbytes);
-      const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 2u;
-      rx[0] = load16(rs, ok ? off : OOB);
-      rx[1] = load16(rs, ok ? off + pbytes : OOB);
+  auto issue_x = [&](u32x4 (&rx)[2]) {
+    if (xC == 0) {
+      const char* base = reinterpret_cast<const char*>(xsrc[xT]) + ((long)xG * x_grp + x_shift);
+      x_rs = make_rsrc(base, (unsigned)(p.R - xG * 32) * x_row);
+      if constexpr (PRE) x_rs1 = make_rsrc(base + x_part, (unsigned)(p.R - xG * 32) * x_row);
+      x_so = 0;
+      if (!h32) {  // (uniform; 6- / 12-row maps) the lane's image row changes with the group
+        const int y = (xG * 32 + skk) % p.H + ky - PAD;
+        x_v = (x_ch_ok & ((unsigned)y < (unsigned)p.H)) ? x_lane : OOBV;
+      }
+    }
+    if constexpr (PRE) {
+      rx[0] = load16s(x_rs, x_v, x_so);
+      rx[1] = load16s(x_rs1, x_v, x_so);
     } else {
-      const rsrc_t rs = make_rsrc(first ? p.x0[t] : p.x1[t], (unsigned)((long)p.R * p.W * Cs * 4));
-      const unsigned off = (unsigned)(((long)(r + ky - PAD) * p.W + xc) * Cs + cl0 + ssub * 8) * 4u;
-      rx[0] = load16(rs, ok ? off : OOB);
-      rx[1] = load16(rs, ok ? off + 16u : OOB);
+      rx[0] = load16s(x_rs, x_v, x_so);
+      rx[1] = load16s(x_rs, x_v + 16u, x_so);
     }
-    if (++xc == p.W) xc = 0, ++xg;
+    x_so += x_col;
+    if (++xC == p.W) {
+      xC = 0;
+      if (++xG == p.G) xG = 0, ++xT;
+    }
   };
-  auto store_dy = [&](int buf) {
-    if (!dy_role) return;
-    u32x4 q0[2], q1[2];
-    if (p.presplit) {
-      q0[0] = rd[0], q1[0] = rd[1], q0[1] = rd[2], q1[1] = rd[3];
+  // The six 16-byte LDS stores of a step's staged operands, as separately placeable pieces (a ds_write_b128 moves its
+  // data to the LDS for ~13 cycles, at half rate when one wave stores alone: 24 KB per workgroup and step cost 12-18 % of
+  // the kernel as a block behind the MFMAs -- timing builds, profiles/r05_wgrad_decomposition.md -- so each piece sits behind
+  // one block of 12 MFMAs).  Pieces 0..3: the dy tile (fp32 operands: pieces 0 / 2 convert a pair of vectors, 1 / 3 store
+  // the second part), 4..5: the input column.
+  u32x4 qd[2], qx[2];
+  auto stage_piece = [&](int j, u32x4 (&rd)[4], u32x4 (&rx)[2], int buf, int slot, bool do_dy, bool do_x) {
+    if (j < 4) {
+      if (!(dy_role && do_dy)) return;
+      unsigned char* d = lds_raw + buf * DYB + dy_lds;
+      if constexpr (PRE) {  // rd[0..1]: the halves of part 0 in the lane's order, rd[2..3]: of part 1
+        *reinterpret_cast<u32x4*>(d + (j >> 1) * 8192 + ((j & 1) ? (dflip ^ 16u) : dflip)) = rd[j];
+      } else {
+        if (j == 0) split8h(rd[0], rd[1], sd, qd);
+        if (j == 2) split8h(rd[2], rd[3], sd, qd);
+        *reinterpret_cast<u32x4*>(d + (j & 1) * 8192 + ((j & 2) ? (dflip ^ 16u) : dflip)) = qd[j & 1];
+      }
     } else {
-      split8h(rd[0], rd[1], sd, q0);
-      split8h(rd[2], rd[3], sd, q1);
+      if (!do_x) return;
+      if constexpr (PRE) {
+        *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + ((j & 1) ? (x_lds ^ 128) : x_lds)) = rx[j & 1];
+      } else {
+        if (j == 4) split8h(rx[0], rx[1], sx, qx);
+        *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + ((j & 1) ? (x_lds ^ 128) : x_lds)) = qx[j & 1];
+      }
     }
-#pragma unroll
-    for (int part = 0; part < 2; ++part) {
-      unsigned char* d = lds_raw + buf * DYB + part * 8192 + dy_lds;
-      *reinterpret_cast<u32x4*>(d + dflip) = q0[part];
-      *reinterpret_cast<u32x4*>(d + (dflip ^ 16u)) = q1[part];
-    }
-  };
-  auto store_x = [&](int slot) {
-    u32x4 q[2];
-    if (p.presplit)
-      q[0] = rx[0], q[1] = rx[1];
-    else
-      split8h(rx[0], rx[1], sx, q);
-    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + x_lds) = q[0];
-    *reinterpret_cast<u32x4*>(lds_raw + slot * XSLOT + (x_lds ^ 128)) = q[1];
   };
 
   // ---- fragment addresses (lane constants) ----
@@ -2200,41 +2280,67 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
     __syncthreads();
   }
   if (S > 0) {
-    // prologue: input columns 0 .. PAD and the dy tile of column 0
+    // prologue: input columns 0 .. PAD and the dy tile of column 0 (AHEAD = 2: and the requests of column 1's operands)
     for (int e = 0; e <= PAD && e < S; ++e) {
-      issue_x();
-      store_x(e);
+      issue_x(rxS[0]);
+#pragma unroll
+      for (int j = 4; j < 6; ++j) stage_piece(j, rdS[0], rxS[0], 0, e, false, true);
     }
-    issue_dy();
-    store_dy(0);
+    issue_dy(rdS[0]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stage_piece(j, rdS[0], rxS[0], 0, 0, true, false);
+    if constexpr (AHEAD == 2) {  // what step 0 stores: requested "in step -1", set 1
+      if (1 < S) issue_dy(rdS[1]);
+      if (PAD + 1 < S) issue_x(rxS[1]);
+    }
     __syncthreads();
-    int c = 0, sm = 0;  // column of the current step inside its group, step index mod NR
-    for (int s = 0; s < S; ++s) {
-      const bool more_dy = s + 1 < S, more_x = s + PAD + 1 < S;
-      if (more_dy) issue_dy();
-      if (more_x) issue_x();
-      const int dbuf = (s & 1) * DYB;
+    int c = 0, s = 0;  // column of the current step inside its image row, step index
+    // one column step at ring phase PH (= s mod NR): the current input column sits in slot PH, the dy tile in buffer PH & 1
+    auto step = [&](auto phase) {
+      constexpr int PH = decltype(phase)::v;
+      constexpr int dbuf = (PH & 1) * DYB;
+      constexpr int LSET = PH % AHEAD, SSET = (PH + 1) % AHEAD;  // register sets: requested into / stored from in this step
+      constexpr int NB = KS * NU;                                 // MFMA blocks of a step (12 MFMAs each)
+      // first block with a store piece behind it, blocks that take pieces.  AHEAD = 1 is the 5x5 128-co form, whose 160
+      // accumulator + 48 fragment + 24 staging registers leave no room for store addresses while fragments are live
+      // (the allocator spills ACCUMULATORS to scratch if pieces sit between its blocks): its pieces follow the last
+      // blocks, where the fragment registers are dead
+      // (fp32 operands add the conversion's temporaries: all pieces behind the last block there)
+      constexpr int LATE = PRE ? RAC_WGRAD_LATE_BLOCKS : 0;
+      constexpr int FIRST = AHEAD == 2 ? 0 : NB - 1 - LATE;
+      constexpr int NSLOT = AHEAD == 2 ? NB - 1 : LATE + 1;
+      const bool st_dy = s + 1 < S, st_x = s + PAD + 1 < S;
+      if (!(RAC_EXP_WGRAD & 2)) {
+        if (s + AHEAD < S) issue_dy(rdS[LSET]);
+        if (s + PAD + AHEAD < S) issue_x(rxS[LSET]);
+      }
+      auto pieces_behind = [&](int blk) {  // (blk is a compile-time constant at every call site)
+        if (RAC_EXP_WGRAD & 4) return;
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (FIRST + (j * NSLOT) / 6 == blk)
+            stage_piece(j, rdS[SSET], rxS[SSET], (PH + 1) & 1, (PH + PAD + 1) % NR, st_dy, st_x);
+      };
       f16x8 fa[4][2];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
       if constexpr (NU == 2 && RAC_WGRAD_ROLL) {
         // The input fragments roll through the taps in halves: the 16-ci block u of tap k + 1 is read into the registers of
         // block u of tap k as soon as that block's 12 MFMAs are issued, under the 12 MFMAs of the other block -- every tap's
-        // fragments are in flight for half a tap before their first use instead of being waited for in front of it (the ISA
-        // of the plain loop: 8 reads, s_waitcnt lgkmcnt(0), 24 MFMAs, five times per step).  No registers added.  Reads are
-        // unconditional (a tap that leaves the image row reads a stale slot), only its MFMAs are skipped.
+        // fragments are in flight for half a tap before their first use instead of being waited for in front of it.  Reads
+        // are unconditional (a tap that leaves the image row reads a stale slot), only its MFMAs are skipped.
         f16x8 fb[2][2];
         auto read_fb = [&](int u, int k) {
-          int sl = sm + k - PAD;
-          sl += sl < 0 ? NR : 0;
-          sl -= sl >= NR ? NR : 0;
+          const int sl = (PH + k - PAD + NR) % NR;
 #pragma unroll
           for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
         };
+        // the first block's operands first: its MFMAs start while the rest of the step's fragments are still in flight
         read_fb(0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int part = 1; part >= 0; --part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
         read_fb(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < KS; ++k) {
           const bool valid = (unsigned)(c + k - PAD) < (unsigned)p.W;  // uniform: the tap stays inside the image row
@@ -2246,36 +2352,54 @@ __global__ __launch_bounds__(256, 2) void wgrad16_kernel(Wgrad16P p) {
             }
             __builtin_amdgcn_sched_barrier(0);
             if (k + 1 < KS) read_fb(u, k + 1);
+            pieces_behind(k * 2 + u);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
       } else {
 #pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        if ((unsigned)(c + k - PAD) >= (unsigned)p.W) continue;  // uniform: the tap leaves the image row
-        int sl = sm + k - PAD;
-        sl += sl < 0 ? NR : 0;
-        sl -= sl >= NR ? NR : 0;
-        f16x8 fb[NU][2];
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-          for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
-#pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int u = 0; u < NU; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+          for (int part = 0; part < 2; ++part) fa[t][part] = tr_frag(lds_raw, dbuf + part * 8192 + offA[t]);
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+          if ((unsigned)(c + k - PAD) < (unsigned)p.W) {  // uniform: the tap stays inside the image row
+            const int sl = (PH + k - PAD + NR) % NR;
+            f16x8 fb[NU][2];
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+              for (int part = 0; part < 2; ++part) fb[u][part] = tr_frag(lds_raw, sl * XSLOT + offB[part][u]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int u = 0; u < NU; ++u) acc[k][t][u] = mma3(fa[t], fb[u], acc[k][t][u]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) pieces_behind(k * NU + u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      }
-      if (more_dy) store_dy((s + 1) & 1);
-      if (more_x) {
-        int sl = sm + PAD + 1;
-        sl -= sl >= NR ? NR : 0;
-        store_x(sl);
-      }
-      __syncthreads();
+      if (!(RAC_EXP_WGRAD & 1)) __syncthreads();
       c = (c + 1 == p.W) ? 0 : c + 1;
-      sm = (sm + 1 == NR) ? 0 : sm + 1;
+      ++s;
+    };
+    for (;;) {
+      step(StepPhase<0>{});
+      if (s == S) break;
+      step(StepPhase<1>{});
+      if (s == S) break;
+      step(StepPhase<2>{});
+      if (s == S) break;
+      step(StepPhase<3>{});
+      if (s == S) break;
+      if constexpr (NR == 6) {
+        step(StepPhase<4>{});
+        if (s == S) break;
+        step(StepPhase<5>{});
+        if (s == S) break;
+      }
     }
   }
 
@@ -3072,11 +3196,14 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
   const int ct = cdiv(a->Cout, co64 ? 64 : 128), nt = cdiv(a->Cin - p.C0, 64) + cdiv(p.C0, 64);
   dim3 grid(ct, nt, a->ksize * p.nsplit);
   typedef void (*fn_t)(Wgrad16P);
-  const fn_t fn = a->ksize == 5 ? (co64 ? (fn_t)wgrad16_kernel<5, 1> : (fn_t)wgrad16_kernel<5, 2>)
-                                : (co64 ? (fn_t)wgrad16_kernel<3, 1> : (fn_t)wgrad16_kernel<3, 2>);
+  static const fn_t fns[8] = {(fn_t)wgrad16_kernel<3, 2, false>, (fn_t)wgrad16_kernel<3, 1, false>,
+                              (fn_t)wgrad16_kernel<5, 2, false>, (fn_t)wgrad16_kernel<5, 1, false>,
+                              (fn_t)wgrad16_kernel<3, 2, true>,  (fn_t)wgrad16_kernel<3, 1, true>,
+                              (fn_t)wgrad16_kernel<5, 2, true>,  (fn_t)wgrad16_kernel<5, 1, true>};
+  const int fi = p.presplit * 4 + (a->ksize == 5) * 2 + co64;
+  const fn_t fn = fns[fi];
   const int lds = 2 * 16384 + (a->ksize + 1) * 8192;
-  static bool attr_done[4] = {false, false, false, false};
-  const int fi = (a->ksize == 5) * 2 + co64;
+  static bool attr_done[8] = {false, false, false, false, false, false, false, false};
   if (!attr_done[fi]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) {

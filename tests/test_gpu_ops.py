@@ -780,7 +780,10 @@ def test_rows_kernel_takes_128_wide_maps(dev, B, Cin, Cout):
                                   (5, 4, 8, 32, 0, 64, 3), (1, 16, 16, 64, 0, 128, 3), (4, 8, 8, 128, 128, 384, 3),
                                   (2, 32, 32, 64, 64, 64, 3), (3, 16, 16, 128, 0, 64, 5), (2, 8, 8, 64, 0, 48, 3),
                                   (2, 64, 64, 64, 0, 64, 3), (1, 32, 32, 128, 0, 128, 3), (3, 32, 32, 96, 0, 96, 3),
-                                  (1, 64, 64, 64, 64, 64, 3)])
+                                  (1, 64, 64, 64, 64, 64, 3),
+                                  # 6- / 12-row maps (48x64 frames): a 32-row group is not whole images, a lane's image row
+                                  # changes from group to group; 7 images of 6 rows = 42 rows: the second group is ragged
+                                  (7, 6, 8, 64, 64, 96, 5), (3, 12, 16, 64, 0, 64, 3), (11, 6, 8, 128, 128, 128, 3)])
 @pytest.mark.parametrize("presplit", [False, True])
 def test_wgrad_split_precision(dev, case, presplit, monkeypatch):
     """Weight gradient on the split-precision pipe against fp64, next to the exact-fp32 MFMA kernel; accumulation into
