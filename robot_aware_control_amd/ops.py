@@ -1847,6 +1847,69 @@ def recurrent_core_ok(h_all, g: int, z: int, nv: int, cells, head, frame_conv) -
     return frame_conv.weight.requires_grad and head[0].requires_grad
 
 
+# The three ConvLSTM chains of the recurrent core on their own streams.  Under teacher forcing the prior's chain needs
+# nothing of the other two (its inputs are the encoder's latents), the posterior's nothing of the frame predictor's, and the
+# frame predictor's step t only z_t of the posterior's step t (dynamics.py:600-629) -- and backward mirrors it (the posterior
+# needs dz_t of the frame predictor's step t, the prior nothing).  In one stream every launch of a chain -- a 512-workgroup gate
+# GEMM that is exactly one round of the chip, a 10 us cell kernel, a data-gradient combine -- waits for the previous one to
+# DRAIN (profiles/r04d_sq_summary.md: matrix pipe 65.6 % busy at M = 1024 against 78.1 % on the same kernel at the planner's
+# M = 64000); with the chains in three streams one chain's ramp, epilogue and pointwise kernels run under another's main
+# loop.  Same kernels on the same operands: results are bit-equal to the one-stream order (tests/test_gpu_model.py).
+# MEASURED (round 5, same box, three interleaved pairs): 23.55 -> 23.42 ms per train step (-0.5 %): concurrent chains share
+# the CUs, each launch stretches, and what the chip gains is only the drain / ramp overlap -- the gate GEMM's gap to its
+# planner-shape rate is per-WORKGROUP (prologue and epilogue of a K / 4 slab), not per launch.  It also makes every
+# per-kernel duration (bench.py's live roofline, rocprof) the duration of a SHARED chip.  Off by default
+# (RAC_CHAIN_STREAMS=1 turns it on).
+# Memory rule: the side streams wait for the main stream where a region starts and the main stream waits for them where it
+# ends; tensors handed from one stream to another inside a region stay referenced until its end (the caching allocator
+# reuses a freed block in its OWN stream's order only).
+CHAIN_STREAMS = os.environ.get("RAC_CHAIN_STREAMS", "0") == "1"
+_CHAIN = {"dev": None, "prior": None, "post": None}
+
+
+class _ChainRegion:
+    """Streams of one forward / backward pass of the core: `on("prior" | "post" | "fp")` is a context manager that makes
+    the chain's stream current (the frame predictor stays on the caller's stream)."""
+
+    def __init__(self, dev, enabled: bool):
+        self.enabled = bool(enabled and CHAIN_STREAMS and torch.device(dev).type == "cuda")
+        self.main = torch.cuda.current_stream() if torch.device(dev).type == "cuda" else None
+        self.keep = []
+        self.streams = {}
+        if not self.enabled:
+            return
+        if _CHAIN["dev"] != torch.device(dev):
+            _CHAIN.update(dev=torch.device(dev), prior=torch.cuda.Stream(device=dev), post=torch.cuda.Stream(device=dev))
+        self.streams = {"prior": _CHAIN["prior"], "post": _CHAIN["post"]}
+        _amax_reserve(dev, 16384)  # no fresh (kernel-zeroed) amax arena inside the region
+        start = torch.cuda.Event()
+        start.record(self.main)
+        for st in self.streams.values():
+            st.wait_event(start)
+
+    def on(self, chain: str):
+        st = self.streams.get(chain)
+        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+
+    def event(self, chain: str):
+        """An event at the chain's current position (None when the chains share one stream)."""
+        if not self.enabled:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.streams.get(chain, self.main))
+        return ev
+
+    def wait(self, chain: str, ev) -> None:
+        if ev is not None:
+            self.streams.get(chain, self.main).wait_event(ev)
+
+    def join(self) -> None:
+        for name in self.streams:
+            self.main.wait_event(self.event(name))
+        self.streams = {}
+        self.keep.clear()
+
+
 class RecurrentCore(torch.autograd.Function):
     """h_pred (T*B), mu, logvar (posterior, T*B), h_prior (T*B) = the T-step recurrence over the encoder's latents.
 
@@ -1861,7 +1924,6 @@ class RecurrentCore(torch.autograd.Function):
         dev = h_all.device
         _, H, W, _ = h_all.shape
         M = B * H * W
-        sp = stream_ptr()
         step = lambda t_: t_.view((T, B) + tuple(t_.shape[1:]))
         h_steps, prior_steps, post_steps = step(h_all), step(prior_all), step(post_all)
         one = amax_one(dev)
@@ -1883,7 +1945,8 @@ class RecurrentCore(torch.autograd.Function):
             h = h_out if h_out is not None else torch.empty_like(x)
             c = torch.empty_like(x)
             act = torch.empty((B, H, W, 4 * g), device=dev, dtype=torch.float32)
-            call("rac_lstm_cell_fwd", ptr(slabs), n_slabs, stride, ptr(cell.bias), ptr(c_prev), ptr(h), ptr(c), ptr(act), M, g, sp)
+            call("rac_lstm_cell_fwd", ptr(slabs), n_slabs, stride, ptr(cell.bias), ptr(c_prev), ptr(h), ptr(c), ptr(act), M, g,
+                 stream_ptr())
             tag_amax(h, one)  # |h| = |o * tanh(c)| < 1
             state[L][l] = (h, c)
             return h, {"x": x, "h_prev": h_prev, "c_prev": c_prev, "act": act, "c": c}
@@ -1893,34 +1956,55 @@ class RecurrentCore(torch.autograd.Function):
         ct = nv + g + z
         pad = (-ct) % 32
         fw_pad = padded_weight(fconv.weight, ct + pad)
+        # the noise of every step, drawn in the reference's order (the prior's draw, dropped, before the posterior's)
+        eps_all = []
         for t in range(T):
-            rec = {}
-            x = retag(prior_steps[t], amax_tag(prior_all))
-            x, rec["prior0"] = run_cell("prior", 0, x)
-            _, rec["prior1"] = run_cell("prior", 1, x, hq_s[t])
-            if plan["draw_prior_noise"]:  # the reference draws the prior's z (and drops it) before the posterior's
+            if plan["draw_prior_noise"]:
                 plan["eps_fn"](mu_s[t])
-            x = retag(post_steps[t], amax_tag(post_all))
-            x, rec["post0"] = run_cell("post", 0, x)
-            h_post, rec["post1"] = run_cell("post", 1, x)
-            slabs, split, stride = conv_forward_split(h_post, None, head_w, want_slabs=True)
-            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_s[t]), ptr(lv_s[t]), M, 2 * z, z, None,
-                 None, sp)
-            eps = plan["eps_fn"](mu_s[t])
-            z_t = torch.empty_like(mu_s[t])
-            call("rac_reparam_fwd", ptr(mu_s[t]), ptr(lv_s[t]), ptr(eps), ptr(z_t), z_t.numel(), sp)
-            v3 = list(vs[t]) + [None] * (3 - len(vs[t]))
-            cat = torch.empty((B, H, W, ct + pad), device=dev, dtype=torch.float32)
-            slot = amax_slot(dev)
-            call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
-                 v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
-                 ptr(h_steps[t]), g, ptr(z_t), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
-            tag_amax(cat, slot)
-            x = conv_forward_split(cat, None, fw_pad, fconv.bias)
-            x, rec["fp0"] = run_cell("fp", 0, x)
-            _, rec["fp1"] = run_cell("fp", 1, x, hp_s[t])
-            rec.update(cat=cat, h_post=h_post, eps=eps)
-            tape.append(rec)
+            eps_all.append(plan["eps_fn"](mu_s[t]))
+        # (operand parts of every weight of the core are refreshed -- one launch over ALL weights -- on the caller's stream)
+        for L in ("prior", "post", "fp"):
+            for cell in cells[L]:
+                weight_parts(cell.gates.weight)
+        weight_parts(head_w)
+        weight_parts(fw_pad)
+        region = _ChainRegion(dev, True)
+        try:
+            for t in range(T):
+                rec = {}
+                with region.on("prior"):
+                    x = retag(prior_steps[t], amax_tag(prior_all))
+                    x, rec["prior0"] = run_cell("prior", 0, x)
+                    _, rec["prior1"] = run_cell("prior", 1, x, hq_s[t])
+                with region.on("post"):
+                    sp = stream_ptr()
+                    x = retag(post_steps[t], amax_tag(post_all))
+                    x, rec["post0"] = run_cell("post", 0, x)
+                    h_post, rec["post1"] = run_cell("post", 1, x)
+                    slabs, split, stride = conv_forward_split(h_post, None, head_w, want_slabs=True)
+                    call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_s[t]), ptr(lv_s[t]), M, 2 * z, z,
+                         None, None, sp)
+                    eps = eps_all[t]
+                    z_t = torch.empty_like(mu_s[t])
+                    call("rac_reparam_fwd", ptr(mu_s[t]), ptr(lv_s[t]), ptr(eps), ptr(z_t), z_t.numel(), sp)
+                    z_ready = region.event("post")
+                region.keep.append(z_t)  # (allocated in the posterior's stream, read by the frame predictor's)
+                region.wait("fp", z_ready)
+                sp = stream_ptr()
+                v3 = list(vs[t]) + [None] * (3 - len(vs[t]))
+                cat = torch.empty((B, H, W, ct + pad), device=dev, dtype=torch.float32)
+                slot = amax_slot(dev)
+                call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
+                     v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
+                     ptr(h_steps[t]), g, ptr(z_t), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
+                tag_amax(cat, slot)
+                x = conv_forward_split(cat, None, fw_pad, fconv.bias)
+                x, rec["fp0"] = run_cell("fp", 0, x)
+                _, rec["fp1"] = run_cell("fp", 1, x, hp_s[t])
+                rec.update(cat=cat, h_post=h_post, eps=eps)
+                tape.append(rec)
+        finally:
+            region.join()
         # (the node keeps what backward reads, not the caller's closures: `eps_fn` is a bound method of the model, and a
         # model -> output tensor -> grad_fn -> plan -> model cycle would keep a dropped model's 4 GB alive until a full GC)
         ctx.plan = {k: plan[k] for k in ("g", "z", "nv", "cells", "head", "frame_conv")}
@@ -1937,7 +2021,6 @@ class RecurrentCore(torch.autograd.Function):
         g, z, nv = plan["g"], plan["z"], plan["nv"]
         M = B * H * W
         dev = ctx.lv_all.device
-        sp = stream_ptr()
         cells, fconv = plan["cells"], plan["frame_conv"]
         head_w, head_b = plan["head"]
         ct = nv + g + z
@@ -1961,7 +2044,7 @@ class RecurrentCore(torch.autograd.Function):
             dc_prev = torch.empty_like(rec["c"])
             slot = amax_slot(dev)
             call("rac_lstm_cell_bwd_srcs", _pack_srcs(srcs), len(srcs), ptr(nxt[0]) if nxt is not None else None,
-                 ptr(rec["act"]), ptr(rec["c_prev"]), ptr(rec["c"]), ptr(dgates), ptr(dc_prev), M, g, ptr(slot), sp)
+                 ptr(rec["act"]), ptr(rec["c_prev"]), ptr(rec["c"]), ptr(dgates), ptr(dc_prev), M, g, ptr(slot), stream_ptr())
             tag_amax(dgates, slot)
             first = is_zero(rec["h_prev"])  # t = 0: nothing flows into the (all-zero, constant) initial state
             cin = g if first else 2 * g
@@ -1976,47 +2059,63 @@ class RecurrentCore(torch.autograd.Function):
         # stream: the frame predictor's run under the posterior's and the prior's backward, not only under the encoder's.
         chain_ws = lambda L, extra: [c.gates.weight for c in cells[L]] + extra
         dcats = [None] * T
-        for t in range(T - 1, -1, -1):
-            rec = tape[t]
-            # frame predictor: layer 1 (its h feeds the decoder), layer 0, then the input conv over cat[v | h_t | z_t]
-            ext = [_src(d_hpred[t], 1, g)] if d_hpred is not None else []
-            s1 = cell_bwd("fp", 1, rec["fp1"], ext)
-            s0 = cell_bwd("fp", 0, rec["fp0"], [s1])
-            dy_f = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
-            slot = amax_slot(dev)
-            tag_amax(grad_sum([s0], dy_f, g, slot), slot)
-            dcat, n_c = conv_dgrad_slabs(dy_f, fw_pad, cpad)
-            conv_wgrad_split_acc(dy_f, rec["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
-            bias_grad_acc(dy_f, fconv.bias)
-            grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
-            dcats[t] = (dcat, n_c)
-        flush_deferred_wgrads_early(chain_ws("fp", [fconv.weight]))
-        for t in range(T - 1, -1, -1):
-            rec = tape[t]
-            dcat, n_c = dcats[t]
-            dcats[t] = None
-            # posterior: reparameterisation + KL gradients -> merged head -> layer 1, layer 0 -> its input conv's output
-            dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
-            slot = amax_slot(dev)
-            call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(lv_s[t]), ptr(rec["eps"]),
-                 ptr(d_mu[t]) if d_mu is not None else None, ptr(d_lv[t]) if d_lv is not None else None, ptr(dy_h), M, z,
-                 ptr(slot), sp)
-            tag_amax(dy_h, slot)
-            dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
-            conv_wgrad_split_acc(dy_h, rec["h_post"], None, head_w, defer=True)
-            bias_grad_acc(dy_h, head_b)
-            q1 = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
-            q0 = cell_bwd("post", 0, rec["post0"], [q1])
-            grad_sum([q0], d_post_all[t], g, slot_post)
-        flush_deferred_wgrads_early(chain_ws("post", [head_w]))
-        for t in range(T - 1, -1, -1):
-            rec = tape[t]
-            # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
-            ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
-            p1 = cell_bwd("prior", 1, rec["prior1"], ext)
-            p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
-            grad_sum([p0], d_prior_all[t], g, slot_prior)
-            tape[t] = None  # (launches are stream ordered: what this step allocated may be reused by the next)
+        for L in ("prior", "post", "fp"):  # (the data gradients' operand parts: refreshed on the caller's stream)
+            for cell in cells[L]:
+                weight_parts(cell.gates.weight, transposed=True)
+        weight_parts(head_w, transposed=True)
+        weight_parts(fw_pad, transposed=True)
+        region = _ChainRegion(dev, True)
+        dz_ready = [None] * T
+        try:
+            for t in range(T - 1, -1, -1):
+                rec = tape[t]
+                # frame predictor: layer 1 (its h feeds the decoder), layer 0, then the input conv over cat[v | h_t | z_t]
+                ext = [_src(d_hpred[t], 1, g)] if d_hpred is not None else []
+                s1 = cell_bwd("fp", 1, rec["fp1"], ext)
+                s0 = cell_bwd("fp", 0, rec["fp0"], [s1])
+                dy_f = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
+                slot = amax_slot(dev)
+                tag_amax(grad_sum([s0], dy_f, g, slot), slot)
+                dcat, n_c = conv_dgrad_slabs(dy_f, fw_pad, cpad)
+                dz_ready[t] = region.event("fp")  # the posterior's step t may start
+                conv_wgrad_split_acc(dy_f, rec["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
+                bias_grad_acc(dy_f, fconv.bias)
+                grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
+                dcats[t] = (dcat, n_c)
+            flush_deferred_wgrads_early(chain_ws("fp", [fconv.weight]))
+            with region.on("post"):
+                for t in range(T - 1, -1, -1):
+                    rec = tape[t]
+                    dcat, n_c = dcats[t]
+                    region.wait("post", dz_ready[t])
+                    # posterior: reparameterisation + KL gradients -> merged head -> layer 1, layer 0 -> its input conv's output
+                    dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
+                    slot = amax_slot(dev)
+                    call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(lv_s[t]), ptr(rec["eps"]),
+                         ptr(d_mu[t]) if d_mu is not None else None, ptr(d_lv[t]) if d_lv is not None else None, ptr(dy_h), M, z,
+                         ptr(slot), stream_ptr())
+                    tag_amax(dy_h, slot)
+                    dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
+                    conv_wgrad_split_acc(dy_h, rec["h_post"], None, head_w, defer=True)
+                    bias_grad_acc(dy_h, head_b)
+                    q1 = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
+                    q0 = cell_bwd("post", 0, rec["post0"], [q1])
+                    grad_sum([q0], d_post_all[t], g, slot_post)
+                flush_deferred_wgrads_early(chain_ws("post", [head_w]))  # (ordered behind the posterior's stream)
+            with region.on("prior"):
+                for t in range(T - 1, -1, -1):
+                    rec = tape[t]
+                    # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
+                    ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
+                    p1 = cell_bwd("prior", 1, rec["prior1"], ext)
+                    p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
+                    grad_sum([p0], d_prior_all[t], g, slot_prior)
+                if region.enabled:
+                    flush_deferred_wgrads_early(chain_ws("prior", []))
+        finally:
+            region.join()
+        # (the tape and the slabs handed between the chains are released only now: behind the join)
+        dcats = tape = None
         # every operand of the core's weight gradients exists now: they start on the side stream, under the encoder's backward
         # (and of whatever else was recorded before: the prior's heads)
         flush_deferred_wgrads_early(None)

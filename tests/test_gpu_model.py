@@ -242,6 +242,60 @@ def test_recurrent_core_matches_the_autograd_path(dev, tag, monkeypatch):
         assert float((a - b).norm() / (b.norm() + 1e-30)) < 1e-5, k
 
 
+def test_recurrent_core_chain_streams_same_bits(dev, monkeypatch):
+    """ops.RecurrentCore with its three ConvLSTM chains on three streams (ops.CHAIN_STREAMS) against the one-stream order,
+    at the benchmarked width (g 512 / z 64, batch 16, five steps: launches long enough to overlap): the same kernels on the
+    same operands, so outputs, input gradients and every weight gradient are the SAME BITS -- a missing event or a block the
+    allocator recycled under a reader shows up here.  The core is replayed on the inputs one real train step gave it."""
+    from robot_aware_control_amd import ops
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=16, n_past=1, n_future=4, lr=1e-4, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=5, randomize_bn_stats=False)
+    data = syn.synth_video(seed=21, T=5, B=16)
+    eps = syn.synth_eps(seed=22, steps=4, B=16, z=64, h=8, w=8)
+    tr = make_trainer(cfg, sd, dev)
+    tr.optimizer.step = lambda: None
+    noise = [e for pair in eps for e in pair]
+    queue = list(noise)
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    seen = {}
+    real = ops.RecurrentCore.apply
+
+    def spy(plan, h, pr, po, *params):
+        seen.update(plan=dict(plan), maps=[t.detach().clone() for t in (h, pr, po)], params=params)
+        return real(plan, h, pr, po, *params)
+    monkeypatch.setattr(ops.RecurrentCore, "apply", spy)
+    tr._train_step(data)
+    monkeypatch.setattr(ops.RecurrentCore, "apply", real)
+    assert tr.model.used_recurrent_core and seen
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    T, B = seen["plan"]["T"], seen["plan"]["B"]
+    shapes = [(T * B, 8, 8, 512), (T * B, 8, 8, 64), (T * B, 8, 8, 64), (T * B, 8, 8, 512)]
+    gouts = [(torch.randn(sh, generator=gen) * 1e-3).to(dev) for sh in shapes]
+    biases = [c.gates.bias for cs in seen["plan"]["cells"].values() for c in cs]
+
+    def replay(streams):
+        monkeypatch.setattr(ops, "CHAIN_STREAMS", streams)
+        queue[:] = noise
+        tr.model.zero_grad()
+        maps = [t.clone().requires_grad_(True) for t in seen["maps"]]
+        with ops.deferred_wgrad():
+            outs = real(dict(seen["plan"]), *maps, *seen["params"])
+            gin = torch.autograd.grad(outs, maps, gouts)
+        torch.cuda.synchronize()
+        return ([o.detach().clone() for o in outs], [g_.clone() for g_ in gin],
+                [p_.grad.detach().clone() for p_ in seen["params"]], [b.grad.detach().clone() for b in biases])
+
+    ref = replay(False)
+    assert all(float(w.abs().max()) > 0 for w in ref[2]) and all(float(g_.abs().max()) > 0 for g_ in ref[1])
+    for rep in range(3):
+        got = replay(True)
+        for name, a, b in zip(("outputs", "input gradients", "weight gradients"), got[:3], ref[:3]):
+            for i, (x, y) in enumerate(zip(a, b)):
+                assert torch.equal(x, y), (rep, name, i, float((x - y).abs().max()))
+        for x, y in zip(got[3], ref[3]):  # (bias gradients: column sums with fp32 atomics)
+            assert float((x - y).norm() / (y.norm() + 1e-30)) < 1e-5
+
+
 def test_train_step_128x128_vs_oracle(dev):
     """BASELINE configs[4] geometry (128x128 frames -> 16x16 latent maps, larger than a GEMM tile) at plumbing
     width: the ConvLSTM gate convs take the image-rows + halo kernel, forward and data gradient."""
