@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 7
+#define RAC_ABI_VERSION 8
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -387,6 +387,11 @@ int rac_first_layer_fwd_split(const float* img, const float* zmask, const float*
  * [3][3][64][4].  H % 8 == 0, W % 32 == 0.  A fixed order of sums per pixel: the result does not depend on the batch. */
 int rac_head_fwd(const float* x, const float* w_taps, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
                  void* stream);
+/* Data gradient of that head w.r.t. its 64-channel input (the autograd of vgg_64.py:218-220; the gradient through the
+ * Sigmoid is rac_act_bwd's):  dx[b][y][x][ci] = sum_{ky, kx, co} d[b][y + ky - 1][x + kx - 1][co] * w[ci][ky][kx][co],
+ * d NHWC [B][H][W][4], w = the (64, 4, 3, 3) ConvTranspose parameter in its memory order [64][3][3][4], dx NHWC
+ * [B][H][W][64] (every element written).  Exact-fp32 FMAs in a fixed order.  W % 16 == 0. */
+int rac_head_dgrad(const float* d, const float* w, float* dx, int32_t B, int32_t H, int32_t W, void* stream);
 /* The same head on the split-precision matrix pipe, as a tap-stacked 1 x 1 conv Z[tap][q][c] = sum_ci w[tap][ci][c] x[q][ci]
  * (M = 36 rows: weights = the MFMA's A operand, 16 pixels = B, loaded straight from HBM and split in registers) followed by
  * the shifted sum y[p] = sigmoid(bias + sum_tap Z[tap][p + d_tap]) through LDS: every input element is read, converted and

@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 7  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 8  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -128,6 +128,7 @@ _SIGS = {
     "rac_first_layer_fwd": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_first_layer_fwd_split": [vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_head_fwd": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "rac_head_dgrad": [vp, vp, vp, i32, i32, i32, vp],
     "rac_head_fwd_split": [vp, vp, i32, vp, vp, vp, i32, i32, i32, vp],
     "rac_thin_wgrad": [vp, vp, i32, i32, vp, i32, i32, i32, i32, i32, vp],
     "rac_unpack_grad": [vp, i32, vp, vp, i32, i32, vp],

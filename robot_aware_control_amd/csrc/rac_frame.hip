@@ -535,6 +535,65 @@ __global__ void robot_atlas_kernel(RobotAtlasP p) {
   for (int i = threadIdx.x; i < p.HW; i += blockDim.x) dst[i] = src[i] ? 1.f : 0.f;
 }
 
+// Data gradient of the 64 -> 4 output head (vgg_64.py:218-220) w.r.t. its 64-channel input:
+//   dx[b][y][x][ci] = sum_{ky, kx, co} d[b][y + ky - 1][x + kx - 1][co] * w[ci][ky][kx][co]        (zero outside the image)
+// 4 channels in, 64 out, 36 products per output element: no shape for a GEMM tile (on the exact-fp32 implicit GEMM it
+// ran at 0.07 of that pipe, 7x its HBM floor).  A thread owns one channel QUAD for the life of the workgroup -- its
+// 4 x 9 weight float4s stay in registers (144 VGPRs) -- and walks pixels: per pixel nine float4 loads of d (the 16 lanes
+// of a pixel read the same addresses: one request), 144 FMAs, one float4 store; the 64 lanes of a wave store four
+// pixels' 64 channels = 1 KB contiguous.  Bound by the 256 B it writes per pixel.
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float4* __restrict__ d, const float4* __restrict__ w,
+                                                         float4* __restrict__ dx, int H, int W, long n_pix, int per_block) {
+  const int q = threadIdx.x & 15, pl = threadIdx.x >> 4;  // channel quad, pixel lane (16 consecutive pixels of a row)
+  float4 wv[4][9];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[c][t] = w[(4 * q + c) * 9 + t];
+  const long first = (long)blockIdx.x * per_block;
+  const long last = min(first + (long)per_block, n_pix);
+  // the nine d vectors of a 16-pixel group (W % 16 == 0: one image row; its coordinates are workgroup-uniform); the next
+  // group's are requested before this group's 144 FMAs: two waves per SIMD do not hide an L2 round trip by themselves
+  // (buffer loads: a tap outside the image reads through an out-of-range offset, which returns zeros -- no branches)
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(d), (short)0, (int)(n_pix * 16), 0x00020000);
+  auto fetch = [&](long base, float4 (&dv)[9]) {
+    const long row = base / W;
+    const int x = (int)(base - row * W) + pl, y = (int)(row % H);
+    const unsigned centre = (unsigned)(base + pl) * 16u;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const bool yok = (unsigned)(y + ky - 1) < (unsigned)H;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bool ok = yok && (unsigned)(x + kx - 1) < (unsigned)W;
+        const unsigned off = centre + (unsigned)(((ky - 1) * W + (kx - 1)) * 16);
+        dv[ky * 3 + kx] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(ok ? off : 0xFFFFFFF0u), 0, 0));
+      }
+    }
+  };
+  float4 dv[9], dn[9];
+  if (first < last) fetch(first, dv);
+  for (long base = first; base < last; base += 16) {
+    if (base + 16 < last) fetch(base + 16, dn);
+    float acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float a = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        a = fmaf(dv[t].x, wv[c][t].x, a);
+        a = fmaf(dv[t].y, wv[c][t].y, a);
+        a = fmaf(dv[t].z, wv[c][t].z, a);
+        a = fmaf(dv[t].w, wv[c][t].w, a);
+      }
+      acc[c] = a;
+    }
+    dx[(base + pl) * 16 + q] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dv[t] = dn[t];
+  }
+}
+
 extern "C" {
 
 int rac_pack_input(const float* img, const float* zmask, const float* mask, int32_t Cm, int32_t pad, float* packed,
@@ -570,6 +629,20 @@ int rac_head_fwd(const float* x, const float* w_taps, const float* bias, float* 
               "rac_head_fwd: H % 8 == 0, W % 32 == 0, 16-byte aligned buffers");
   hipLaunchKernelGGL(head_direct_kernel, dim3((H / 8) * (W / 32), B), dim3(256), 0, ST(stream), x, w_taps, bias, y, H, W);
   return check_launch("rac_head_fwd");
+}
+
+int rac_head_dgrad(const float* d, const float* w, float* dx, int32_t B, int32_t H, int32_t W, void* stream) {
+  RAC_REQUIRE(d && w && dx && B > 0 && H > 0 && W > 0, "rac_head_dgrad: bad args");
+  RAC_REQUIRE(W % 16 == 0 && aligned16(d) && aligned16(w) && aligned16(dx), "rac_head_dgrad: W % 16 == 0, 16-byte aligned buffers");
+  const long n_pix = (long)B * H * W;
+  // two workgroups per CU (the 144 weight registers allow two waves per SIMD), one round; whole 16-pixel groups each
+  long per_block = ((n_pix + 511) / 512 + 15) / 16 * 16;
+  if (per_block < 64) per_block = 64;
+  const long blocks = (n_pix + per_block - 1) / per_block;
+  RAC_REQUIRE(blocks < (1L << 31) && per_block < (1L << 31) && n_pix < (1L << 28) - 16, "rac_head_dgrad: too many pixels");
+  hipLaunchKernelGGL(head_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), reinterpret_cast<const float4*>(d),
+                     reinterpret_cast<const float4*>(w), reinterpret_cast<float4*>(dx), H, W, n_pix, (int)per_block);
+  return check_launch("rac_head_dgrad");
 }
 
 int rac_thin_wgrad(const float* wide, const float* thin, int32_t thin_stride, int32_t Ct, float* parts, int32_t n_parts,

@@ -352,6 +352,7 @@ SPLIT_GEMM = os.environ.get("RAC_SPLIT_GEMM", "1") == "1"
 SPLIT_GEMM_TRAIN = SPLIT_GEMM
 HEAD_DIRECT = os.environ.get("RAC_HEAD_DIRECT", "1") == "1"  # the 64 -> 4 output head as FMAs (rac_head_fwd)
 FIRST_MFMA = os.environ.get("RAC_FIRST_MFMA", "1") == "1"  # the frozen model's first encoder layer on the matrix pipe
+HEAD_DGRAD = os.environ.get("RAC_HEAD_DGRAD", "1") == "1"  # its data gradient as one streaming pass (rac_head_dgrad)
 HEAD_MFMA = os.environ.get("RAC_HEAD_MFMA", "1") == "1"  # ... on the matrix pipe, roles swapped (rac_head_fwd_split)
 # narrowest layer (output channels) that runs split-precision
 SPLIT_MIN_COUT = int(os.environ.get("RAC_SPLIT_MIN_COUT", "64"))
@@ -1408,7 +1409,11 @@ class ConvTHead(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dx[ci] = sum_{tap,co} d[p+tap][co] * w[ci][tap][co]  -> FWD form with "Cout"=Ciw, "Cin"=Cow
-            conv_raw(FWD, d, None, weight, dx, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow)
+            if HEAD_DGRAD and d.is_cuda and (Ciw, Cow, k) == (64, 4, 3) and W % 16 == 0:
+                # 4 channels in, 64 out: one pass bound by the 256 B it writes per pixel (rac_head_dgrad), not a GEMM tile
+                call("rac_head_dgrad", ptr(d), ptr(weight_mem(weight)), ptr(dx), B, H, W, stream_ptr())
+            else:
+                conv_raw(FWD, d, None, weight, dx, B=B, H=H, W=W, ksize=k, Cin=Cow, Cout=Ciw, a_split=Cow)
         if weight.requires_grad:
             g = grad_buffer(weight)
             # dw[ci][tap][co] += sum_p x[p][ci] * d[p+tap][co]  -> WGRAD with dy:=x, x:=d

@@ -137,6 +137,16 @@ def test_convT_head(dev, B, H, W, Ci, monkeypatch):
     assert relerr(from_map(xd.grad), x.grad) < 2e-5
     assert relerr(wd.grad.cpu(), w.grad) < 3e-5
     assert relerr(bd.grad.cpu(), b.grad) < 2e-5
+    if Ci == 64 and W % 16 == 0:
+        # the head's data gradient as one streaming pass (rac_head_dgrad) against the exact-fp32 implicit GEMM and fp64
+        x64 = x.detach().double().requires_grad_(True)
+        torch.sigmoid(F.conv_transpose2d(x64, w.detach().double(), b.detach().double(), 1, 1)).backward(gy.double())
+        monkeypatch.setattr(ops, "HEAD_DGRAD", False)
+        xg = to_map(x.detach(), dev).requires_grad_(True)
+        ops.ConvTHead.apply(xg, wd.detach(), bd.detach()).backward(to_map(gy, dev))
+        monkeypatch.setattr(ops, "HEAD_DGRAD", True)
+        e_new, e_gemm = relerr(from_map(xd.grad), x64.grad), relerr(from_map(xg.grad), x64.grad)
+        assert e_new < 2e-6 and e_new < 2 * e_gemm + 1e-7, (e_new, e_gemm)
 
 
 def test_first_layer_and_head_on_constant_inputs(dev):

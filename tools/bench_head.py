@@ -27,3 +27,22 @@ for name, mfma, direct in (("matrix pipe, roles swapped (rac_head_fwd_split)", T
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20
     print(f"{name}: {ms * 1e3:.0f} us  ({x.numel() * 4 / ms / 1e9:.2f} TB/s of input)", flush=True)
+
+# the head's data gradient (training: 80 images of 64 x 64): one streaming pass against the exact-fp32 implicit GEMM
+Bt = 80
+d = torch.randn(Bt, H, W, 4, device=dev)
+dx = torch.empty(Bt, H, W, 64, device=dev)
+forms = (("streaming pass (rac_head_dgrad)", lambda: ops.call("rac_head_dgrad", ops.ptr(d), ops.ptr(w), ops.ptr(dx), Bt, H, W, ops.stream_ptr())),
+         ("exact-fp32 implicit GEMM", lambda: ops.conv_raw(ops.FWD, d, None, w, dx, B=Bt, H=H, W=W, ksize=3, Cin=4, Cout=64, a_split=4)))
+for name, fn in forms:
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print(f"head dgrad, {name}: {ms * 1e3:.0f} us  ({dx.numel() * 4 / ms / 1e9:.2f} TB/s written)", flush=True)
