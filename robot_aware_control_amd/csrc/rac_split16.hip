@@ -1141,8 +1141,11 @@ __global__ __launch_bounds__(256, 2) void first16_kernel(const float* __restrict
 #ifndef RAC_ROWS_PIN
 #define RAC_ROWS_PIN 1
 #endif
-template <int NV, int WM, int NT, int D, bool FAST = false>
+// KSF: kernel size of the FAST form (3, or 5: the 5x5 ConvLSTM gate convs on the 16x16 latents of a 128x128 model --
+// round 5; whole-row tiles only, 128-column workgroups only).
+template <int NV, int WM, int NT, int D, bool FAST = false, int KSF = 3>
 __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
+  constexpr int PF = KSF / 2, TAPSF = KSF * KSF;  // (FAST form: pad, taps per channel chunk)
   constexpr int WN = 4 / WM;
   constexpr int MB = 8 / WM;            // 16-row blocks per wave
   constexpr int NB = 2 * NT;            // 16-column blocks per wave
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int wn = wid % WN, wm = wid / WN;
   const int TM = p.tile_m;
   const int nmb = TM >> 4;
-  const bool seg = FAST && p.seg_w;  // 2-D tile (unrolled 3x3 form only)
+  const bool seg = FAST && KSF == 3 && p.seg_w;  // 2-D tile (unrolled 3x3 form only)
   SegOrigin so{};
   if (seg) so = seg_origin(p, bx);
   const int m0 = seg ? so.m0 : bx * TM, n0 = by * BNW;
@@ -1208,12 +1211,12 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
   const int halo = p.pad * p.W;
   // staged pixel rows: the tile's image rows + the halo rows (a multiple of 16); 2-D tile: the (seg_h + 2) x (seg_w + 2) halo tile
   const int nrows = seg ? (p.seg_h + 2) * (p.seg_w + 2) : TM + 2 * halo;
-  // FAST (3 x 3): every staged image row sits in W + 2 LDS rows, a zero row either side, so a horizontal tap that leaves
+  // FAST: every staged image row sits in W + 2 PF LDS rows, PF zero rows either side, so a horizontal tap that leaves
   // the image reads zeros by address: no per-lane validity mask / compare / select per (tap, block) -- as the tile
   // kernel's padded segments.  (2-D tile: the halo columns are staged like any other pixel, zeros outside the image.)
   // Otherwise: the staged rows + 16 zero rows that the select points at.
   const int WD = seg ? p.seg_w : p.W;  // pixels of a tile row
-  const int WP = WD + 2;
+  const int WP = WD + 2 * PF;
   // one 8-channel group; (FAST) rounded to 256 B: the four k-groups of a read must start on the same 16-byte slot
   const int cplane = FAST ? (((seg ? nrows : (nrows / p.W) * WP) + 15) & ~15) * 16 : (nrows + 16) * 16;
   const int pplane = 4 * cplane;
@@ -1246,7 +1249,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       s_pix[i] = (so.img * (p.H >> 1) + (y >> 1)) * (p.W >> 1) + (x >> 1);
       continue;
     }
-    s_off[i] = g < 4 ? g * cplane + (FAST ? (row / p.W) * WP + 1 + row % p.W : row) * 16 : -1;
+    s_off[i] = g < 4 ? g * cplane + (FAST ? (row / p.W) * WP + PF + row % p.W : row) * 16 : -1;
     const int y = y_tile - p.pad + row / p.W;
     s_ok[i] = (g < 4) & ((unsigned)y < (unsigned)p.H) & (m0 - halo + row < p.M);
     s_pix[i] = m0 - halo + row;
@@ -1270,7 +1273,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
 #pragma unroll
   for (int t = 0; t < MB; ++t) {
     const int r0 = (wm * MB + t) * 16;
-    ablk[t] = lq * cplane + ((1 + r0 / WD) * WP + 1 + r0 % WD + lr) * 16;
+    ablk[t] = lq * cplane + ((PF + r0 / WD) * WP + PF + r0 % WD + lr) * 16;
   }
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
@@ -1340,8 +1343,76 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
       pre[nb][1] = p.scale ? p.scale[nc] : 1.f;
       pre[nb][2] = p.scale ? p.shift[nc] : 0.f;
     }
-    static_assert(D == 3, "the 9 taps of a chunk walk a ring of 3 weight register sets");
-    const int c_begin = kc_begin / 9, c_end = kc_end / 9;
+    static_assert(D == 3, "the taps of a chunk walk a ring of 2 or 3 weight register sets");
+    const int c_begin = kc_begin / TAPSF, c_end = kc_end / TAPSF;
+    if constexpr (KSF == 5) {
+      // 5 x 5: 25 taps per chunk.  Unrolled like the 3 x 3 form the chunk body is 2 x 25 taps x 48 MFMAs = 160 KB of code (the
+      // instruction cache holds 64 KB); here the taps run in a loop whose body is ONE PAIR of taps (weight sets 0 and 1, each
+      // refilled in place by quarters for the tap two ahead), the tap's offset in the padded rows is a scalar, and the chunk
+      // switch (conversion + stores of the next chunk, one barrier) hangs off the pair whose tap is a chunk's last.  What the
+      // padded rows buy is the same as in the 3 x 3 form: no per-lane mask, compare and select per (tap, row block).
+      static_assert(NT == 2, "the 5x5 form exists for 128-column workgroups");
+      if (c_begin < c_end) {
+        u32x4 bs[2][4 * NT];
+        issue_a(c_begin);
+        load_b(bs[0], kc_begin);
+        load_b(bs[1], min(kc_begin + 1, kc_end - 1));
+        store_a(0);
+        __syncthreads();
+        if (c_begin + 1 < c_end) issue_a(c_begin + 1);  // (right behind a conversion: see conv16_tile_kernel)
+        int cc = c_begin, ky = 0, kx = 0, cur = 0;
+        auto load_b_quarter = [&](u32x4(&rb)[4 * NT], int nb, int kc) {
+          const int j = nb >> 1, h = nb & 1;
+#pragma unroll
+          for (int part = 0; part < 2; ++part)
+            rb[(j * 2 + part) * 2 + h] = __builtin_bit_cast(
+                u32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(b_off[j] + part * w_pstride + h * 1024u), kc * 2048, 0));
+        };
+        auto one_tap = [&](u32x4(&rb)[4 * NT], int kc) {
+          const int shift = ((ky - PF) * WP + (kx - PF)) * 16 + cur * abuf;  // wave-uniform: the tap in the padded rows
+          f16x8 fb[NB][2];
+#pragma unroll
+          for (int j2 = 0; j2 < NT; ++j2)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+              for (int part = 0; part < 2; ++part) fb[j2 * 2 + nb][part] = __builtin_bit_cast(f16x8, rb[(j2 * 2 + part) * 2 + nb]);
+          f16x8 fa[MB][2];
+#pragma unroll
+          for (int t = 0; t < MB; ++t) {
+            const int ao = ablk[t] + shift;
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+              fa[t][part] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(lds_raw + ao + part * pplane));
+          }
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int t = 0; t < MB; ++t) acc[t][nb] = mma3(fa[t], fb[nb], acc[t][nb]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b_quarter(rb, nb, min(kc + 2, kc_end - 1));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          const bool last_tap = (ky == KSF - 1) & (kx == KSF - 1);
+          if (last_tap) {
+            if (cc + 1 < c_end) {
+              store_a(cur ^ 1);
+              __syncthreads();
+              cur ^= 1;
+              if (cc + 2 < c_end) issue_a(cc + 2);
+            }
+            ++cc, ky = 0, kx = 0;
+          } else {
+            kx = kx + 1 == KSF ? 0 : kx + 1;
+            ky += kx == 0;
+          }
+        };
+        for (int kc = kc_begin; kc < kc_end; kc += 2) {
+          one_tap(bs[0], kc);
+          if (kc + 1 < kc_end) one_tap(bs[1], kc + 1);
+        }
+      }
+    } else
     if (c_begin < c_end) {
       // weight register sets: 128-column workgroups (NT = 2: 32 VGPRs per set) keep TWO and request one tap ahead -- with
       // three the kernel needs more than 256 VGPRs, and the scheduler, to stay inside, sank every request to just before the
@@ -1374,11 +1445,11 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
         constexpr int P = decltype(par)::value;
         const bool more = cc + 1 < c_end;
         if (more) issue_a(cc + 1);
-        const int kc0 = cc * 9;
+        const int kc0 = cc * TAPSF;
         const int bufo = cur * abuf;
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-          const int ky = tap / 3, kx = tap % 3;
+        for (int tap = 0; tap < TAPSF; ++tap) {
+          const int ky = tap / KSF, kx = tap % KSF;
 #if !(RAC_EXP_ROWS_NOB) && !RAC_ROWS_REFILL  // (timing build: the weight fragments loaded once per workgroup)
           load_b(bs[(tap + AHEAD + P) % R], min(kc0 + tap + AHEAD, kc_end - 1));
 #endif
@@ -1388,7 +1459,7 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
           // conv16_rows_persist_kernel does: +4 % on the 64-column form, nothing on the 128-column one -- not done.)
           __builtin_amdgcn_sched_barrier(0);
 #endif
-          const int shift = ((ky - 1) * WP + (kx - 1)) * 16 + bufo;  // wave-uniform: the tap in the padded rows
+          const int shift = ((ky - PF) * WP + (kx - PF)) * 16 + bufo;  // wave-uniform: the tap in the padded rows
           f16x8 fb[NB][2];
 #pragma unroll
           for (int j2 = 0; j2 < NT; ++j2)
@@ -1434,12 +1505,13 @@ __global__ __launch_bounds__(256, 2) void conv16_rows_kernel(Conv16P p) {
         }
       };
       if constexpr (R == 2) {
+        static_assert(TAPSF % 2 == 1, "an odd number of taps: the set of a chunk's first tap alternates");
         for (int cc = c_begin; cc < c_end; cc += 2) {
           chunk(std::integral_constant<int, 0>{}, cc);
           if (cc + 1 < c_end) chunk(std::integral_constant<int, 1>{}, cc + 1);
         }
       } else {
-        static_assert(9 % R == 0, "ring phase");
+        static_assert(TAPSF % R == 0, "ring phase");
         for (int cc = c_begin; cc < c_end; ++cc) chunk(std::integral_constant<int, 0>{}, cc);
       }
     }
@@ -2901,11 +2973,14 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
         {conv16_rows_kernel<2, 2, 2, 3, true>, conv16_rows_kernel<3, 2, 2, 3, true>, conv16_rows_kernel<4, 2, 2, 3, true>},
         {conv16_rows_kernel<2, 2, 1, 3, true>, conv16_rows_kernel<3, 2, 1, 3, true>, conv16_rows_kernel<4, 2, 1, 3, true>},
         {conv16_rows_kernel<2, 4, 1, 3, true>, conv16_rows_kernel<3, 4, 1, 3, true>, conv16_rows_kernel<4, 4, 1, 3, true>}};
+    // 5 x 5 (the ConvLSTM gate convs on 16x16 latents: BASELINE configs[4]), 128-column workgroups: the same unrolled form
+    static const rows_fn fast5_fns[3] = {conv16_rows_kernel<2, 2, 2, 3, true, 5>, conv16_rows_kernel<3, 2, 2, 3, true, 5>,
+                                         conv16_rows_kernel<4, 2, 2, 3, true, 5>};
     size_t lds_rows = (size_t)2 * 2 * 4 * (nrows + 16) * 16;
     static bool rows_attr = false;
     if (!rows_attr) {
-      for (int i = 0; i < 18; ++i) {
-        const rows_fn f = i < 9 ? fns[i / 3][i % 3] : fast_fns[(i - 9) / 3][i % 3];
+      for (int i = 0; i < 21; ++i) {
+        const rows_fn f = i < 9 ? fns[i / 3][i % 3] : (i < 18 ? fast_fns[(i - 9) / 3][i % 3] : fast5_fns[i - 18]);
         if (!f) continue;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(f),
                                            hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2930,6 +3005,13 @@ static int conv16_launch(const rac_conv_args* a, const uint32_t* a_amax0, const 
     const bool fast = a->ksize == 3 && p.tile_m == 128 && p.cps % 9 == 0 && fast_fns[width][nv - 2] &&
                       (tile2d || !(nofast && atoi(nofast)));
     RAC_REQUIRE(fast || !tile2d, "rac_conv2d_fwd_split: 2-D tiles need the unrolled 3x3 form");
+    const char* nofast5 = getenv("RAC_ROWS_FAST5");  // (=0: the generic loop for 5x5 convs on maps larger than a tile)
+    const size_t lds5 = (size_t)2 * 2 * 4 * ((((nrows / a->W) * (a->W + 4)) + 15) & ~15) * 16;
+    if (a->ksize == 5 && width == 0 && p.tile_m == 128 && p.cps % 25 == 0 && !(nofast && atoi(nofast)) &&
+        !(nofast5 && atoi(nofast5) == 0) && lds5 <= (size_t)2 * 2 * 4 * (256 + 16) * 16) {
+      fn = fast5_fns[nv - 2];
+      lds_rows = lds5;
+    }
     if (fast) {
       fn = fast_fns[width][nv - 2];
       // padded rows: W + 2 LDS rows per image row (2-D tile: the halo tile itself), the plane rounded to 256 B

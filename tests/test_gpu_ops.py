@@ -716,6 +716,34 @@ def test_rows_kernel_2d_tiles_are_the_same_bits(dev, B, H, W, C0, C1, Cout, up, 
     assert relerr(from_map(got[0]), ref) < 2e-6
 
 
+@pytest.mark.parametrize("B,C0,C1,Cout", [(3, 64, 64, 256), (8, 128, 128, 512), (2, 96, 0, 128)])
+def test_rows_kernel_5x5_padded_rows_are_the_same_bits(dev, B, C0, C1, Cout, monkeypatch):
+    """5x5 convs on 16x16 maps (the ConvLSTM gate convs of a 128x128 model, BASELINE configs[4]): the padded-row form of
+    the rows kernel (a tap that leaves the image row reads zeros by address; RAC_ROWS_FAST5, default) against the generic
+    loop with its per-lane tap masks (RAC_ROWS_FAST5=0): same operands, same order of sums -- bit-equal; forward (two
+    sources, K split and unsplit with per-image scales), the data gradient, and against fp64."""
+    from robot_aware_control_amd import ops
+    H = W = 16
+    x0 = to_map(rnd(71, B, C0, H, W), dev)
+    x1 = to_map(rnd(72, B, C1, H, W), dev) if C1 else None
+    wt = cl_weight(rnd(73, Cout, C0 + C1, 5, 5) * 0.03).to(dev)
+    gy = to_map(rnd(74, B, Cout, H, W), dev)
+
+    def run():
+        y = ops.conv_forward_split(x0, x1, wt, None, per_image=True)
+        slabs, n, stride = ops.conv_forward_split(x0, x1, wt, want_slabs=True)
+        d0, d1 = ops.conv_dgrad_split(gy, wt, C0, C1)
+        return y, slabs.clone(), d0, d1
+    monkeypatch.setenv("RAC_ROWS_FAST5", "1")
+    got = run()
+    monkeypatch.setenv("RAC_ROWS_FAST5", "0")
+    want = run()
+    for a, b in zip(got, want):
+        assert (a is None and b is None) or torch.equal(a, b)
+    xin = torch.cat([from_map(x0).double()] + ([from_map(x1).double()] if C1 else []), 1)
+    assert relerr(from_map(got[0]), F.conv2d(xin, wt.cpu().double(), None, 1, 2)) < 2e-6
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,fused", [
     (3, 64, 64, 64, 64, True),      # 2-D tiles, 64 columns
     (600, 64, 64, 64, 64, True),    # the persistent form
