@@ -228,6 +228,10 @@ def build_train(args, dev):
         cf.batch_size, cf.n_future = 8, 10
     log("building trainer (g512/z64, 238.6 M params)")
     tr = PredictionTrainer(cf)
+    # as PredictionTrainer.train() does: the large weights' optimiser update may finish under the next step's encoder
+    # (every step's whole update still lies inside the timed region: it ends with a device-wide synchronise)
+    if os.environ.get("RAC_ADAM_OVERLAP", "1") == "1" and hasattr(tr.optimizer, "overlap_next_forward"):
+        tr.optimizer.overlap_next_forward = True
     # random weights that keep activations O(1) and make the predictions depend on the actions (synth_state_dict)
     tr.model.load_state_dict(syn.synth_state_dict(tr.model, seed=11))
     tr.model.train()

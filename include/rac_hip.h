@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 8
+#define RAC_ABI_VERSION 9
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -496,6 +496,11 @@ typedef struct rac_adam_frag_job {
 } rac_adam_frag_job;
 int rac_adam_frag_multi(const rac_adam_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, float lr, float beta1,
                         float beta2, float eps, int32_t step, void* stream);
+/* The same pass on at most `max_workgroups` workgroups, each walking every max_workgroups-th block of work: an update that
+ * runs beside other streams' kernels (optim.FusedAdam's late group under the next step's encoder) leaves them the CUs'
+ * registers and LDS; 2 per CU (512) keep ~64 KB per CU in flight.  Same bits as rac_adam_frag_multi. */
+int rac_adam_frag_multi_bounded(const rac_adam_frag_job* jobs, int32_t n_jobs, int64_t total_blocks, int32_t max_workgroups,
+                                float lr, float beta1, float beta2, float eps, int32_t step, void* stream);
 /* bound[idx[j]] = bits(float(exact[idx[j]]) + margin); exact[idx[j]] = 0   (j < n; idx in device memory) */
 int rac_amax_bound(uint32_t* exact, uint32_t* bound, const int32_t* idx, int32_t n, float margin, void* stream);
 /* rac_adam_step over a list of float4 ranges [begin4, begin4 + n4) of the flat buffers (device table; range r owns the

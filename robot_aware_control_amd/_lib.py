@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 8  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 9  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -144,6 +144,7 @@ _SIGS = {
     "rac_cem_robot_inputs": [vp, vp, vp, vp, vp, i32, i32, f32, f32, f32, f32, f32, f32, f32, vp, vp, i32, i32, i32, i32, i32, vp],
     "rac_adam_step": [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, vp],
     "rac_adam_frag_multi": [vp, i32, i64, f32, f32, f32, f32, i32, vp],
+    "rac_adam_frag_multi_bounded": [vp, i32, i64, i32, f32, f32, f32, f32, i32, vp],
     "rac_amax_bound": [vp, vp, vp, i32, f32, vp],
     "rac_adam_ranges": [vp, vp, vp, vp, vp, i32, i64, f32, f32, f32, f32, i32, vp],
     "rac_version": [],

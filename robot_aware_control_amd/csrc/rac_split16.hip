@@ -1990,15 +1990,20 @@ __global__ __launch_bounds__(256) void absmax_multi_kernel(const rac_absmax_job*
 // step Adam can take), whose exponent is the scale the convs then undo; the exact new maximum is folded into amax_out
 // for the next bound.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_frag_job* jobs, int n_jobs, float b1, float b2,
-                                                              float eps, float step_size, float inv_sqrt_bc2) {
+__global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_frag_job* jobs, int n_jobs, long total_blocks,
+                                                              float b1, float b2, float eps, float step_size,
+                                                              float inv_sqrt_bc2) {
   __shared__ float tile[2][32][33];
   __shared__ unsigned mx_sh[4];
-  const int j = job_of_block(jobs, n_jobs, blockIdx.x);
+  // one block of work = two 32 x 32 cells; a workgroup takes blocks blockIdx.x, + gridDim.x, ... (the grid is the block
+  // count, or a bounded number of workgroups: rac_adam_frag_multi_bounded -- a pass that shares the chip with other
+  // streams' kernels leaves them registers and LDS)
+  for (long blk = blockIdx.x; blk < total_blocks; blk += gridDim.x) {
+  const int j = job_of_block(jobs, n_jobs, (int)blk);
   const rac_adam_frag_job q = jobs[j];
   const int taps = q.ksize * q.ksize, cch = q.Cin >> 5;
   const int half = threadIdx.x >> 7;
-  const long cell = (blockIdx.x - q.block_begin) * 2 + half;  // ((nt * cch + cc) * taps + tap)
+  const long cell = (blk - q.block_begin) * 2 + half;  // ((nt * cch + cc) * taps + tap)
   // (walking the cells along the input channels first -- consecutive workgroups on consecutive 256-byte pieces of the same
   // weight rows, the fragment writes then 50 KB apart -- measured 2.02 ms against 1.85 for this order)
   const bool active = cell < (long)(q.Cout >> 5) * cch * taps;
@@ -2061,6 +2066,7 @@ __global__ __launch_bounds__(256) void adam_frag_multi_kernel(const rac_adam_fra
   if (threadIdx.x == 0) {
     mx = max(max(mx_sh[0], mx_sh[1]), max(mx_sh[2], mx_sh[3]));
     if (mx > __hip_atomic_load(q.amax_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(q.amax_out, mx);
+  }
   }
 }
 
@@ -2854,8 +2860,20 @@ extern "C" int rac_adam_frag_multi(const rac_adam_frag_job* jobs, int32_t n_jobs
               "rac_adam_frag_multi: bad args");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_frag_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     jobs, n_jobs, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+                     jobs, n_jobs, (long)total_blocks, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
   return check_launch("rac_adam_frag_multi");
+}
+
+extern "C" int rac_adam_frag_multi_bounded(const rac_adam_frag_job* jobs, int32_t n_jobs, int64_t total_blocks,
+                                           int32_t max_workgroups, float lr, float beta1, float beta2, float eps, int32_t step,
+                                           void* stream) {
+  RAC_REQUIRE(jobs && n_jobs > 0 && total_blocks > 0 && total_blocks < (1L << 31) && step >= 1 && max_workgroups >= 1,
+              "rac_adam_frag_multi_bounded: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long grid = total_blocks < max_workgroups ? total_blocks : max_workgroups;
+  hipLaunchKernelGGL(adam_frag_multi_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), jobs,
+                     n_jobs, (long)total_blocks, beta1, beta2, eps, (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)));
+  return check_launch("rac_adam_frag_multi_bounded");
 }
 
 extern "C" int rac_amax_bound(uint32_t* exact, uint32_t* bound, const int32_t* idx, int32_t n, float margin, void* stream) {

@@ -507,7 +507,27 @@ def _wp_upload(jobs, device):
     return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
 
 
-# optim.ShardedAdam while the all-gather of the updated parameters is in flight: `ready(param)` says whether a parameter's
+_ADAM_SIDE = {"stream": None}  # fused_adam_step(late=...): the late weights' update runs here
+ADAM_LATE_WGS = int(os.environ.get("RAC_ADAM_LATE_WGS", "512"))  # ... on this many workgroups (2 per CU)
+
+
+def low_priority_stream(dev):
+    """A HIP stream BELOW the default priority (torch offers only default and higher): its workgroups take the slots the
+    default-priority streams leave.  Falls back to a plain stream if the runtime refuses."""
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        lo, hi = C.c_int(0), C.c_int(0)
+        if hip.hipDeviceGetStreamPriorityRange(C.byref(lo), C.byref(hi)) == 0 and lo.value > 0:
+            with torch.cuda.device(dev):
+                h = C.c_void_p()
+                if hip.hipStreamCreateWithPriority(C.byref(h), C.c_uint(1), C.c_int(lo.value)) == 0 and h.value:  # 1: non-blocking
+                    return torch.cuda.ExternalStream(h.value, device=dev)
+    except OSError:
+        pass
+    return torch.cuda.Stream(device=dev)
+
+# optim.ShardedAdam while the all-gather of the updated parameters is in flight (or optim.FusedAdam while its late weights'
+# update runs on the side stream): `ready(param)` says whether a parameter's
 # buckets have been waited for (its new values may be read by kernels enqueued now).  _wp_refresh leaves the others stale.
 PARAM_GATE = None
 
@@ -615,11 +635,17 @@ def adam_step_bound(beta1: float, beta2: float):
     return _ADAM_BOUNDS[key]
 
 
-def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
+def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     """One optimiser step over the flat buffers with the registered split-precision weights' parts refreshed in the
     same pass.  False (nothing launched) when that is not possible yet -- a weight whose parts or maximum are not
     current (first steps, new registrations), no registered weight inside `flat`, an unbounded Adam step: the caller
-    then takes rac_adam_step and the parts are refreshed lazily."""
+    then takes rac_adam_step and the parts are refreshed lazily.
+
+    `late` = (first flat element, {data_ptr of the weights that may be late}): the registered weights behind that element
+    whose memory is in the set are updated on a SIDE stream (behind everything enqueued so far) and the call returns
+    (event, [(offset, numel)]) -- the event the consumer of those weights must wait for -- instead of True: the pass is
+    bound by HBM (8.6 GB per step), the next step's encoder forward is many small launches bound by latency; the caller
+    (optim.FusedAdam with `overlap_next_forward`) makes the model wait behind its encoder."""
     global PARAM_EPOCH
     if not ADAM_FUSED:
         return False
@@ -646,7 +672,8 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
     if not covered:
         return False
     covered.sort(key=lambda c: c[0])
-    sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+    is_late = (lambda off, w: late is not None and off >= late[0] and w.data_ptr() in late[1])
+    sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(), None if late is None else (late[0], tuple(sorted(late[1]))),
            tuple((off, ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items()))) for off, ent, _ in covered))
     plan = st["adam_plan"]
     if plan is not None and plan["sig"] == sig and plan.get("unsupported"):
@@ -654,7 +681,16 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
     if plan is None or plan["sig"] != sig:
         lib = _lib.load()
         jobs = (AdamFragJob * len(covered))()
-        ranges, blocks, pos = [], 0, 0
+        n_early = sum(1 for off, _, w in covered if not is_late(off, w))
+        slot_of = {}  # the early jobs first in the table, the late ones behind them (each group numbers its own blocks)
+        ne = nl = 0
+        for j, (off, _, w) in enumerate(covered):
+            if is_late(off, w):
+                slot_of[j], nl = n_early + nl, nl + 1
+            else:
+                slot_of[j], ne = ne, ne + 1
+        ranges, blocks, late_blocks, pos = [], 0, 0, 0
+        late_spans = []
         for i, (off, ent, w) in enumerate(covered):
             co, ci, k, _ = w.shape
             n = w.numel()
@@ -666,12 +702,17 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
             if off > pos:
                 ranges.append((pos // 4, (off - pos) // 4))
             pos = off + n
-            jobs[i] = AdamFragJob(p=base + 4 * off, g=grad.data_ptr() + 4 * off, m=m.data_ptr() + 4 * off,
-                                  v=v.data_ptr() + 4 * off, scale_slot=ptr(ent.slot),
-                                  amax_out=ptr(st["exact"][ent.idx:ent.idx + 1]), parts_fwd=ptr(ent.parts.get(False)),
-                                  parts_t=ptr(ent.parts.get(True)), part_stride=n, Cout=co, Cin=ci, ksize=k, reserved=0,
-                                  block_begin=blocks)
-            blocks += lib.rac_weight_frag_blocks(co, ci, k)
+            lt = is_late(off, w)
+            jobs[slot_of[i]] = AdamFragJob(p=base + 4 * off, g=grad.data_ptr() + 4 * off, m=m.data_ptr() + 4 * off,
+                                           v=v.data_ptr() + 4 * off, scale_slot=ptr(ent.slot),
+                                           amax_out=ptr(st["exact"][ent.idx:ent.idx + 1]), parts_fwd=ptr(ent.parts.get(False)),
+                                           parts_t=ptr(ent.parts.get(True)), part_stride=n, Cout=co, Cin=ci, ksize=k, reserved=0,
+                                           block_begin=late_blocks if lt else blocks)
+            if lt:
+                late_blocks += lib.rac_weight_frag_blocks(co, ci, k)
+                late_spans.append((off, n))
+            else:
+                blocks += lib.rac_weight_frag_blocks(co, ci, k)
         if pos < flat.numel():
             ranges.append((pos // 4, (flat.numel() - pos + 3) // 4))
         rjobs = (AdamRange * max(1, len(ranges)))()
@@ -681,20 +722,37 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step) -> bool:
             rblocks += _cdiv(n4, 1024)
         plan = st["adam_plan"] = {
             "sig": sig, "jobs": _wp_upload(jobs, dev), "n_jobs": len(covered), "blocks": blocks,
+            "n_early": n_early, "late_blocks": late_blocks, "late_spans": late_spans,
             "ranges": _wp_upload(rjobs, dev), "n_ranges": len(ranges), "rblocks": rblocks,
             "idx": torch.tensor([ent.idx for _, ent, _ in covered], device=dev, dtype=torch.int32)}
     sp = stream_ptr()
     call("rac_amax_bound", ptr(st["exact"]), ptr(st["slots"]), ptr(plan["idx"]), plan["n_jobs"],
          float(lr) * bound * 1.01, sp)
-    call("rac_adam_frag_multi", ptr(plan["jobs"]), plan["n_jobs"], plan["blocks"], float(lr), float(beta1), float(beta2),
-         float(eps), int(step), sp)
+    n_early, n_late = plan["n_early"], plan["n_jobs"] - plan["n_early"]
+    if n_early:
+        call("rac_adam_frag_multi", ptr(plan["jobs"]), n_early, plan["blocks"], float(lr), float(beta1), float(beta2),
+             float(eps), int(step), sp)
     if plan["n_ranges"]:
         call("rac_adam_ranges", ptr(flat), ptr(grad), ptr(m), ptr(v), ptr(plan["ranges"]), plan["n_ranges"],
              plan["rblocks"], float(lr), float(beta1), float(beta2), float(eps), int(step), sp)
+    done = None
+    if n_late:
+        main = torch.cuda.current_stream()
+        if _ADAM_SIDE["stream"] is None or _ADAM_SIDE["stream"].device != dev:
+            _ADAM_SIDE["stream"] = low_priority_stream(dev)
+        side = _ADAM_SIDE["stream"]
+        ready = torch.cuda.Event()
+        ready.record(main)  # every gradient, the scale bounds and whatever read the old weights precede the side launch
+        side.wait_event(ready)
+        with torch.cuda.stream(side):
+            call("rac_adam_frag_multi_bounded", ptr(plan["jobs"]) + n_early * C.sizeof(AdamFragJob), n_late,
+                 plan["late_blocks"], ADAM_LATE_WGS, float(lr), float(beta1), float(beta2), float(eps), int(step), stream_ptr())
+            done = torch.cuda.Event()
+            done.record(side)
     PARAM_EPOCH += 1
     for _, ent, w in covered:  # their parts and maxima already describe the new values
         ent.tag = _wp_tag(w)
-    return True
+    return (done, list(plan["late_spans"])) if done is not None else True
 
 
 def weight_parts(weight: torch.Tensor, transposed: bool = False):

@@ -12,12 +12,51 @@ from . import _lib, ops
 
 
 class FusedAdam(torch.optim.Optimizer):
+    # The pass is bound by HBM (8.6 GB per step at g512: ~1.7 ms); the forward pass that follows starts with the encoder's
+    # many small launches (2.2 ms, bound by latency, reading only the encoder's parameters).  With `overlap_next_forward` the
+    # update of the large conv weights BEHIND the encoder's (the ConvLSTMs', the decoder's: 90 % of the bytes) runs on a side
+    # stream and the model waits for it behind its encoder (SVGConvModel._encode through ops.PARAM_GATE, as for the sharded
+    # optimiser's all-gather): same arithmetic, same bits.  Until that wait the late weights hold old values on the main
+    # stream -- so this is OFF unless a training loop that owns every reader of the parameters turns it on
+    # (PredictionTrainer.train, bench.py); `state_dict`, `load_state_dict` and `wait_params()` wait.
+    overlap_next_forward = False
+
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         params = list(model.parameters())
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False))
         self._model = model
         self._steps = 0
         self._m = self._v = None
+        self._late = None  # (event, [(offset, numel)]) of the late weights' update in flight
+
+    def wait_params(self, upto: int = None):
+        """Make the current stream wait for the late weights' update (`upto`: only if a late weight lies below that flat
+        element -- none does: the late group starts behind the encoder)."""
+        if self._late is None:
+            return
+        if upto is not None and all(off >= upto for off, _ in self._late[1]):
+            return
+        torch.cuda.current_stream().wait_event(self._late[0])
+        self._late = None
+        if ops.PARAM_GATE is self:
+            ops.PARAM_GATE = None
+
+    def ready(self, t: torch.Tensor) -> bool:
+        if self._late is None:
+            return True
+        flat, _ = self._model.flat_parameters()
+        lo = (t.data_ptr() - flat.data_ptr()) // 4
+        hi = lo + t.numel()
+        return all(not (off < hi and lo < off + n) for off, n in self._late[1])
+
+    def _late_group(self):
+        """(first flat element, data pointers) of the weights that may be updated late: the large conv weights whose
+        gradient the next step's lazy zero_grad does not touch, behind the encoder's parameters."""
+        model = self._model
+        lazy = getattr(model, "_lazy_params", None)
+        if not self.overlap_next_forward or not lazy or not hasattr(model, "_encoder_extent"):
+            return None
+        return model._encoder_extent(), frozenset(p.data_ptr() for p in lazy)
 
     def _moments(self):
         flat, _ = self._model.flat_parameters()
@@ -37,7 +76,13 @@ class FusedAdam(torch.optim.Optimizer):
             ops.finish_grads()
         # one pass that also writes the next step's operand parts of the split-precision conv weights, when their parts
         # and maxima are current (every step after the first); plain Adam over the whole buffer otherwise
-        if ops.fused_adam_step(flat, grad, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps):
+        self.wait_params()  # (a late update never outlives the forward pass that follows it; a caller without one: here)
+        res = ops.fused_adam_step(flat, grad, m, v, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self._steps,
+                                  late=self._late_group())
+        if res:
+            if res is not True:
+                self._late = res
+                ops.PARAM_GATE = self
             return
         ops.PARAM_EPOCH += 1  # invalidates caches derived from the parameters (padded weight copies, operand parts)
         _lib.call("rac_adam_step", flat.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), flat.numel(),
@@ -51,12 +96,14 @@ class FusedAdam(torch.optim.Optimizer):
             yield p, torch.as_strided(m, p.shape, p.stride(), off), torch.as_strided(v, p.shape, p.stride(), off)
 
     def state_dict(self):
+        self.wait_params()
         if self._steps:
             for p, mv, vv in self._views():
                 self.state[p] = {"step": torch.tensor(float(self._steps)), "exp_avg": mv, "exp_avg_sq": vv}
         return super().state_dict()
 
     def load_state_dict(self, state_dict):
+        self.wait_params()
         super().load_state_dict(state_dict)
         steps = 0
         for p, mv, vv in self._views():

@@ -608,6 +608,10 @@ class PredictionTrainer(object):
         switch, default off) a GIF of generations is written per epoch / evaluation (`plot`)."""
         cf = self._config
         self._step = self._load_checkpoint(cf.dynamics_model_ckpt)
+        # this loop owns every reader of the parameters between two steps (forward passes and checkpoints, which wait):
+        # the optimiser may finish the large weights' update under the next step's encoder (optim.FusedAdam)
+        if os.environ.get("RAC_ADAM_OVERLAP", "1") == "1" and isinstance(self.optimizer, FusedAdam):
+            self.optimizer.overlap_next_forward = True
         if batch_generator is None:
             batch_generator, test_loader = self._setup_data()
             transfer_loader = transfer_loader or getattr(self, "transfer_loader", None)
@@ -681,6 +685,7 @@ class PredictionTrainer(object):
         that assemble the full Adam moments (ShardedAdam.state_dict: all-gathers) and waits for the parameter all-gather of
         the last step, so that the parameters rank 0 clones are the updated ones."""
         opt_sd = None
+        self.optimizer.wait_params()  # (parameters whose update is still in flight: FusedAdam's late group, an all-gather)
         if isinstance(self.optimizer, ShardedAdam):
             opt_sd = self.optimizer.state_dict()  # collective: before the rank check
         if _dist_on() and dist.get_rank() != 0:

@@ -989,11 +989,28 @@ def test_fused_adam_step_writes_the_next_parts(dev):
             refc = F.conv2d(from_map(x).double(), w.detach().cpu().double(), None, 1, k // 2)
             assert relerr(from_map(got), refc) < 2e-6
         grad.mul_(1.7)
+    # `late`: the weights behind an offset (here the second and third) are updated on a side stream; after the returned
+    # event the buffers and the parts are the bits of the one-stream pass
+    keep = [t.clone() for t in (flat, m, v)]
+    assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4) is True
+    want = [t.clone() for t in (flat, m, v)] + [q.clone() for w in ws for q in ops._WP_ENTRIES[id(w)].parts.values()]
+    want_slots = [ops._WP_ENTRIES[id(w)].slot.clone() for w in ws]
+    for t, k0 in zip((flat, m, v), keep):
+        t.copy_(k0)
+    for w in ws:  # (the restored weights' parts: the lazy path, as after load_state_dict)
+        ops.weight_parts(w)
+    off1 = (ws[1].data_ptr() - flat.data_ptr()) // 4
+    res = ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4, late=(off1, frozenset(w.data_ptr() for w in ws[1:])))
+    assert res is not True and res and sorted(res[1]) == sorted(((w.data_ptr() - flat.data_ptr()) // 4, w.numel()) for w in ws[1:])
+    torch.cuda.current_stream().wait_event(res[0])
+    got = [flat, m, v] + [q for w in ws for q in ops._WP_ENTRIES[id(w)].parts.values()]
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+    assert all(torch.equal(ops._WP_ENTRIES[id(w)].slot, sl) for w, sl in zip(ws, want_slots))
     # a weight changed behind the parts' back (load_state_dict ...): the fused step declines, the lazy refresh repairs
     ws[0].mul_(2.0)
-    assert not ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
+    assert not ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 5)
     ops.weight_parts(ws[0])
-    assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4)
+    assert ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 5)
 
 
 def test_bound_scaled_weight_parts_cost_at_most_one_bit(dev):
