@@ -170,6 +170,25 @@ def pmc_traffic(tag, kernel_substr, workgroups):
     return None, None
 
 
+def pmc_tail(workload):
+    """HBM GB/s of the memory-bound tail kernels (`roofline.tail`): bytes per launch from the newest committed PMC profile,
+    durations from the same profile set's kernel trace (profiles/*_pmc_traffic.json, key "tail"; tools/profile_pack.py)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")))
+    if not files:
+        return None
+    try:
+        rows = [r for r in json.load(open(files[-1])).get("tail", []) if r["workload"] == workload]
+    except (OSError, ValueError, KeyError):
+        return None
+    if not rows:
+        return None
+    out = {r["kernel"]: {"bytes": r["hbm_side_bytes_per_launch"], "avg_ms": r["avg_us"] / 1e3, "gbps": r["gbps"],
+                         "frac_of_8TBps": r["frac_of_8TBps"]} for r in rows}
+    out["source"] = os.path.relpath(files[-1], ROOT)
+    return out
+
+
 def profile_summary(prof, flops_per_pixel_row):
     """Average HIP-event duration of the profiled kernel and its algorithmic FLOP rate."""
     if not prof["events"]:
@@ -660,6 +679,9 @@ def main():
         if not (args.h48 or args.cfg5 or args.group_norm):
             out["roofline"]["kernel"] = ("conv16_tile_kernel: FWD 5x5 ConvLSTM gate conv as GEMM (M=%d, N=2048, K=25600)"
                                          % (train["cf"].batch_size * 64))
+        tail = pmc_tail("train")
+        if tail:
+            out["roofline"]["tail"] = tail
         out["time_breakdown_ms"] = train["phases"]
         if distributed:
             out["ranks"] = {"train_ms_per_step": train["rank_ms_per_step"]}
@@ -688,6 +710,9 @@ def main():
                    "frac_of_split_peak": cem["tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
                    "gate_gemm": gate, "get_action": cem["get_action"],
                    "per_gpu_value": cem["rollouts_per_s"] / world, "efficiency_vs_n1": None}
+        tail = pmc_tail("cem")
+        if tail:
+            cem_obj["tail"] = tail
         if distributed:
             cem_obj["ranks"] = {"s_per_iteration": cem["rank_s_per_iter"], "cost_allgather_ms": cem["cost_allgather_ms"]}
         if train is None:

@@ -1148,12 +1148,14 @@ def plan_wgrad_split(tiles: int, groups: int) -> int:
     forced = os.environ.get("RAC_WGRAD_SPLITK")
     if forced:
         return max(1, min(int(forced), groups))
-    if tiles >= 1024:
+    if tiles >= 768:
         # two or more rounds of workgroups without splitting K: a split only evens out the last round, and pays for it
         # with a slab of the whole gradient written, read back and added (the 5x5 gate weights: 210 MB per slab).  Measured
         # (round 4, T = 5 steps of B = 16, g 512, launch + combine): 5x5 (1280 tiles) 1.21 ms unsplit against 1.31 (x 2),
         # 1.40 (x 3), 1.50 (x 4); in the train step 1.03 ms against 0.96 + 0.12.  The 3x3 gate weights (768 tiles = 1.5
-        # rounds) keep their x 2: 0.43 + 0.03 ms in the step against 0.50 unsplit.
+        # rounds) kept a x 2 in round 4 (0.43 + 0.03 ms against 0.50 unsplit); with round 5's kernel the launch is short
+        # enough that the slab costs more than the uneven last round: 0.526-0.533 ms unsplit against 0.546-0.554 (x 2),
+        # 0.575 (x 3) for launch + combine (tools/bench_gemm.py wgrad 16 512 3, T = 5).
         return 1
     best, best_eff = 1, 0.0
     for ns in range(1, min(groups, 64) + 1):

@@ -29,12 +29,19 @@ def short(name):
     return re.sub(r"\(.*", "", name.replace("rac::", "").replace("void ", ""))
 
 
-def counters(d):
+# the HBM-bound tail of both workloads (bench.py's roofline.tail): bytes from the PMC passes, durations from the kernel stats
+TAIL = {"train": ("adam_frag_multi_kernel", "adam_ranges_kernel", "bn_bwd_reduce_rows_kernel", "bn_bwd_apply_rows_kernel",
+                  "affine_act_kernel4", "slab_reduce_stats_rows_kernel", "lstm_cell_bwd_srcs_kernel", "lstm_cell_fwd_kernel",
+                  "head_dgrad_kernel"),
+        "cem": ("first16_kernel", "head16_kernel", "cem_step_tail_kernel")}
+
+
+def counters(d, kernels=KERNELS):
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
-            if k.startswith(KERNELS):
+            if k.startswith(kernels):
                 wg = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
                 agg[(k, wg)][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
@@ -70,10 +77,36 @@ def main(src, tag):
             rows.append({"kernel": key[0], "workgroups": key[1], "FETCH_SIZE_KB_raw": fk, "WRITE_SIZE_KB": wk,
                          "hbm_side_bytes_per_launch": (2 * fk + wk) * 1024})
         res[name] = sorted(rows, key=lambda r: -r["hbm_side_bytes_per_launch"])[:8]
+    # ---- the memory-bound tail: bytes per launch (all launches of a kernel name pooled, weighted by their count) and GB/s
+    tail = []
+    for wl, names in TAIL.items():
+        stats = os.path.join(src, f"stats_{wl}", "run_kernel_stats.csv")
+        dur = {}
+        if os.path.exists(stats):
+            for r in csv.DictReader(open(stats)):
+                dur[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]))
+        f = counters(os.path.join(src, f"pmc_FETCH_SIZE_{wl}"), names)
+        w = counters(os.path.join(src, f"pmc_WRITE_SIZE_{wl}"), names)
+        for name in names:
+            fk = [(k, c) for k, c in f.items() if k[0].startswith(name)]
+            if not fk:
+                continue
+            # launches of different grid sizes: average over the launches (the counters() entries are per (kernel, grid) means)
+            fetch = sum(c.get("FETCH_SIZE", 0.0) for _, c in fk) / len(fk)
+            write = sum(w.get(k, {}).get("WRITE_SIZE", 0.0) for k, _ in fk) / len(fk)
+            d = next((v for k, v in dur.items() if k.startswith(name)), None)
+            if d is None:
+                continue
+            nbytes = (2 * fetch + write) * 1024
+            tail.append({"workload": wl, "kernel": name, "hbm_side_bytes_per_launch": nbytes, "avg_us": d[0] / 1e3,
+                         "launches_in_trace": d[1], "gbps": nbytes / d[0], "frac_of_8TBps": nbytes / d[0] / 8000.0})
+    res["tail"] = tail
     res["_note"] = ("rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes. Bytes = (2*FETCH_SIZE + "
                     "WRITE_SIZE)*1024 (gfx950 FETCH_SIZE reports half of a wide coalesced read). L2<->fabric bytes; "
                     "Infinity-Cache hits are included. gemm_train / gemm_cem: tools/bench_gemm.py fwd at M=1024 / 64000; "
-                    "wgrad5 / wgrad3: the time-batched (T=5, B=16) ConvLSTM weight gradients.")
+                    "wgrad5 / wgrad3: the time-batched (T=5, B=16) ConvLSTM weight gradients.  tail: the memory-bound kernels of both workloads -- "
+                    "bytes per launch averaged over a kernel's launch shapes (PMC passes of bench.py), average duration from the "
+                    "kernel-trace run of the same build (weight gradients in order), GB/s = bytes / duration.")
     json.dump(res, open(os.path.join(prof, f"{tag}_pmc_traffic.json"), "w"), indent=1)
     # ---- SQ summary
     out = io.StringIO()
