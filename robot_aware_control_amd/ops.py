@@ -1929,6 +1929,8 @@ def recurrent_core_ok(h_all, g: int, z: int, nv: int, cells, head, frame_conv) -
 # ends; tensors handed from one stream to another inside a region stay referenced until its end (the caching allocator
 # reuses a freed block in its OWN stream's order only).
 CHAIN_STREAMS = os.environ.get("RAC_CHAIN_STREAMS", "0") == "1"
+CORE_LAYER_MAJOR = os.environ.get("RAC_CORE_LAYER_MAJOR", "1") == "1"  # a layer's T launches back to back (RecurrentCore)
+CORE_BATCH_THIN = os.environ.get("RAC_CORE_BATCH_THIN", "1") == "1"    # ... and the thin convs between the chains once over all steps
 _CHAIN = {"dev": None, "prior": None, "post": None}
 
 
@@ -2001,7 +2003,6 @@ class RecurrentCore(torch.autograd.Function):
         cells = plan["cells"]  # {L: (cell0, cell1)}
         head_w, head_b = plan["head"]
         fconv = plan["frame_conv"]
-        tape = []
 
         def run_cell(L, l, x, h_out=None):
             cell = cells[L][l].gates
@@ -2034,46 +2035,127 @@ class RecurrentCore(torch.autograd.Function):
         weight_parts(head_w)
         weight_parts(fw_pad)
         region = _ChainRegion(dev, True)
-        try:
+        tape = [dict() for _ in range(T)]
+        h0 = {L: [None] * T for L in ("prior", "post", "fp")}
+        z_all, xf_all, z_ready = [None] * T, [None] * T, [None] * T
+
+        # the pieces of one time step, each a closure over t (a layer of a ConvLSTM depends on its own previous step and on
+        # the layer BELOW at the same step, never on the layer above)
+        def prior_l0(t):
+            h0["prior"][t], tape[t]["prior0"] = run_cell("prior", 0, retag(prior_steps[t], amax_tag(prior_all)))
+
+        def prior_l1(t):
+            _, tape[t]["prior1"] = run_cell("prior", 1, h0["prior"][t], hq_s[t])
+
+        def post_l0(t):
+            h0["post"][t], tape[t]["post0"] = run_cell("post", 0, retag(post_steps[t], amax_tag(post_all)))
+
+        def post_l1(t):
+            sp = stream_ptr()
+            h_post, tape[t]["post1"] = run_cell("post", 1, h0["post"][t])
+            slabs, split, stride = conv_forward_split(h_post, None, head_w, want_slabs=True)
+            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_s[t]), ptr(lv_s[t]), M, 2 * z, z,
+                 None, None, sp)
+            z_t = torch.empty_like(mu_s[t])
+            call("rac_reparam_fwd", ptr(mu_s[t]), ptr(lv_s[t]), ptr(eps_all[t]), ptr(z_t), z_t.numel(), sp)
+            z_all[t] = z_t
+            tape[t].update(h_post=h_post, eps=eps_all[t])
+
+        def fp_in(t):
+            sp = stream_ptr()
+            v3 = list(vs[t]) + [None] * (3 - len(vs[t]))
+            cat = torch.empty((B, H, W, ct + pad), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
+                 v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
+                 ptr(h_steps[t]), g, ptr(z_all[t]), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
+            tag_amax(cat, slot)
+            xf_all[t] = conv_forward_split(cat, None, fw_pad, fconv.bias)
+            tape[t]["cat"] = cat
+
+        def fp_l0(t):
+            h0["fp"][t], tape[t]["fp0"] = run_cell("fp", 0, xf_all[t])
+
+        def fp_l1(t):
+            _, tape[t]["fp1"] = run_cell("fp", 1, h0["fp"][t], hp_s[t])
+
+        batch_thin = CORE_LAYER_MAJOR and CORE_BATCH_THIN and not region.enabled and T > 1
+        thin = {}
+
+        def post_l1_cell(t):  # (batched form: the posterior's top layer writes slice t of one tensor)
+            if t == 0:
+                thin["h_post"] = torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32)
+            h_post = step(thin["h_post"])[t]
+            _, tape[t]["post1"] = run_cell("post", 1, h0["post"][t], h_post)
+            tape[t]["h_post"] = h_post
+
+        def post_head_all():
+            # mu | logvar head and the reparameterisation of ALL steps in one launch each (M = T B H W rows instead of T launches
+            # of B H W: five 20 us launches at 0.07 of the pipe become one at ~0.4)
+            sp = stream_ptr()
+            h_all_post = tag_amax(thin["h_post"], one)
+            slabs, split, stride = conv_forward_split(h_all_post, None, head_w, want_slabs=True)
+            call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_all), ptr(lv_all), T * M, 2 * z, z,
+                 None, None, sp)
+            eps_stack = torch.stack(eps_all)
+            zs = torch.empty_like(mu_all)
+            call("rac_reparam_fwd", ptr(mu_all), ptr(lv_all), ptr(eps_stack), ptr(zs), zs.numel(), sp)
+            thin.update(eps=eps_stack, z=zs)
             for t in range(T):
-                rec = {}
-                with region.on("prior"):
-                    x = retag(prior_steps[t], amax_tag(prior_all))
-                    x, rec["prior0"] = run_cell("prior", 0, x)
-                    _, rec["prior1"] = run_cell("prior", 1, x, hq_s[t])
-                with region.on("post"):
-                    sp = stream_ptr()
-                    x = retag(post_steps[t], amax_tag(post_all))
-                    x, rec["post0"] = run_cell("post", 0, x)
-                    h_post, rec["post1"] = run_cell("post", 1, x)
-                    slabs, split, stride = conv_forward_split(h_post, None, head_w, want_slabs=True)
-                    call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_s[t]), ptr(lv_s[t]), M, 2 * z, z,
-                         None, None, sp)
-                    eps = eps_all[t]
-                    z_t = torch.empty_like(mu_s[t])
-                    call("rac_reparam_fwd", ptr(mu_s[t]), ptr(lv_s[t]), ptr(eps), ptr(z_t), z_t.numel(), sp)
-                    z_ready = region.event("post")
-                region.keep.append(z_t)  # (allocated in the posterior's stream, read by the frame predictor's)
-                region.wait("fp", z_ready)
-                sp = stream_ptr()
-                v3 = list(vs[t]) + [None] * (3 - len(vs[t]))
-                cat = torch.empty((B, H, W, ct + pad), device=dev, dtype=torch.float32)
-                slot = amax_slot(dev)
-                call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
-                     v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
-                     ptr(h_steps[t]), g, ptr(z_t), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
-                tag_amax(cat, slot)
-                x = conv_forward_split(cat, None, fw_pad, fconv.bias)
-                x, rec["fp0"] = run_cell("fp", 0, x)
-                _, rec["fp1"] = run_cell("fp", 1, x, hp_s[t])
-                rec.update(cat=cat, h_post=h_post, eps=eps)
-                tape.append(rec)
+                tape[t]["eps"] = eps_stack[t]
+
+        def fp_in_all():
+            # cat[tile(v) | h_t | z_t] and the frame predictor's input conv over all steps at once
+            sp = stream_ptr()
+            v3 = [torch.cat([vs[t][k] for t in range(T)]) if k < len(vs[0]) else None for k in range(3)]
+            cat = torch.empty((T * B, H, W, ct + pad), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
+                 v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
+                 ptr(h_all), g, ptr(thin["z"]), z, pad, ptr(cat), T * B, H * W, ptr(slot), 0, sp)
+            tag_amax(cat, slot)
+            xf = conv_forward_split(cat, None, fw_pad, fconv.bias)
+            thin.update(cat=cat, xf=xf)
+            xs = step(xf)
+            for t in range(T):
+                xf_all[t] = retag(xs[t], amax_tag(xf))
+
+        try:
+            if region.enabled:  # one stream per chain: time-major, the frame predictor's step t behind the posterior's
+                for t in range(T):
+                    with region.on("prior"):
+                        prior_l0(t), prior_l1(t)
+                    with region.on("post"):
+                        post_l0(t), post_l1(t)
+                        z_ready[t] = region.event("post")
+                    region.keep.append(z_all[t])  # (allocated in the posterior's stream, read by the frame predictor's)
+                    region.wait("fp", z_ready[t])
+                    fp_in(t), fp_l0(t), fp_l1(t)
+            elif CORE_LAYER_MAJOR:
+                # LAYER-major: a layer's T launches back to back.  Its weights (5x5 gate convs: 210 MB of operand parts, 3x3:
+                # 75 MB) then meet the Infinity Cache from the second launch on instead of coming from HBM every time (in
+                # time-major order 855 MB of other weights pass between two uses); same kernels, same operands, same bits.
+                # `batch_thin`: the two thin convs between the chains (posterior head, frame predictor's input conv) once
+                # over all steps -- every step's operands exist before the first is needed in this order.
+                order = ((prior_l0, prior_l1, post_l0, post_l1_cell, post_head_all, fp_in_all, fp_l0, fp_l1) if batch_thin
+                         else (prior_l0, prior_l1, post_l0, post_l1, fp_in, fp_l0, fp_l1))
+                for piece in order:
+                    if piece in (post_head_all, fp_in_all):
+                        piece()
+                        continue
+                    for t in range(T):
+                        piece(t)
+            else:
+                for t in range(T):
+                    for piece in (prior_l0, prior_l1, post_l0, post_l1, fp_in, fp_l0, fp_l1):
+                        piece(t)
         finally:
             region.join()
         # (the node keeps what backward reads, not the caller's closures: `eps_fn` is a bound method of the model, and a
         # model -> output tensor -> grad_fn -> plan -> model cycle would keep a dropped model's 4 GB alive until a full GC)
         ctx.plan = {k: plan[k] for k in ("g", "z", "nv", "cells", "head", "frame_conv")}
         ctx.tape = tape
+        ctx.thin = thin if batch_thin else None
         ctx.lv_all = lv_all
         ctx.shape = (T, B, H, W)
         plan["final_state"] = state
@@ -2131,60 +2213,128 @@ class RecurrentCore(torch.autograd.Function):
         weight_parts(fw_pad, transposed=True)
         region = _ChainRegion(dev, True)
         dz_ready = [None] * T
-        try:
-            for t in range(T - 1, -1, -1):
-                rec = tape[t]
-                # frame predictor: layer 1 (its h feeds the decoder), layer 0, then the input conv over cat[v | h_t | z_t]
-                ext = [_src(d_hpred[t], 1, g)] if d_hpred is not None else []
-                s1 = cell_bwd("fp", 1, rec["fp1"], ext)
-                s0 = cell_bwd("fp", 0, rec["fp0"], [s1])
-                dy_f = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
+        top = {L: [None] * T for L in ("prior", "post", "fp")}  # the top layer's data-gradient slabs per step
+        dheads = [None] * T
+
+        def fp_b1(t):  # frame predictor, layer 1 (its h feeds the decoder)
+            ext = [_src(d_hpred[t], 1, g)] if d_hpred is not None else []
+            top["fp"][t] = cell_bwd("fp", 1, tape[t]["fp1"], ext)
+
+        def fp_b0(t):  # ... layer 0, then the input conv over cat[v | h_t | z_t]
+            s0 = cell_bwd("fp", 0, tape[t]["fp0"], [top["fp"][t]])
+            dy_f = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            tag_amax(grad_sum([s0], dy_f, g, slot), slot)
+            dcat, n_c = conv_dgrad_slabs(dy_f, fw_pad, cpad)
+            dz_ready[t] = region.event("fp")  # the posterior's step t may start
+            conv_wgrad_split_acc(dy_f, tape[t]["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
+            bias_grad_acc(dy_f, fconv.bias)
+            grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
+            dcats[t] = (dcat, n_c)
+
+        def post_b1(t):  # posterior: reparameterisation + KL gradients -> merged head -> layer 1
+            rec = tape[t]
+            dcat, n_c = dcats[t]
+            dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
+            slot = amax_slot(dev)
+            call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(lv_s[t]), ptr(rec["eps"]),
+                 ptr(d_mu[t]) if d_mu is not None else None, ptr(d_lv[t]) if d_lv is not None else None, ptr(dy_h), M, z,
+                 ptr(slot), stream_ptr())
+            tag_amax(dy_h, slot)
+            dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
+            conv_wgrad_split_acc(dy_h, rec["h_post"], None, head_w, defer=True)
+            bias_grad_acc(dy_h, head_b)
+            dheads[t] = dhead
+            top["post"][t] = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
+
+        def post_b0(t):  # ... layer 0 -> its input conv's output
+            grad_sum([cell_bwd("post", 0, tape[t]["post0"], [top["post"][t]])], d_post_all[t], g, slot_post)
+
+        def prior_b1(t):  # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
+            ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
+            top["prior"][t] = cell_bwd("prior", 1, tape[t]["prior1"], ext)
+
+        def prior_b0(t):
+            grad_sum([cell_bwd("prior", 0, tape[t]["prior0"], [top["prior"][t]])], d_prior_all[t], g, slot_prior)
+
+        steps = range(T - 1, -1, -1)
+        layer_major = CORE_LAYER_MAJOR and not region.enabled
+        thin = ctx.thin  # forward ran the posterior head and the frame predictor's input conv over all steps at once
+        if thin is not None:
+            dy_f_all = torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32)
+            slot_f = amax_slot(dev)
+
+            def fp_b0(t):  # layer 0 of the frame predictor: the gradient of its input, slice t of one tensor  # noqa: F811
+                s0 = cell_bwd("fp", 0, tape[t]["fp0"], [top["fp"][t]])
+                grad_sum([s0], dy_f_all.view(T, B, H, W, g)[t], g, slot_f)
+
+            def fp_in_b_all():  # the input conv's data gradient, its weight gradient and d h, over all steps
+                tag_amax(dy_f_all, slot_f)
+                dcat, n_c = conv_dgrad_slabs(dy_f_all, fw_pad, cpad)
+                conv_wgrad_split_acc(dy_f_all, thin["cat"], None, fconv.weight, defer=True)
+                bias_grad_acc(dy_f_all, fconv.bias)
+                grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all, g)
+                thin["dcat"] = (dcat, n_c)
+
+            def post_head_b_all():  # reparameterisation + KL gradients and the merged head's data gradient, all steps
+                dcat, n_c = thin["dcat"]
+                dy_h = torch.empty((T * B, H, W, 2 * z), device=dev, dtype=torch.float32)
                 slot = amax_slot(dev)
-                tag_amax(grad_sum([s0], dy_f, g, slot), slot)
-                dcat, n_c = conv_dgrad_slabs(dy_f, fw_pad, cpad)
-                dz_ready[t] = region.event("fp")  # the posterior's step t may start
-                conv_wgrad_split_acc(dy_f, rec["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
-                bias_grad_acc(dy_f, fconv.bias)
-                grad_sum([_src(dcat, n_c, cpad, nv)], d_h_all[t], g)
-                dcats[t] = (dcat, n_c)
+                call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(ctx.lv_all), ptr(thin["eps"]),
+                     ptr(d_mu) if d_mu is not None else None, ptr(d_lv) if d_lv is not None else None, ptr(dy_h), T * M, z,
+                     ptr(slot), stream_ptr())
+                tag_amax(dy_h, slot)
+                dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
+                conv_wgrad_split_acc(dy_h, tag_amax(thin["h_post"], amax_one(dev)), None, head_w, defer=True)
+                bias_grad_acc(dy_h, head_b)
+                thin["dhead"] = (dhead, n_h)
+
+            def post_b1(t):  # noqa: F811  (its head gradient: rows t of the batched slabs)
+                dhead, n_h = thin["dhead"]
+                rows = dhead.view(n_h, T, M, g)[0, t]  # (first slab's rows of step t: the others follow at the slab stride)
+                src = (rows, n_h, dhead.numel() // n_h if n_h > 1 else 0, g, 0)
+                top["post"][t] = cell_bwd("post", 1, tape[t]["post1"], [src])
+        try:
+            if layer_major:  # (see forward: a layer's T data-gradient launches back to back)
+                for piece in (fp_b1, fp_b0):
+                    for t in steps:
+                        piece(t)
+                if thin is not None:
+                    fp_in_b_all()
+            else:
+                for t in steps:
+                    fp_b1(t), fp_b0(t)
             flush_deferred_wgrads_early(chain_ws("fp", [fconv.weight]))
             with region.on("post"):
-                for t in range(T - 1, -1, -1):
-                    rec = tape[t]
-                    dcat, n_c = dcats[t]
-                    region.wait("post", dz_ready[t])
-                    # posterior: reparameterisation + KL gradients -> merged head -> layer 1, layer 0 -> its input conv's output
-                    dy_h = torch.empty((B, H, W, 2 * z), device=dev, dtype=torch.float32)
-                    slot = amax_slot(dev)
-                    call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(lv_s[t]), ptr(rec["eps"]),
-                         ptr(d_mu[t]) if d_mu is not None else None, ptr(d_lv[t]) if d_lv is not None else None, ptr(dy_h), M, z,
-                         ptr(slot), stream_ptr())
-                    tag_amax(dy_h, slot)
-                    dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
-                    conv_wgrad_split_acc(dy_h, rec["h_post"], None, head_w, defer=True)
-                    bias_grad_acc(dy_h, head_b)
-                    q1 = cell_bwd("post", 1, rec["post1"], [_src(dhead, n_h, g, 0)])
-                    q0 = cell_bwd("post", 0, rec["post0"], [q1])
-                    grad_sum([q0], d_post_all[t], g, slot_post)
+                if layer_major:
+                    if thin is not None:
+                        post_head_b_all()
+                    for piece in (post_b1, post_b0):
+                        for t in steps:
+                            piece(t)
+                else:
+                    for t in steps:
+                        region.wait("post", dz_ready[t])
+                        post_b1(t), post_b0(t)
                 flush_deferred_wgrads_early(chain_ws("post", [head_w]))  # (ordered behind the posterior's stream)
             with region.on("prior"):
-                for t in range(T - 1, -1, -1):
-                    rec = tape[t]
-                    # prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
-                    ext = [_src(d_hprior[t], 1, g)] if d_hprior is not None else []
-                    p1 = cell_bwd("prior", 1, rec["prior1"], ext)
-                    p0 = cell_bwd("prior", 0, rec["prior0"], [p1])
-                    grad_sum([p0], d_prior_all[t], g, slot_prior)
+                if layer_major:
+                    for piece in (prior_b1, prior_b0):
+                        for t in steps:
+                            piece(t)
+                else:
+                    for t in steps:
+                        prior_b1(t), prior_b0(t)
                 if region.enabled:
                     flush_deferred_wgrads_early(chain_ws("prior", []))
         finally:
             region.join()
         # (the tape and the slabs handed between the chains are released only now: behind the join)
-        dcats = tape = None
+        dcats = tape = top = dheads = None
         # every operand of the core's weight gradients exists now: they start on the side stream, under the encoder's backward
         # (and of whatever else was recorded before: the prior's heads)
         flush_deferred_wgrads_early(None)
-        ctx.tape = ctx.plan = None
+        ctx.tape = ctx.plan = ctx.thin = None
         flat = lambda t_: t_.view((T * B, H, W, g))
         d_prior_all, d_post_all = tag_amax(flat(d_prior_all), slot_prior), tag_amax(flat(d_post_all), slot_post)
         return (None, flat(d_h_all), d_prior_all, d_post_all) + (None,) * (len(ctx.needs_input_grad) - 4)

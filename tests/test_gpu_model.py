@@ -243,7 +243,8 @@ def test_recurrent_core_matches_the_autograd_path(dev, tag, monkeypatch):
 
 
 def test_recurrent_core_chain_streams_same_bits(dev, monkeypatch):
-    """ops.RecurrentCore with its three ConvLSTM chains on three streams (ops.CHAIN_STREAMS) against the one-stream order,
+    """ops.RecurrentCore's schedules: layer-major in one stream (the default order), time-major in one stream, the thin convs
+    batched over the steps (the default), and its three ConvLSTM chains on three streams (ops.CHAIN_STREAMS),
     at the benchmarked width (g 512 / z 64, batch 16, five steps: launches long enough to overlap): the same kernels on the
     same operands, so outputs, input gradients and every weight gradient are the SAME BITS -- a missing event or a block the
     allocator recycled under a reader shows up here.  The core is replayed on the inputs one real train step gave it."""
@@ -285,8 +286,24 @@ def test_recurrent_core_chain_streams_same_bits(dev, monkeypatch):
         return ([o.detach().clone() for o in outs], [g_.clone() for g_ in gin],
                 [p_.grad.detach().clone() for p_ in seen["params"]], [b.grad.detach().clone() for b in biases])
 
+    # one stream, LAYER-major (a layer's T launches back to back), the thin convs per step: the reference schedule
+    monkeypatch.setattr(ops, "CORE_BATCH_THIN", False)
     ref = replay(False)
     assert all(float(w.abs().max()) > 0 for w in ref[2]) and all(float(g_.abs().max()) > 0 for g_ in ref[1])
+    # ... against time-major in one stream: the same bits
+    monkeypatch.setattr(ops, "CORE_LAYER_MAJOR", False)
+    got = replay(False)
+    monkeypatch.setattr(ops, "CORE_LAYER_MAJOR", True)
+    for a, b in zip(got[:3], ref[:3]):
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+    # ... against the default (the posterior head and the frame predictor's input conv once over all steps: one operand scale
+    # per batched tensor instead of one per step -- not the same bits, the same numbers)
+    monkeypatch.setattr(ops, "CORE_BATCH_THIN", True)
+    got = replay(False)
+    monkeypatch.setattr(ops, "CORE_BATCH_THIN", False)
+    for name, a, b in zip(("outputs", "input gradients", "weight gradients"), got[:3], ref[:3]):
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30)) < 2e-6, (name, i)
     for rep in range(3):
         got = replay(True)
         for name, a, b in zip(("outputs", "input gradients", "weight gradients"), got[:3], ref[:3]):
