@@ -683,6 +683,10 @@ def main():
         if tail:
             out["roofline"]["tail"] = tail
         out["time_breakdown_ms"] = train["phases"]
+        if out["time_breakdown_ms"] is not None and os.environ.get("RAC_ADAM_OVERLAP", "1") == "1":
+            # (optim.FusedAdam.overlap_next_forward: `adam` is the part on the main stream; the large weights' update runs on
+            # a side stream under the next step's `forward`, which it stretches)
+            out["time_breakdown_ms"]["note"] = "adam: main-stream part only; the large weights' update overlaps the next forward"
         if distributed:
             out["ranks"] = {"train_ms_per_step": train["rank_ms_per_step"]}
         if ddp_modes is not None:

@@ -509,6 +509,7 @@ def _wp_upload(jobs, device):
 
 _ADAM_SIDE = {"stream": None}  # fused_adam_step(late=...): the late weights' update runs here
 ADAM_LATE_WGS = int(os.environ.get("RAC_ADAM_LATE_WGS", "512"))  # ... on this many workgroups (2 per CU)
+ADAM_WGS = int(os.environ.get("RAC_ADAM_WGS", "0"))  # (experiments: the one-stream pass on a bounded grid too; 0 = one workgroup per block)
 
 
 def low_priority_stream(dev):
@@ -729,7 +730,10 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     call("rac_amax_bound", ptr(st["exact"]), ptr(st["slots"]), ptr(plan["idx"]), plan["n_jobs"],
          float(lr) * bound * 1.01, sp)
     n_early, n_late = plan["n_early"], plan["n_jobs"] - plan["n_early"]
-    if n_early:
+    if n_early and ADAM_WGS:
+        call("rac_adam_frag_multi_bounded", ptr(plan["jobs"]), n_early, plan["blocks"], ADAM_WGS, float(lr), float(beta1),
+             float(beta2), float(eps), int(step), sp)
+    elif n_early:
         call("rac_adam_frag_multi", ptr(plan["jobs"]), n_early, plan["blocks"], float(lr), float(beta1), float(beta2),
              float(eps), int(step), sp)
     if plan["n_ranges"]:
