@@ -287,6 +287,47 @@ def gen_train():
             save(f"train_cfg1_{tag}" + ("_sched" if sched else ""), **out)
 
 
+def gen_train_t5():
+    """F4b: one PredictionTrainer._train_step of a FIVE-frame window (n_future 4: the shape of BASELINE configs[1]'s
+    recurrence) at g 128 / z 16, batch 4 -- the size at which the HIP path takes its hand-scheduled recurrent core
+    (layer-major order, thin convs batched over the steps): losses, every parameter's gradient norm, gradient slices of
+    each ConvLSTM chain, the decoder and the encoder, and the weights' norms behind the optimiser step."""
+    from src.prediction.trainer import PredictionTrainer
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-4, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=6, randomize_bn_stats=False)
+    ns = ns_for(cfg, wandb=False, jobname="g", wandb_project="x", wandb_entity="x", wandb_group=None,
+                wandb_job_type=None, img_augmentation=False, seed=0, scheduled_sampling=False,
+                scheduled_sampling_k=4000, learned_robot_model=False)
+    tr = PredictionTrainer(ns)
+    tr.model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    tr.model.train()
+    tr._step = 0
+    data = syn.synth_video(seed=31, T=5, B=4)
+    eps = syn.synth_eps(seed=32, steps=4, B=4, z=16, h=8, w=8)
+    for e in eps:
+        _EPS.extend(e)
+    losses = tr._train_step(data)
+    assert not _EPS
+    out = {f"loss_{k}": v for k, v in losses.items()}
+    grads = dict(tr.model.named_parameters())
+    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    out["grad_norms"] = np.array([grads[k].grad.double().norm().item() for k in pk])
+    for name, key, sl in (("prior0", "prior.lstm.0.gates.weight", (slice(0, 4), slice(0, 8))),
+                          ("post1", "posterior.lstm.1.gates.weight", (slice(0, 4), slice(0, 8))),
+                          ("fp0", "frame_predictor.lstm.0.gates.weight", (slice(0, 4), slice(0, 8))),
+                          ("fp_in", "frame_pred_input_conv.weight", (slice(0, 8), slice(None))),
+                          ("head_mu", "posterior.mu_net.weight", (slice(0, 4), slice(0, 16))),
+                          ("dec", "decoder.upc4.1.main.0.weight", (slice(0, 4), slice(None))),
+                          ("enc", "encoder.c1.0.main.0.weight", (slice(None), slice(None)))):
+        if key in grads:
+            out[f"grad_{name}"] = grads[key].grad[sl].clone()
+            out[f"gradkey_{name}"] = np.array(key)
+    st = tr.model.state_dict()
+    keys = [k for k, _, kind in orc.param_spec(cfg) if kind != "bn_nbt"]
+    out["norms_after"] = np.array([st[k].double().norm().item() for k in keys])
+    save("train_t5_ra", **out)
+
+
 SWEEP = {
     # future robot state + black_robot_input + dontcare_mse with a robot pixel weight, two context frames, skip
     # connections frozen after the context (last_frame_skip False)
@@ -655,8 +696,10 @@ def gen_train_video():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "cem", "groupnorm", "eval", "sweep", "dataset",
+    which = sys.argv[1:] or ["forward", "shape", "losses", "train", "traint5", "cem", "groupnorm", "eval", "sweep", "dataset",
                              "simcem", "trainvideo", "hostcosts", "heatmap", "robot"]
+    if "traint5" in which:
+        gen_train_t5()
     if "heatmap" in which:
         gen_heatmap()
     if "simcem" in which:

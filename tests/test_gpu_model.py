@@ -186,6 +186,39 @@ def test_train_steps_vs_reference_golden(dev, golden_dir, name, tag, sched, seq,
         assert np.mean(dw <= 0.05 * cfg.lr * (1 + 3 * step)) >= 0.9
 
 
+def test_train_step_five_frames_vs_reference_golden(dev, golden_dir):
+    """One optimiser step of a FIVE-frame window (n_future 4, g 128 / z 16, batch 4) against the REAL reference's own numbers
+    (oracle/gen_golden.py::gen_train_t5): at this size the HIP path takes its hand-scheduled recurrent core -- layer-major
+    order, the thin convs between the chains batched over the steps (asserted) -- so this is that schedule against
+    PredictionTrainer._train_step itself, not against the oracle.  Measured (tools/dev_t5_vs_reference.py): losses within
+    1.4e-7, every parameter's gradient norm within 7.9e-4 (median 3.8e-5), the gradient slices within 3.9e-3 (the sign /
+    slope flips of the module docstring, here on 4 x 5 frames).  Held to: losses 1e-5, gradient norms 5e-3, slices 1.5e-2
+    -- tighter than the three-frame traces' bounds -- and the weights behind the Adam step."""
+    g = load(golden_dir, "train_t5_ra")
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-4, **FLAGSETS["ra"])
+    tr = make_trainer(cfg, orc.make_weights(cfg, seed=6, randomize_bn_stats=False), dev)
+    data = syn.synth_video(seed=31, T=5, B=4)
+    queue = [e for pair in syn.synth_eps(seed=32, steps=4, B=4, z=16, h=8, w=8) for e in pair]
+    tr.model.eps_source = lambda shape: queue.pop(0)
+    losses = tr._train_step(data)
+    assert not queue and tr.model.used_recurrent_core
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        np.testing.assert_allclose(losses[k], float(g[f"loss_{k}"]), rtol=1e-5)
+    grads = dict(tr.model.named_parameters())
+    pkeys = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    gn = np.array([grads[k].grad.double().norm().item() for k in pkeys])
+    np.testing.assert_allclose(gn, g["grad_norms"], rtol=5e-3, atol=1e-9)
+    for name in ("prior0", "post1", "fp0", "fp_in", "head_mu", "dec", "enc"):
+        key = str(g[f"gradkey_{name}"])
+        ref = torch.from_numpy(g[f"grad_{name}"])
+        sl = tuple(slice(0, n) for n in ref.shape)
+        assert rel(grads[key].grad[sl], ref) < 1.5e-2, name
+    sd = tr.model.state_dict()
+    keys = [k for k, _, kind in orc.param_spec(cfg) if kind != "bn_nbt"]
+    norms = np.array([sd[k].double().norm().item() for k in keys])
+    np.testing.assert_allclose(norms, g["norms_after"], rtol=2e-4)
+
+
 @pytest.mark.parametrize("seq", [True, False])
 def test_train_step_vs_oracle_g128(dev, seq, monkeypatch):
     """A wider model (g=128, B=4, 3 predicted frames): exercises the split-K and 128x128-tile paths."""

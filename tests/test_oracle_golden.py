@@ -167,6 +167,25 @@ def test_train_steps(golden_dir, name, tag, sched):
               atol=5e-6 * (1 + 3 * step))  # Adam's first steps move every weight by ~lr*sign(g): tiny grads make 5% of lr the noise floor
 
 
+def test_train_step_five_frames(golden_dir):
+    """The oracle against the reference's one-step trace of a five-frame window at g 128 / batch 4 (gen_train_t5): the
+    fixture the GPU path's recurrent core is held to (tests/test_gpu_model.py)."""
+    g = load(golden_dir, "train_t5_ra")
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-4, **FLAGSETS["ra"])
+    ts = orc.TrainState.create(cfg, orc.make_weights(cfg, seed=6, randomize_bn_stats=False))
+    losses = orc.train_step(ts, syn.synth_video(seed=31, T=5, B=4), syn.synth_eps(seed=32, steps=4, B=4, z=16, h=8, w=8), None)
+    for k in ("recon_loss", "robot_loss", "world_loss", "kld"):
+        close(losses[k], g[f"loss_{k}"], rtol=2e-5)
+    pk = [k for k, _, kind in orc.param_spec(cfg) if not orc.is_buffer(kind)]
+    close(np.array([ts.sd[k].grad.double().norm().item() for k in pk]), g["grad_norms"], rtol=1e-4, atol=1e-10)
+    for name in ("prior0", "post1", "fp0", "fp_in", "head_mu", "dec", "enc"):
+        ref = torch.from_numpy(g[f"grad_{name}"])
+        got = ts.sd[str(g[f"gradkey_{name}"])].grad[tuple(slice(0, n) for n in ref.shape)]
+        close(got, ref, rtol=1e-3, atol=1e-7)
+    keys = [k for k, _, kind in orc.param_spec(cfg) if kind != "bn_nbt"]
+    close(np.array([ts.sd[k].detach().double().norm().item() for k in keys]), g["norms_after"], rtol=1e-4)
+
+
 @pytest.mark.parametrize("tag", ["vanilla", "ra"])
 def test_cem(golden_dir, tag):
     g = load(golden_dir, f"cem_{tag}")
