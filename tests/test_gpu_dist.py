@@ -202,7 +202,7 @@ def test_bench_two_ranks_rehearsal():
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--cem-candidates", "64", "--cem-batch", "64", "--cem-iters", "1", "--cem-opt-iter", "2",
-           "--exact-steps", "2", "--side-steps", "1"]
+           "--no-exact", "--no-side"]  # (the exact-fp32 and configs[4] legs: rank-agnostic, rehearsed in test_gpu_nccl.py)
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -220,6 +220,5 @@ def test_bench_two_ranks_rehearsal():
     cem = out["cem"]
     assert cem["config"]["parallelism"] == "candidate-shard2" and cem["config"]["candidates"] == 128
     assert cem["ranks"]["cost_allgather_ms"] is not None and len(cem["ranks"]["s_per_iteration"]) == 2
-    assert out["cem_ra"]["value"] > 0 and out["fp32_exact"]["train"]["ms_per_step"] > 0
-    assert out["side"]["cfg5"]["value"] > 0 and "128x128" in out["side"]["cfg5"]["config"]["workload"]
+    assert out["cem_ra"]["value"] > 0 and "fp32_exact" not in out and "side" not in out
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only

@@ -61,7 +61,7 @@ def test_bench_under_torchrun_one_rank_rccl():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
            "--warmup", "1", "--cem-candidates", "64", "--cem-batch", "64", "--cem-iters", "1", "--cem-opt-iter", "2",
-           "--no-exact", "--no-side", "--no-cem-ra", "--no-cpu-baseline"]
+           "--exact-steps", "1", "--side-steps", "1", "--no-cem-ra", "--no-cpu-baseline"]
     res = subprocess.run(cmd, cwd=ROOT, env=_env(RAC_DIST_FORCE="1"), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stderr[-4000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -70,3 +70,8 @@ def test_bench_under_torchrun_one_rank_rccl():
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["cem"]["value"] > 0
     assert "allreduce_exposed" in out["time_breakdown_ms"]            # the DDP branch of the train step ran
     assert out["cem"]["ranks"]["cost_allgather_ms"] is not None       # and the planner's all-gather
+    # the exact-fp32 and configs[4] legs under a process group (the two-rank rehearsal of test_gpu_dist.py skips them), and
+    # both gradient-exchange modes on RCCL
+    assert out["fp32_exact"]["train"]["ms_per_step"] > 0 and out["fp32_exact"]["cem"]["rollouts_per_s"] > 0
+    assert out["side"]["cfg5"]["value"] > 0 and "128x128" in out["side"]["cfg5"]["config"]["workload"]
+    assert out["ddp_modes"]["sharded"].get("ms_per_step", 0) > 0, out["ddp_modes"]
