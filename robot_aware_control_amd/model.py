@@ -482,7 +482,7 @@ class SVGConvModel(nn.Module):
         Returns (x4 (T*B,H,W,4), [mu_t], [logvar_t], [mu_p_t], [logvar_p_t])."""
         T, B = images.shape[0], images.shape[1]
         flat = lambda t: None if t is None else t.reshape((T * B,) + tuple(t.shape[2:]))
-        h_all, skips = self._encode(flat(images), flat(masks), flat(heatmaps), flat(zero_masks), 2, T)
+        h_all, skips = self._encode(flat(images), flat(masks), flat(heatmaps), flat(zero_masks), 2, T, staged=True)
         h_steps = h_all.view((T, B) + tuple(h_all.shape[1:])).unbind(0)
         # the prior's and the posterior's input convs see only data and the encoder output (the posterior encodes the
         # CURRENT frame: dynamics.py:619), all known before the recurrence starts: ONE launch each over the T*B latents
@@ -504,6 +504,7 @@ class SVGConvModel(nn.Module):
             q = self.posterior_input_conv
             post_all = ops.ConvBias.apply(h_all, None, q.weight, q.bias, ACT_NONE, not torch.is_grad_enabled())
         core = self._recurrent_core(T, B, h_all, prior_all, post_all, robots, actions)
+        ops.param_wait()  # (whatever the core did not wait for itself: every path from here on may read any parameter)
         if core is not None:
             h_pred_all, mu_all, lv_all, h_prior_all = core
             mu_p_all, logvar_p_all = self.prior.heads(h_prior_all)
@@ -577,13 +578,27 @@ class SVGConvModel(nn.Module):
         """Flat-buffer element index behind the encoder's last parameter (the encoder is registered first)."""
         return max(p._rac_off + p.numel() for p in self.encoder.parameters())
 
-    def _encode(self, image, mask, heatmap, zero_mask, n_updates, groups):
-        gate = ops.PARAM_GATE  # a sharded optimiser's parameter all-gather still in flight (optim.ShardedAdam)
+    def late_update_groups(self):
+        """Parameters behind the encoder's in the order a teacher-forced window first reads them (optim.FusedAdam updates
+        its late weights in these groups): the prior's chain (+ both input convs, which run right behind the encoder), the
+        posterior's, then the frame predictor's and the decoder's (everything else)."""
+        first = [self.prior_input_conv.weight, self.posterior_input_conv.weight] + [c.gates.weight for c in self.prior.lstm
+                                                                                    if hasattr(c, "gates")]
+        second = [c.gates.weight for c in self.posterior.lstm if hasattr(c, "gates")]
+        return [first, second]
+
+    def _encode(self, image, mask, heatmap, zero_mask, n_updates, groups, staged=False):
+        """`staged`: the caller waits for the later parameter groups itself (forward_sequence_maps: the recurrent core takes
+        its chains' weights as they arrive); otherwise everything is waited for behind the encoder."""
+        gate = ops.PARAM_GATE  # an optimiser update still in flight: optim.ShardedAdam's all-gather, FusedAdam's late groups
         if gate is not None:
             gate.wait_params(upto=self._encoder_extent())
         out = self._encode_now(image, mask, heatmap, zero_mask, n_updates, groups)
         if gate is not None:
-            gate.wait_params()  # everything behind the encoder's parameters: waited for under the encoder's kernels
+            if staged and hasattr(gate, "wait_for"):
+                gate.wait_for(self.prior_input_conv.weight)  # the first late group, under the encoder's kernels
+            else:
+                gate.wait_params()  # everything behind the encoder's parameters: waited for under the encoder's kernels
         return out
 
     def _encode_now(self, image, mask, heatmap, zero_mask, n_updates, groups):

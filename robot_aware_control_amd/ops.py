@@ -533,6 +533,20 @@ def low_priority_stream(dev):
 PARAM_GATE = None
 
 
+def param_wait(t: torch.Tensor = None) -> None:
+    """Make the current stream wait for an optimiser update that is still in flight (PARAM_GATE): of the parameter memory
+    `t`, or of everything."""
+    gate = PARAM_GATE
+    if gate is None:
+        return
+    if t is None:
+        gate.wait_params()
+    elif hasattr(gate, "wait_for"):
+        gate.wait_for(t)
+    elif not gate.ready(t):
+        gate.wait_params()
+
+
 def _wp_refresh(device):
     """Bring every registered weight of `device` whose parameter changed up to date."""
     st = _wp_state(device)
@@ -642,9 +656,10 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     current (first steps, new registrations), no registered weight inside `flat`, an unbounded Adam step: the caller
     then takes rac_adam_step and the parts are refreshed lazily.
 
-    `late` = (first flat element, {data_ptr of the weights that may be late}): the registered weights behind that element
-    whose memory is in the set are updated on a SIDE stream (behind everything enqueued so far) and the call returns
-    (event, [(offset, numel)]) -- the event the consumer of those weights must wait for -- instead of True: the pass is
+    `late` = (first flat element, {data_ptr of the weights that may be late} or a list of such sets, in the order the next
+    forward pass needs them): the registered weights behind that element whose memory is in a set are updated on a SIDE
+    stream (behind everything enqueued so far; one launch per set, in order) and the call returns
+    [(event, [(offset, numel)]) per set] -- the event the consumer of those weights must wait for -- instead of True: the pass is
     bound by HBM (8.6 GB per step), the next step's encoder forward is many small launches bound by latency; the caller
     (optim.FusedAdam with `overlap_next_forward`) makes the model wait behind its encoder."""
     global PARAM_EPOCH
@@ -673,8 +688,20 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     if not covered:
         return False
     covered.sort(key=lambda c: c[0])
-    is_late = (lambda off, w: late is not None and off >= late[0] and w.data_ptr() in late[1])
-    sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(), None if late is None else (late[0], tuple(sorted(late[1]))),
+    # late[1]: one set of data pointers, or a LIST of sets = groups in the order the next forward pass needs them (each
+    # group its own launch and event on the side stream, which runs them in that order)
+    late_sets = [] if late is None else (list(late[1]) if isinstance(late[1], (list, tuple)) else [late[1]])
+
+    def late_group(off, w):  # index of the weight's late group, -1: updated on the caller's stream
+        if late is None or off < late[0]:
+            return -1
+        for gi, ptrs in enumerate(late_sets):
+            if w.data_ptr() in ptrs:
+                return gi
+        return -1
+    is_late = lambda off, w: late_group(off, w) >= 0
+    sig = (base, grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+           None if late is None else (late[0], tuple(tuple(sorted(ps)) for ps in late_sets)),
            tuple((off, ent.idx, tuple(sorted((t, q.data_ptr()) for t, q in ent.parts.items()))) for off, ent, _ in covered))
     plan = st["adam_plan"]
     if plan is not None and plan["sig"] == sig and plan.get("unsupported"):
@@ -682,16 +709,20 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     if plan is None or plan["sig"] != sig:
         lib = _lib.load()
         jobs = (AdamFragJob * len(covered))()
-        n_early = sum(1 for off, _, w in covered if not is_late(off, w))
-        slot_of = {}  # the early jobs first in the table, the late ones behind them (each group numbers its own blocks)
-        ne = nl = 0
-        for j, (off, _, w) in enumerate(covered):
-            if is_late(off, w):
-                slot_of[j], nl = n_early + nl, nl + 1
+        groups = [late_group(off, w) for off, _, w in covered]
+        n_early = sum(1 for gi in groups if gi < 0)
+        n_in = [sum(1 for gi in groups if gi == k) for k in range(len(late_sets))]
+        first = [n_early + sum(n_in[:k]) for k in range(len(late_sets))]  # a group's first slot in the job table
+        slot_of, taken = {}, [0] * len(late_sets)  # the early jobs first, then group by group (each numbers its own blocks)
+        ne = 0
+        for j, gi in enumerate(groups):
+            if gi >= 0:
+                slot_of[j], taken[gi] = first[gi] + taken[gi], taken[gi] + 1
             else:
                 slot_of[j], ne = ne, ne + 1
-        ranges, blocks, late_blocks, pos = [], 0, 0, 0
-        late_spans = []
+        ranges, blocks, pos = [], 0, 0
+        late_blocks = [0] * len(late_sets)
+        late_spans = [[] for _ in late_sets]
         for i, (off, ent, w) in enumerate(covered):
             co, ci, k, _ = w.shape
             n = w.numel()
@@ -703,15 +734,16 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
             if off > pos:
                 ranges.append((pos // 4, (off - pos) // 4))
             pos = off + n
-            lt = is_late(off, w)
+            gi = groups[i]
+            lt = gi >= 0
             jobs[slot_of[i]] = AdamFragJob(p=base + 4 * off, g=grad.data_ptr() + 4 * off, m=m.data_ptr() + 4 * off,
                                            v=v.data_ptr() + 4 * off, scale_slot=ptr(ent.slot),
                                            amax_out=ptr(st["exact"][ent.idx:ent.idx + 1]), parts_fwd=ptr(ent.parts.get(False)),
                                            parts_t=ptr(ent.parts.get(True)), part_stride=n, Cout=co, Cin=ci, ksize=k, reserved=0,
-                                           block_begin=late_blocks if lt else blocks)
+                                           block_begin=late_blocks[gi] if lt else blocks)
             if lt:
-                late_blocks += lib.rac_weight_frag_blocks(co, ci, k)
-                late_spans.append((off, n))
+                late_blocks[gi] += lib.rac_weight_frag_blocks(co, ci, k)
+                late_spans[gi].append((off, n))
             else:
                 blocks += lib.rac_weight_frag_blocks(co, ci, k)
         if pos < flat.numel():
@@ -723,7 +755,7 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
             rblocks += _cdiv(n4, 1024)
         plan = st["adam_plan"] = {
             "sig": sig, "jobs": _wp_upload(jobs, dev), "n_jobs": len(covered), "blocks": blocks,
-            "n_early": n_early, "late_blocks": late_blocks, "late_spans": late_spans,
+            "n_early": n_early, "late_blocks": late_blocks, "late_spans": late_spans, "late_first": first, "late_n": n_in,
             "ranges": _wp_upload(rjobs, dev), "n_ranges": len(ranges), "rblocks": rblocks,
             "idx": torch.tensor([ent.idx for _, ent, _ in covered], device=dev, dtype=torch.int32)}
     sp = stream_ptr()
@@ -739,7 +771,7 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     if plan["n_ranges"]:
         call("rac_adam_ranges", ptr(flat), ptr(grad), ptr(m), ptr(v), ptr(plan["ranges"]), plan["n_ranges"],
              plan["rblocks"], float(lr), float(beta1), float(beta2), float(eps), int(step), sp)
-    done = None
+    done = []
     if n_late:
         main = torch.cuda.current_stream()
         if _ADAM_SIDE["stream"] is None or _ADAM_SIDE["stream"].device != dev:
@@ -749,14 +781,19 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
         ready.record(main)  # every gradient, the scale bounds and whatever read the old weights precede the side launch
         side.wait_event(ready)
         with torch.cuda.stream(side):
-            call("rac_adam_frag_multi_bounded", ptr(plan["jobs"]) + n_early * C.sizeof(AdamFragJob), n_late,
-                 plan["late_blocks"], ADAM_LATE_WGS, float(lr), float(beta1), float(beta2), float(eps), int(step), stream_ptr())
-            done = torch.cuda.Event()
-            done.record(side)
+            for gi, n_g in enumerate(plan["late_n"]):
+                if not n_g:
+                    continue
+                call("rac_adam_frag_multi_bounded", ptr(plan["jobs"]) + plan["late_first"][gi] * C.sizeof(AdamFragJob), n_g,
+                     plan["late_blocks"][gi], ADAM_LATE_WGS, float(lr), float(beta1), float(beta2), float(eps), int(step),
+                     stream_ptr())
+                ev = torch.cuda.Event()
+                ev.record(side)
+                done.append((ev, list(plan["late_spans"][gi])))
     PARAM_EPOCH += 1
     for _, ent, w in covered:  # their parts and maxima already describe the new values
         ent.tag = _wp_tag(w)
-    return (done, list(plan["late_spans"])) if done is not None else True
+    return done if done else True
 
 
 def weight_parts(weight: torch.Tensor, transposed: bool = False):
@@ -2025,7 +2062,19 @@ class RecurrentCore(torch.autograd.Function):
         nv = plan["nv"]
         ct = nv + g + z
         pad = (-ct) % 32
-        fw_pad = padded_weight(fconv.weight, ct + pad)
+        staged = CORE_LAYER_MAJOR and not (CHAIN_STREAMS and h_all.is_cuda)  # (chains in order: their weights may arrive in order)
+        if not staged:
+            param_wait()
+        fw_box = []
+
+        def fw_pad_now():  # the frame predictor's padded input-conv weight: rebuilt from the parameter, so behind its update
+            if not fw_box:
+                param_wait(fconv.weight)
+                fw_box.append(padded_weight(fconv.weight, ct + pad))
+                weight_parts(fw_box[0])
+            return fw_box[0]
+        if not staged:
+            fw_pad_now()
         # the noise of every step, drawn in the reference's order (the prior's draw, dropped, before the posterior's)
         eps_all = []
         for t in range(T):
@@ -2037,7 +2086,6 @@ class RecurrentCore(torch.autograd.Function):
             for cell in cells[L]:
                 weight_parts(cell.gates.weight)
         weight_parts(head_w)
-        weight_parts(fw_pad)
         region = _ChainRegion(dev, True)
         tape = [dict() for _ in range(T)]
         h0 = {L: [None] * T for L in ("prior", "post", "fp")}
@@ -2074,7 +2122,7 @@ class RecurrentCore(torch.autograd.Function):
                  v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
                  ptr(h_steps[t]), g, ptr(z_all[t]), z, pad, ptr(cat), B, H * W, ptr(slot), 0, sp)
             tag_amax(cat, slot)
-            xf_all[t] = conv_forward_split(cat, None, fw_pad, fconv.bias)
+            xf_all[t] = conv_forward_split(cat, None, fw_pad_now(), fconv.bias)
             tape[t]["cat"] = cat
 
         def fp_l0(t):
@@ -2118,7 +2166,7 @@ class RecurrentCore(torch.autograd.Function):
                  v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
                  ptr(h_all), g, ptr(thin["z"]), z, pad, ptr(cat), T * B, H * W, ptr(slot), 0, sp)
             tag_amax(cat, slot)
-            xf = conv_forward_split(cat, None, fw_pad, fconv.bias)
+            xf = conv_forward_split(cat, None, fw_pad_now(), fconv.bias)
             thin.update(cat=cat, xf=xf)
             xs = step(xf)
             for t in range(T):
@@ -2144,6 +2192,13 @@ class RecurrentCore(torch.autograd.Function):
                 order = ((prior_l0, prior_l1, post_l0, post_l1_cell, post_head_all, fp_in_all, fp_l0, fp_l1) if batch_thin
                          else (prior_l0, prior_l1, post_l0, post_l1, fp_in, fp_l0, fp_l1))
                 for piece in order:
+                    # (optim.FusedAdam's late update arrives group by group: prior, posterior, frame predictor + decoder)
+                    if piece is prior_l0:
+                        param_wait(cells["prior"][0].gates.weight)
+                    elif piece is post_l0:
+                        param_wait(cells["post"][0].gates.weight)
+                    elif piece in (fp_in, fp_in_all):
+                        param_wait(cells["fp"][0].gates.weight)
                     if piece in (post_head_all, fp_in_all):
                         piece()
                         continue

@@ -4,6 +4,8 @@ State-dict compatible with `torch.optim.Adam` (reference trainer.py:109-122,829-
 `step`, `exp_avg`, `exp_avg_sq` entries are views of two flat moment buffers."""
 from __future__ import annotations
 
+import os
+
 import torch
 
 import torch.distributed as dist
@@ -27,36 +29,67 @@ class FusedAdam(torch.optim.Optimizer):
         self._model = model
         self._steps = 0
         self._m = self._v = None
-        self._late = None  # (event, [(offset, numel)]) of the late weights' update in flight
+        self._late = []  # [(event, [(offset, numel)])] of the late weights' updates in flight, in the order they complete
 
     def wait_params(self, upto: int = None):
         """Make the current stream wait for the late weights' update (`upto`: only if a late weight lies below that flat
-        element -- none does: the late group starts behind the encoder)."""
-        if self._late is None:
+        element -- none does: the late groups start behind the encoder)."""
+        if not self._late:
             return
-        if upto is not None and all(off >= upto for off, _ in self._late[1]):
+        if upto is not None and all(off >= upto for _, spans in self._late for off, _ in spans):
             return
-        torch.cuda.current_stream().wait_event(self._late[0])
-        self._late = None
+        torch.cuda.current_stream().wait_event(self._late[-1][0])  # (one in-order side stream: the last event covers all)
+        self._late = []
         if ops.PARAM_GATE is self:
             ops.PARAM_GATE = None
 
+    def wait_for(self, t: torch.Tensor):
+        """... for the late group that holds the parameter memory `t` (and the groups in front of it: one stream)."""
+        if not self._late:
+            return
+        flat, _ = self._model.flat_parameters()
+        lo = (t.data_ptr() - flat.data_ptr()) // 4
+        hi = lo + t.numel()
+        hit = [k for k, (_, spans) in enumerate(self._late) if any(off < hi and lo < off + n for off, n in spans)]
+        if not hit:
+            return
+        torch.cuda.current_stream().wait_event(self._late[hit[-1]][0])
+        self._late = self._late[hit[-1] + 1:]
+        if not self._late and ops.PARAM_GATE is self:
+            ops.PARAM_GATE = None
+
     def ready(self, t: torch.Tensor) -> bool:
-        if self._late is None:
+        if not self._late:
             return True
         flat, _ = self._model.flat_parameters()
         lo = (t.data_ptr() - flat.data_ptr()) // 4
         hi = lo + t.numel()
-        return all(not (off < hi and lo < off + n) for off, n in self._late[1])
+        return all(not (off < hi and lo < off + n) for _, spans in self._late for off, n in spans)
 
     def _late_group(self):
-        """(first flat element, data pointers) of the weights that may be updated late: the large conv weights whose
-        gradient the next step's lazy zero_grad does not touch, behind the encoder's parameters."""
+        """(first flat element, [sets of data pointers]) of the weights that may be updated late: the large conv weights
+        whose gradient the next step's lazy zero_grad does not touch, behind the encoder's parameters -- ONE group, waited for
+        behind the encoder.  RAC_ADAM_LATE_GROUPS=1 groups them in the order the forward pass needs them
+        (SVGConvModel.late_update_groups: prior, posterior, frame predictor + decoder; the recurrent core then waits chain by
+        chain, ops.param_wait) so that two thirds of the pass run under the prior's and the posterior's gate GEMMs instead of
+        under the encoder -- measured SLOWER (three same-box rounds: 23.07 ms no overlap, 22.75 one group, 23.41 staged groups):
+        the gate GEMMs at M = 1024 stream their weights from HBM and lose more than the encoder does."""
         model = self._model
         lazy = getattr(model, "_lazy_params", None)
         if not self.overlap_next_forward or not lazy or not hasattr(model, "_encoder_extent"):
             return None
-        return model._encoder_extent(), frozenset(p.data_ptr() for p in lazy)
+        lazy_ptrs = {p.data_ptr() for p in lazy}
+        groups = getattr(model, "late_update_groups", None) if os.environ.get("RAC_ADAM_LATE_GROUPS", "0") == "1" else None
+        sets, seen = [], set()
+        for grp in (groups() if groups is not None else []):
+            ptrs = frozenset(p.data_ptr() for p in grp if p.data_ptr() in lazy_ptrs and p.data_ptr() not in seen)
+            seen |= ptrs
+            if ptrs:
+                sets.append(ptrs)
+        rest = frozenset(lazy_ptrs - seen)
+        if rest:
+            sets.append(rest)
+        return model._encoder_extent(), sets
 
     def _moments(self):
         flat, _ = self._model.flat_parameters()
@@ -81,7 +114,7 @@ class FusedAdam(torch.optim.Optimizer):
                                   late=self._late_group())
         if res:
             if res is not True:
-                self._late = res
+                self._late = list(res)
                 ops.PARAM_GATE = self
             return
         ops.PARAM_EPOCH += 1  # invalidates caches derived from the parameters (padded weight copies, operand parts)
@@ -182,6 +215,12 @@ class ShardedAdam(FusedAdam):
         self._pending = keep
         if not keep and ops.PARAM_GATE is self:
             ops.PARAM_GATE = None
+
+    def wait_for(self, t: torch.Tensor):
+        """(the all-gather's buckets complete in issue order: waiting for a parameter is waiting for the buckets up to its end)"""
+        if not self.ready(t):
+            flat, _ = self._model.flat_parameters()
+            self.wait_params(upto=(t.data_ptr() - flat.data_ptr()) // 4 + t.numel())
 
     def ready(self, t: torch.Tensor) -> bool:
         """Have the buckets overlapping the parameter memory `t` been waited for?"""

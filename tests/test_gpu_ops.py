@@ -1000,9 +1000,12 @@ def test_fused_adam_step_writes_the_next_parts(dev):
     for w in ws:  # (the restored weights' parts: the lazy path, as after load_state_dict)
         ops.weight_parts(w)
     off1 = (ws[1].data_ptr() - flat.data_ptr()) // 4
-    res = ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4, late=(off1, frozenset(w.data_ptr() for w in ws[1:])))
-    assert res is not True and res and sorted(res[1]) == sorted(((w.data_ptr() - flat.data_ptr()) // 4, w.numel()) for w in ws[1:])
-    torch.cuda.current_stream().wait_event(res[0])
+    # (two late groups, in the order their consumers run: each its own launch and event on the side stream)
+    res = ops.fused_adam_step(flat, grad, m, v, 1e-3, 0.9, 0.999, 1e-8, 4,
+                              late=(off1, [frozenset([ws[2].data_ptr()]), frozenset([ws[1].data_ptr()])]))
+    span = lambda w: ((w.data_ptr() - flat.data_ptr()) // 4, w.numel())
+    assert res is not True and [sp for _, sp in res] == [[span(ws[2])], [span(ws[1])]]
+    torch.cuda.current_stream().wait_event(res[-1][0])  # (one in-order stream: the last event covers every group)
     got = [flat, m, v] + [q for w in ws for q in ops._WP_ENTRIES[id(w)].parts.values()]
     assert all(torch.equal(a, b) for a, b in zip(got, want))
     assert all(torch.equal(ops._WP_ENTRIES[id(w)].slot, sl) for w, sl in zip(ws, want_slots))
