@@ -945,8 +945,16 @@ int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const
   int rpb;
   const long Mg = M / groups;
   int bpg_rows, rpb_rows;
-  // (about 1024 workgroups: every one ends in 8 fp64 atomics per channel quad onto the same 2 C addresses)
-  if (bn_rows_form(C, Mg, groups, 1024, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
+  // Every workgroup ends in 8 fp64 atomics per channel quad onto the same 2 C addresses of its group.  A large tensor wants
+  // ~1024 workgroups for its bytes; a small one (the 8x8 / 16x16 layers: 10-21 MB) is not bound by bytes at all -- its pass
+  // took 27 us warm or cold, against 13 for the apply pass over the same tensors -- but by that contention: 256 workgroups
+  // (47 per group instead of 128) run it in 16 us (tools/bench_bn_reduce.py; in the train step the pass runs beside the side
+  // stream's weight gradients and the step time does not move: 23.04 / 23.00 / 23.05 ms).  (Copies of the accumulators, a
+  // workgroup adding into copy index mod R, were built and measured: the reduce pass gains what the apply pass then loses
+  // summing the copies.)
+  static const int reduce_blocks_env = [] { const char* e = getenv("RAC_BN_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int reduce_blocks = reduce_blocks_env > 0 ? reduce_blocks_env : ((long)M * C * 4 <= (24L << 20) ? 256 : 1024);
+  if (bn_rows_form(C, Mg, groups, reduce_blocks, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
       aligned16(shift) && aligned16(mean) && aligned16(invstd)) {
     hipLaunchKernelGGL(bn_bwd_reduce_rows_kernel, dim3(bpg_rows * groups), dim3(256), 0, ST(stream), (const f32x4*)dy,
                        (const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)mean, (const f32x4*)invstd,
