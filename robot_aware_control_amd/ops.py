@@ -509,6 +509,7 @@ def _wp_upload(jobs, device):
 
 _ADAM_SIDE = {"stream": None}  # fused_adam_step(late=...): the late weights' update runs here
 ADAM_LATE_WGS = int(os.environ.get("RAC_ADAM_LATE_WGS", "512"))  # ... on this many workgroups (2 per CU)
+ADAM_LOW_PRIORITY = os.environ.get("RAC_ADAM_LOW_PRIORITY", "0") == "1"  # (experiments: a below-default-priority HIP stream)
 ADAM_WGS = int(os.environ.get("RAC_ADAM_WGS", "0"))  # (experiments: the one-stream pass on a bounded grid too; 0 = one workgroup per block)
 
 
@@ -775,7 +776,7 @@ def fused_adam_step(flat, grad, m, v, lr, beta1, beta2, eps, step, late=None):
     if n_late:
         main = torch.cuda.current_stream()
         if _ADAM_SIDE["stream"] is None or _ADAM_SIDE["stream"].device != dev:
-            _ADAM_SIDE["stream"] = low_priority_stream(dev)
+            _ADAM_SIDE["stream"] = low_priority_stream(dev) if ADAM_LOW_PRIORITY else torch.cuda.Stream(device=dev)
         side = _ADAM_SIDE["stream"]
         ready = torch.cuda.Event()
         ready.record(main)  # every gradient, the scale bounds and whatever read the old weights precede the side launch
