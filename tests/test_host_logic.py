@@ -156,3 +156,35 @@ def test_reset_parameters_moments():
     flat, grad = m.flat_parameters()
     used = sum((p.numel() + 3) // 4 * 4 for p in m.parameters())  # 16-byte aligned views, the buffer padded to whole 4 KB
     assert (used + 1023) // 1024 * 1024 == flat.numel() == grad.numel() and float(flat[used:].abs().max()) == 0.0
+
+
+def test_bench_starts_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE: the script starts `torch.distributed.run` as a CHILD process
+    with the same arguments and exits with its return code -- before torch or the HIP library is imported (bench.py calls
+    this ahead of those imports); with WORLD_SIZE set, or N = 1, it is a rank itself."""
+    import importlib
+    import subprocess
+    import sys
+    import types
+    bench = importlib.import_module("bench")
+    calls = []
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None: (calls.append((cmd, env)), types.SimpleNamespace(returncode=7))[1])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    for argv in (["bench.py", "--gpus", "4", "--steps", "3"], ["bench.py", "--steps", "3", "--gpus=4"]):
+        calls.clear()
+        monkeypatch.setattr(sys, "argv", argv)
+        with pytest.raises(SystemExit) as e:
+            bench._launch_ranks_if_needed()
+        assert e.value.code == 7 and len(calls) == 1
+        cmd, env = calls[0]
+        assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+        assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+        assert cmd[-len(argv) + 1:] == argv[1:] and cmd[-len(argv)].endswith("bench.py")
+        assert env.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    bench._launch_ranks_if_needed()  # one GPU: this process is the benchmark
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench._launch_ranks_if_needed()  # launched by torch.distributed.run: a rank
+    assert not calls
