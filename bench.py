@@ -79,6 +79,36 @@ TRAIN_FWD_GFLOP_PER_SAMPLE_STEP = 36.26   # SURVEY.md 8d, hook-counted on the re
 CEM_FWD_GFLOP_PER_CAND_STEP = 24.46
 CEM_CHECK_TOP, CEM_CHECK_OTHERS = 32, 32  # the oracle re-rolls the GPU's own top 32 candidates and 32 random others
 
+
+
+def fwd_gflop(cf, train=True):
+    """Algorithmic conv FLOP (2 x MAC, convs and the transposed-conv head only) of ONE forward pass of the model per sample
+    and time step: the train forward as the reference runs it (two encoder passes, prior + posterior + frame predictor,
+    dynamics.py:575-644) or the planner's prior-only forward.  Reproduces SURVEY.md 8d's hook-counted figures exactly
+    (36.26 / 24.46 / 24.45 / 7.42 / 145.03 GF); a NormConvLSTMCell's two g -> 4g convs are one ConvLSTMCell's 2g -> 4g."""
+    g, z, A, R = cf.g_dim, cf.z_dim, cf.action_dim, cf.robot_dim
+    hw = cf.image_height * cf.image_width
+    enc_c = cf.channels + ((1 + (1 if cf.model_use_future_mask else 0)) if cf.model_use_mask else 0)
+    if getattr(cf, "model_use_heatmap", False):
+        enc_c += 1 + (1 if getattr(cf, "model_use_future_heatmap", False) else 0)
+    extra = (R if cf.model_use_robot_state else 0) + (R if cf.model_use_future_robot_state else 0)
+    enc = (hw * 9 * (enc_c * 64 + 64 * 64) + hw // 4 * 9 * (64 * 128 + 128 * 128)
+           + hw // 16 * 9 * (128 * 256 + 2 * 256 * 256) + hw // 64 * 9 * (256 * 512 + 512 * 512 + 512 * g))
+    dec = (hw // 64 * 9 * (g * 512 + 512 * 512 + 512 * 256) + hw // 16 * 9 * (512 * 256 + 256 * 256 + 256 * 128)
+           + hw // 4 * 9 * (256 * 128 + 128 * 64) + hw * 9 * (128 * 64 + 64 * (cf.channels + 1)))
+    lat = hw // 64
+    lstm = lat * (25 + 9) * (2 * g * 4 * g)
+    head = lat * 9 * g * z * 2
+    prior_in = lat * 9 * (g + A + extra) * g
+    post_in = lat * 9 * (g + (R if cf.model_use_robot_state else 0)) * g
+    fp_in = lat * 9 * (g + A + z + extra) * g
+    if train:
+        mac = 2 * enc + dec + 3 * lstm + 2 * head + prior_in + post_in + fp_in
+    else:
+        mac = enc + dec + 2 * lstm + head + prior_in + fp_in
+    return 2.0 * mac / 1e9
+
+
 RA = dict(model_use_mask=True, model_use_future_mask=True, model_use_robot_state=True,
           reconstruction_loss="dontcare_l1")
 
@@ -228,24 +258,34 @@ def phase_breakdown(events, steps):
 
 
 def train_workload_name(args, cf):
-    if args.cfg5:
+    if getattr(args, "deployed", False):
+        base = ("SVG train step in the configuration of the reference's deployed checkpoints (evaluate_checkpoint.py:40-46, "
+                "roboaware line): 48x64 frames, bs 16/GPU, n_past 1, n_future 5, --lstm_group_norm True, future robot state")
+    elif args.cfg5:
         base = "SVG train step, per-GPU shard of BASELINE configs[4]: 128x128, bs 8/GPU, n_past 1, n_future 10"
     elif args.h48:
         base = "SVG train step at the reference's default frame size 48x64 (side config): bs 16/GPU, n_past 1, n_future 5"
     else:
         base = "SVG train step, BASELINE configs[1]: 64x64, bs 16/GPU, n_past 1, n_future 5"
     gn = ", --lstm_group_norm True (NormConvLSTMCell, side config)" if args.group_norm else ""
+    sched = getattr(args, "sched", None)
+    if sched:
+        gn += (", --scheduled_sampling True with the coin forced: " +
+               ("every frame after the first fed back from the model's own prediction" if sched == "all"
+                else "every other frame fed back (50 % mix)"))
     return f"{base}, g_dim {cf.g_dim}, z_dim {cf.z_dim}, robot-aware flags (dontcare_l1){gn}"
 
 
 def build_train(args, dev):
     cf = namespace(dev, lstm_group_norm=args.group_norm, ddp_shard_optimizer=bool(getattr(args, "shard_optimizer", False)))
+    if getattr(args, "deployed", False):  # evaluate_checkpoint.py:40-46 (roboaware line) at the default 48 x 64 frame
+        cf.g_dim, cf.lstm_group_norm, cf.image_height, cf.model_use_future_robot_state = 256, True, 48, True
     if args.h48:  # the reference's default frame size (config/__init__.py:166-171): 48 x 64 -> 6 x 8 latent maps
         cf.image_height = 48
     if args.cfg5:  # BASELINE configs[4] per GPU: 128x128 frames, 8 samples, 10 predicted frames (16x16 latent maps)
         cf.image_width = cf.image_height = 128
         cf.batch_size, cf.n_future = 8, 10
-    log("building trainer (g512/z64, 238.6 M params)")
+    log(f"building trainer (g{cf.g_dim}/z{cf.z_dim}, {cf.image_height}x{cf.image_width})")
     tr = PredictionTrainer(cf)
     # as PredictionTrainer.train() does: the large weights' optimiser update may finish under the next step's encoder
     # (every step's whole update still lies inside the timed region: it ends with a device-wide synchronise)
@@ -262,8 +302,17 @@ def bench_train(args, dev, rank, world, distributed, exact_of=None):
     with every conv on the exact-fp32 MFMA kernels (ops.SPLIT_GEMM off): a shorter timed region, no CPU check."""
     cf, tr = build_train(args, dev)
     B, T = cf.batch_size, cf.n_past + cf.n_future
-    want_check = (rank == 0 and world == 1 and not args.no_cpu_baseline and not (args.h48 or args.cfg5 or args.group_norm)
-                  and exact_of is None)
+    side_cfg = args.h48 or args.cfg5 or args.group_norm or getattr(args, "deployed", False) or getattr(args, "sched", None)
+    want_check = rank == 0 and world == 1 and not args.no_cpu_baseline and not side_cfg and exact_of is None
+    # scheduled sampling with the coin forced (trainer.py:132-147,354): frame i of the window is ground truth or the model's
+    # own prediction of it; "all": every frame after the first is fed back (what > 85 % of the README run's steps do)
+    n_steps = cf.n_past + cf.n_future - 1
+    sched = getattr(args, "sched", None)
+    use_truth = None
+    if sched == "all":
+        use_truth = [True, True] + [False] * (n_steps - 1)
+    elif sched == "mix":
+        use_truth = [True, True] + [bool(i % 2) for i in range(n_steps - 1)]
     check = None
     if exact_of is not None and exact_of["check"] is not None:
         ck = exact_of["check"]
@@ -280,7 +329,7 @@ def bench_train(args, dev, rank, world, distributed, exact_of=None):
                for i in range(2)]
     batches_dev = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in b.items()} for b in batches]
     for i in range(3):  # prime the caching allocator (new tensor sizes cost a hipMalloc + sync each); not a warmup step
-        losses = tr._train_step(batches_dev[i % 2])
+        losses = tr._train_step(batches_dev[i % 2], use_truth=use_truth)
         if i == 0 and want_check:
             check = {"sd": sd0, "data": batches[0], "eps": eps, "gpu_losses": dict(losses)}
             tr.model.eps_source = None
@@ -288,7 +337,7 @@ def bench_train(args, dev, rank, world, distributed, exact_of=None):
     log("allocator primed")
     steps, warmup = (args.steps, args.warmup) if exact_of is None else (args.exact_steps, 2)
     for i in range(warmup):
-        tr._train_step(batches_dev[i % 2])
+        tr._train_step(batches_dev[i % 2], use_truth=use_truth)
         torch.cuda.synchronize()
     g = cf.g_dim
     # dominant kernel: ConvLSTM layer-0 gate GEMM, FWD  (M = B*64, N = 4g, K = 25 * 2g)
@@ -298,9 +347,16 @@ def bench_train(args, dev, rank, world, distributed, exact_of=None):
     barrier_sync(distributed)
     t0 = time.perf_counter()
     for i in range(steps):
-        tr._train_step(batches_dev[i % 2])
+        tr._train_step(batches_dev[i % 2], use_truth=use_truth)
     barrier_sync(distributed)
     dt_local = time.perf_counter() - t0
+    opt = tr.optimizer
+    opt_info = {"optimizer": type(opt).__name__,
+                "shard_requested": bool(getattr(cf, "ddp_shard_optimizer", False)),
+                "late_update_overlapped": bool(getattr(opt, "_late_group", lambda: None)() is not None)}
+    opt.wait_params()  # nothing of this trainer's optimiser stays installed behind it (ops.PARAM_GATE is process-global)
+    if ops.PARAM_GATE is opt:
+        ops.PARAM_GATE = None
     dt = max_over_ranks(dt_local, dev, distributed)
     log(f"train{'' if exact_of is None else ' (exact fp32)'}: {steps} steps in {dt:.3f} s")
     ops.PROFILE = None
@@ -308,17 +364,30 @@ def bench_train(args, dev, rank, world, distributed, exact_of=None):
     starts = [e for n, e in events if n == "start"]
     step_ms = [a.elapsed_time(b) for a, b in zip(starts[:-1], starts[1:])]
     frames = world * B * T * steps
-    fwd_gflop = 145.03 if args.cfg5 else TRAIN_FWD_GFLOP_PER_SAMPLE_STEP  # 128x128 / 64x64 train forward
-    if args.h48:
-        fwd_gflop *= 48.0 / 64.0  # every conv's FLOPs scale with the pixel count
-    step_flop = 3 * B * (T - 1) * fwd_gflop * 1e9
+    # SURVEY 8d's hook-counted figures for the BASELINE configs (36.26 / 145.03 GF per sample-step); the analytic count --
+    # which reproduces them -- for the side configurations
+    if args.cfg5 and side_only(args, "cfg5"):
+        per_fwd = 145.03
+    elif args.cfg5 or args.h48 or args.group_norm or getattr(args, "deployed", False):
+        per_fwd = fwd_gflop(cf)
+    else:
+        per_fwd = TRAIN_FWD_GFLOP_PER_SAMPLE_STEP
+    if not (args.h48 or args.group_norm or getattr(args, "deployed", False)):
+        assert abs(fwd_gflop(cf) - per_fwd) < 0.01, (fwd_gflop(cf), per_fwd)
+    step_flop = 3 * B * (T - 1) * per_fwd * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
     return {"frames_per_s": frames / dt, "ms_per_step": dt / steps * 1e3,
             "median_ms_per_step": float(np.median(step_ms)) if step_ms else None,
             "step_tflops_per_gpu": step_flop / (dt / steps) / 1e12, "step_tflop": step_flop / 1e12, "kernel": kern,
             "global_batch": world * B, "phases": phase_breakdown(events, steps), "steps": steps,
             "rank_ms_per_step": [x / steps * 1e3 for x in per_rank(dt_local, dev, distributed, world)],
-            "check": check, "cf": cf, "workload": train_workload_name(args, cf)}
+            "check": check, "cf": cf, "workload": train_workload_name(args, cf), "optimizer": opt_info}
+
+
+def side_only(args, name):
+    """Is `name` the only side switch set (the BASELINE config it names, not a combination)?"""
+    flags = {"cfg5": args.cfg5, "h48": args.h48, "group_norm": args.group_norm, "deployed": getattr(args, "deployed", False)}
+    return flags[name] and not any(v for k, v in flags.items() if k != name)
 
 
 class SyntheticRobotInputs:
@@ -333,16 +402,19 @@ class SyntheticRobotInputs:
         return self.model.predict_batch(data, thick)
 
 
-def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
+def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None, deployed=False):
     """`ra`: the robot-aware planner (mask + future mask + robot state into the model, dontcare cost; per-candidate
     states / masks produced on the device).  `exact_of`: repeat the split-precision run's problem with the same weights
-    on the exact-fp32 MFMA kernels (one timed iteration)."""
+    on the exact-fp32 MFMA kernels (one timed iteration).  `deployed`: the reference's deployed checkpoints' model
+    (evaluate_checkpoint.py:40-46, vanilla line: g 256 / z 64, --lstm_group_norm True) on the default 48 x 64 frame."""
     n_per_gpu, horizon = args.cem_candidates, 15
     flags = dict(RA, reward_type="dontcare") if ra else dict(model_use_mask=False, model_use_future_mask=False,
                                                              model_use_robot_state=False, reconstruction_loss="l1")
     cf = namespace(dev, candidates_batch_size=args.cem_batch, batch_size=args.cem_batch,
-                   lstm_group_norm=args.group_norm, experiment="control_wx250s_synthetic",
+                   lstm_group_norm=args.group_norm or deployed, experiment="control_wx250s_synthetic",
                    cem_shared_start=not args.no_cem_shared_start, **flags)
+    if deployed:
+        cf.g_dim, cf.image_height = 256, 48
     model = SVGConvModel(cf)
     # (action channels amplified 1000x: the eight graded candidates' costs then sit >= 1e-3 apart, relative)
     model.load_state_dict(syn.synth_state_dict(model, seed=12, action_gain=1000.0))
@@ -353,7 +425,9 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
     model.eval()
     N = n_per_gpu * world
     demo = None
-    if ra:
+    if deployed:
+        prob = syn.synth_cem_problem(seed=0, N=N, T=horizon - 1, H=cf.image_height, W=cf.image_width)
+    elif ra:
         prob = syn.synth_cem_problem(seed=0, N=N, T=horizon - 1)
     else:
         # the planning problem with well-separated elites (K / K+1 cost gap >= 1e-3; the fixture of
@@ -376,9 +450,9 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
         prob["goal_masks"] = [prob["goal_masks"][0]] * (horizon - 1)
         goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
     g = cf.g_dim
-    tag = ("cem-ra" if ra else "cem") + ("" if exact_of is None else " (exact fp32)")
+    tag = ("cem-deployed" if deployed else "cem-ra" if ra else "cem") + ("" if exact_of is None else " (exact fp32)")
     log(f"{tag}: model built, {N} candidates")
-    small = syn.synth_cem_problem(seed=0, N=N, T=2)
+    small = syn.synth_cem_problem(seed=0, N=N, T=2, H=cf.image_height, W=cf.image_width)
     pol.traj_sampler.generate_model_rollouts(small["actions"], start, goal)  # allocator priming, 2 model steps
     iters, warm = (args.cem_iters, args.cem_warmup) if exact_of is None else (1, 0)
     for _ in range(warm):
@@ -400,16 +474,20 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
     ops.PROFILE = None
     pol.traj_sampler.time_gather = False
     assert len(ro["sum_cost"]) == N and np.all(np.isfinite(ro["sum_cost"]))
-    it_flop_per_gpu = n_per_gpu * (horizon - 1) * CEM_FWD_GFLOP_PER_CAND_STEP * 1e9
+    per_fwd = fwd_gflop(cf, train=False) if (deployed or args.group_norm) else CEM_FWD_GFLOP_PER_CAND_STEP
+    it_flop_per_gpu = n_per_gpu * (horizon - 1) * per_fwd * 1e9
     kern = profile_summary(prof, 2.0 * (4 * g) * (25 * 2 * g))
     out = {"rollouts_per_s": N * iters / dt, "s_per_iter": dt / iters, "iters": iters,
            "tflops_per_gpu": it_flop_per_gpu / (dt / iters) / 1e12, "kernel": kern, "candidates": N,
            "candidates_batch_size": args.cem_batch, "check": None,
            "rank_s_per_iter": [x / iters for x in per_rank(dt_local, dev, distributed, world)],
            "cost_allgather_ms": float(np.mean(gather_s)) * 1e3 if distributed else None, "get_action": None}
+    out["gflop_per_candidate_step"] = per_fwd
     if exact_of is not None:
         if exact_of["check"] is not None:
             out["check_sum_cost"] = ro["sum_cost"][exact_of["check"]["idx"]].copy()
+        return out
+    if deployed:
         return out
     # secondary metric: the whole planner call at the config's opt_iter -- sampling, robot inputs, rollouts,
     # cost gather, top-k, refit
@@ -422,13 +500,18 @@ def bench_cem(args, dev, rank, world, distributed, ra=False, exact_of=None):
     out["get_action"] = {"value": N * args.cem_opt_iter / dt_ga, "unit": "candidate-rollouts/s",
                          "opt_iter": args.cem_opt_iter, "s_per_call": dt_ga,
                          "note": "CEMPolicy.get_action end to end (sampling, rollouts, cost gather, top-k, refit)"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and N >= 1000 and not args.group_norm and not ra:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and N >= 1000 and not args.group_norm:
         # the oracle re-rolls the GPU's OWN best candidates (the elite set must be right, not 64 arbitrary costs) + others
         order = np.argsort(-ro["sum_cost"], kind="stable")
         idx = np.concatenate([order[:CEM_CHECK_TOP],
                               np.random.RandomState(0).choice(order[CEM_CHECK_TOP:], CEM_CHECK_OTHERS, replace=False)])
         out["check"] = {"sd": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}, "prob": prob,
-                        "idx": idx, "gpu_sum_cost": ro["sum_cost"][idx].copy(), "gpu_top": order[:5].copy()}
+                        "idx": idx, "gpu_sum_cost": ro["sum_cost"][idx].copy(), "gpu_top": order[:5].copy(), "ra": ra}
+        if ra:
+            # the robot model's answer for the checked candidates (a candidate's states and masks depend on nothing but its
+            # own actions): what the oracle's rollout of them is fed
+            st, mk = pol.traj_sampler._predict_robot(prob["actions"][torch.from_numpy(idx)], start, len(idx), horizon - 1)
+            out["check"]["states"], out["check"]["masks"] = st.float().cpu(), mk.float().cpu()
     return out
 
 
@@ -504,6 +587,33 @@ def cpu_baseline(train, cem):
     return out
 
 
+def check_cem_ra(cem_ra):
+    """The robot-aware planner's costs against the oracle: the GPU's own top 32 + 32 others re-rolled on the CPU with the
+    states and masks the device-side robot model gave those candidates; sum_cost <= 1e-5 of the largest, and the ranking of
+    the GPU's elites wherever neighbours are further apart than 10 x the error."""
+    from oracle import svg_oracle as orc
+    ck = cem_ra["check"]
+    idx = ck["idx"]
+    n = len(idx)
+    ccfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=n, candidates_batch_size=n, sample_mean=True, reward_type="dontcare", **RA)
+    prob = ck["prob"]
+    t0 = time.perf_counter()
+    ref = orc.cem_rollouts(ck["sd"], ccfg, prob["actions"][idx], prob["start_img"], prob["goal_imgs"], prob["goal_masks"],
+                           ck["states"], ck["masks"])["sum_cost"]
+    t_cem = time.perf_counter() - t0
+    got = ck["gpu_sum_cost"]
+    err = float(np.abs(got - ref).max() / np.abs(ref).max())
+    assert err <= 1e-5, ("robot-aware GPU rollout costs drifted from the oracle", err)
+    order = np.argsort(-ref[:CEM_CHECK_TOP], kind="stable")
+    gaps = np.abs(np.diff(ref[:CEM_CHECK_TOP][order])) / np.abs(ref).max()
+    resolvable = gaps[:5] > 10 * err
+    same = all(got[order[i]] > got[order[i + 1]] for i in np.nonzero(resolvable)[0])
+    assert same, ("robot-aware GPU elite order differs from the oracle's where the gap resolves it", gaps[:5], err)
+    return {"cem_ra_sum_cost_rel_err": err, "cem_ra_top5_gaps_resolved": int(resolvable.sum()),
+            "cem_ra_top5_order_identical_where_resolved": bool(same), "cem_ra_top5_min_gap_rel": float(gaps[:5].min()),
+            "cem_ra_cpu_rollouts_per_s": n / t_cem}
+
+
 def exact_fp32_runs(args, dev, rank, world, distributed, train, cem):
     """The same workloads with every conv on the exact-fp32 MFMA kernels (ops.SPLIT_GEMM off; v_mfma_f32_32x32x2_f32,
     peak 157.3 TFLOP/s): what the split-precision operand format buys, and what it costs in accuracy -- the first train
@@ -569,6 +679,12 @@ def main():
                     help="N > 1: time only the chosen gradient-exchange mode (default: both, reported under `ddp_modes`)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[4] per-GPU side line (`side.cfg5`)")
     ap.add_argument("--side-steps", type=int, default=5, help="timed steps of the configs[4] per-GPU side line")
+    ap.add_argument("--deployed", action="store_true",
+                    help="train workload in the deployed checkpoints' configuration (g 256, --lstm_group_norm True, 48x64, "
+                         "future robot state); not the headline")
+    ap.add_argument("--sched", default=None, choices=["all", "mix"],
+                    help="train workload with the scheduled-sampling coin forced: every frame after the first fed back "
+                         "(all) or every other one (mix); not the headline")
     ap.add_argument("--group-norm", action="store_true",
                     help="both workloads with --lstm_group_norm True (NormConvLSTMCell; not the headline config)")
     args = ap.parse_args()
@@ -586,6 +702,9 @@ def main():
     if os.environ.get("RAC_BENCH_ONE_GPU") == "1":
         local = 0
         os.environ["LOCAL_RANK"] = "0"
+    elif torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node shows {torch.cuda.device_count()} device(s): one rank "
+                         f"per GPU (RAC_BENCH_ONE_GPU=1 + RAC_DIST_BACKEND=gloo rehearses N ranks on one card)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if distributed:
@@ -597,6 +716,17 @@ def main():
     torch.manual_seed(1234)
     np.random.seed(1234)
     os.environ.setdefault("RAC_GC_FREEZE", "1")  # the benchmark process builds its objects once
+    dist_info = None
+    if distributed:
+        # what the collective library itself saw: its backend, its world size, and the card behind every rank
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": dist.get_rank(), "index": dev.index, "uuid": str(getattr(props, "uuid", "")), "name": props.name}
+        cards = [None] * dist.get_world_size()
+        dist.all_gather_object(cards, mine)
+        dist_info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                     "devices": sorted(cards, key=lambda c: c["rank"])}
+        if os.environ.get("RAC_BENCH_ONE_GPU") != "1" and len({(c["index"], c["uuid"]) for c in cards}) != len(cards):
+            raise SystemExit(f"bench.py: two ranks share a device: {cards}")
 
     out = {"metric": "SVG train frames/sec + CEM candidate-rollouts/sec, 64x64", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak",
@@ -613,27 +743,45 @@ def main():
             # the flags chose (all-reduce unless --shard-optimizer); a failure of the other mode is recorded, not fatal.
             def mode_line(t):
                 ph = t["phases"] or {}
-                return {"ms_per_step": t["ms_per_step"], "frames_per_s": t["frames_per_s"],
+                line = {"ms_per_step": t["ms_per_step"], "frames_per_s": t["frames_per_s"],
                         "allreduce_exposed": ph.get("allreduce_exposed"), "adam": ph.get("adam"),
-                        "rank_ms_per_step": t["rank_ms_per_step"]}
+                        "rank_ms_per_step": t["rank_ms_per_step"], "optimizer": t["optimizer"]["optimizer"]}
+                if t["optimizer"]["shard_requested"] and t["optimizer"]["optimizer"] != "ShardedAdam":
+                    line["fallback"] = "sharded optimiser not available at this world size: this line IS all-reduce + full Adam"
+                return line
             this, other = ("sharded", "allreduce") if args.shard_optimizer else ("allreduce", "sharded")
             ddp_modes = {this: mode_line(train), "headline": this}
             oa = argparse.Namespace(**vars(args))
             oa.shard_optimizer = not args.shard_optimizer
+            # the other mode may fail on ONE rank (out of memory, a collective error): the ranks agree on the outcome before
+            # anyone records it -- a rank that failed alone would otherwise leave the rest inside a collective
+            res, failure = None, None
             try:
-                ddp_modes[other] = mode_line(bench_train(oa, dev, rank, world, distributed))
-            except Exception as e:  # noqa: BLE001  (every rank takes the same branch: the failure is deterministic)
-                ddp_modes[other] = {"error": f"{type(e).__name__}: {e}"}
+                res = bench_train(oa, dev, rank, world, distributed)
+            except Exception as e:  # noqa: BLE001
+                failure = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if failure is None else 1], device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            n_failed = int(flag.item())
+            if n_failed == 0:
+                ddp_modes[other] = mode_line(res)
+            elif n_failed == dist.get_world_size():
+                ddp_modes[other] = {"error": failure}
+            else:  # the ranks disagree: whatever state the group is in, this run is not a measurement
+                print(f"[bench] rank {rank}: the second gradient-exchange mode failed on {n_failed} of "
+                      f"{dist.get_world_size()} ranks ({failure})", file=sys.stderr, flush=True)
+                os._exit(3)
             torch.cuda.empty_cache()
     cem_ra = None
     if args.workload in ("both", "cem"):
-        cem = bench_cem(args, dev, rank, world, distributed)
+        cem = bench_cem(args, dev, rank, world, distributed, deployed=args.deployed)
         torch.cuda.empty_cache()
-        if not args.no_cem_ra and not args.group_norm:
+        if not args.no_cem_ra and not args.group_norm and not args.deployed:
             cem_ra = bench_cem(args, dev, rank, world, distributed, ra=True)
             torch.cuda.empty_cache()
     side = None
-    if train is not None and not args.no_side and not (args.h48 or args.cfg5 or args.group_norm):
+    headline = not (args.h48 or args.cfg5 or args.group_norm or args.deployed or args.sched)
+    if train is not None and not args.no_side and headline:
         # BASELINE configs[4] per GPU (128x128 frames, bs 8, n_future 10: the shard one of 8 DDP ranks trains on), driver-timed
         sa = argparse.Namespace(**vars(args))
         sa.cfg5, sa.steps, sa.warmup = True, args.side_steps, 2
@@ -647,8 +795,45 @@ def main():
                          "step_achieved": st["step_tflops_per_gpu"], "step_peak": SPLIT_PEAK_TFLOPS,
                          "step_frac": st["step_tflops_per_gpu"] / SPLIT_PEAK_TFLOPS,
                          "time_breakdown_ms": st["phases"]}}
+    if train is not None and not args.no_side and headline:
+        # the paths the reference's own command lines take (README.md:103,111: --scheduled_sampling True;
+        # evaluate_checkpoint.py:40-46: --lstm_group_norm True, g 256; config/__init__.py:165-171: 48 x 64 frames)
+        def train_side(**switches):
+            sa = argparse.Namespace(**vars(args))
+            sa.steps, sa.warmup = args.side_steps, 2
+            for k_, v_ in switches.items():
+                setattr(sa, k_, v_)
+            st = bench_train(sa, dev, rank, world, distributed)
+            torch.cuda.empty_cache()
+            return {"value": st["frames_per_s"], "unit": "frames/s", "ms_per_step": st["ms_per_step"],
+                    "steps": st["steps"], "warmup": 2,
+                    "config": {"workload": st["workload"], "global_batch": st["global_batch"],
+                               "parallelism": f"ddp{world}", "algorithmic_tflop_per_step_per_gpu": st["step_tflop"]},
+                    "step_achieved": st["step_tflops_per_gpu"], "step_peak": SPLIT_PEAK_TFLOPS,
+                    "step_frac": st["step_tflops_per_gpu"] / SPLIT_PEAK_TFLOPS, "time_breakdown_ms": st["phases"]}
+        side = side or {}
+        side["sched"] = train_side(sched="all")
+        side["sched"]["vs_teacher_forced"] = side["sched"]["ms_per_step"] / train["ms_per_step"]
+        side["sched_mix"] = train_side(sched="mix")
+        side["sched_mix"]["vs_teacher_forced"] = side["sched_mix"]["ms_per_step"] / train["ms_per_step"]
+        side["deployed_train"] = train_side(deployed=True)
+        side["deployed_train_sched"] = train_side(deployed=True, sched="all")
+    if cem is not None and not args.no_side and headline:
+        dc = bench_cem(args, dev, rank, world, distributed, deployed=True)
+        torch.cuda.empty_cache()
+        side = side or {}
+        side["deployed_cem"] = {"value": dc["rollouts_per_s"], "unit": "candidate-rollouts/s",
+                                "s_per_iteration": dc["s_per_iter"],
+                                "config": {"workload": "CEM rollouts through the reference's deployed model (evaluate_checkpoint.py:"
+                                                       "40-46, vanilla line): g 256 / z 64, --lstm_group_norm True, 48x64 frames, "
+                                                       "1000 candidates/GPU x horizon 15, dense image cost",
+                                           "candidates": dc["candidates"], "candidates_batch_size": dc["candidates_batch_size"],
+                                           "parallelism": f"candidate-shard{world}",
+                                           "algorithmic_gflop_per_candidate_step": dc["gflop_per_candidate_step"]},
+                                "achieved_tflops_per_gpu": dc["tflops_per_gpu"],
+                                "frac_of_split_peak": dc["tflops_per_gpu"] / SPLIT_PEAK_TFLOPS}
     exact = arith_err = None
-    if not args.no_exact and not (args.h48 or args.cfg5 or args.group_norm):
+    if not args.no_exact and headline:
         exact, arith_err = exact_fp32_runs(args, dev, rank, world, distributed, train, cem)
 
     if train is not None:
@@ -676,19 +861,21 @@ def main():
         for key in ("sustained_mfma_peak", "frac_of_sustained"):  # informational (profiles/r03_mfma_power.md)
             if key in kr:
                 out["roofline"][key] = kr[key]
-        if not (args.h48 or args.cfg5 or args.group_norm):
+        if headline:
             out["roofline"]["kernel"] = ("conv16_tile_kernel: FWD 5x5 ConvLSTM gate conv as GEMM (M=%d, N=2048, K=25600)"
                                          % (train["cf"].batch_size * 64))
         tail = pmc_tail("train")
         if tail:
             out["roofline"]["tail"] = tail
         out["time_breakdown_ms"] = train["phases"]
-        if out["time_breakdown_ms"] is not None and os.environ.get("RAC_ADAM_OVERLAP", "1") == "1":
+        out["optimizer"] = train["optimizer"]
+        if train["optimizer"]["late_update_overlapped"]:
             # (optim.FusedAdam.overlap_next_forward: `adam` is the part on the main stream; the large weights' update runs on
             # a side stream under the next step's `forward`, which it stretches)
-            out["time_breakdown_ms"]["note"] = "adam: main-stream part only; the large weights' update overlaps the next forward"
+            out["time_breakdown_note"] = "adam: main-stream part only; the large weights' update overlaps the next forward"
         if distributed:
             out["ranks"] = {"train_ms_per_step": train["rank_ms_per_step"]}
+            out["dist"] = dist_info
         if ddp_modes is not None:
             out["ddp_modes"] = ddp_modes
         # the SCALE record's per-N fields: the driver computes efficiency from the per-N values itself
@@ -747,8 +934,12 @@ def main():
         out["side"] = side
     if exact is not None:
         out["fp32_exact"] = exact
+    if distributed and "dist" not in out:
+        out["dist"] = dist_info
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb = cpu_baseline(train, cem)
+        if cem_ra is not None and cem_ra["check"] is not None:
+            cb.setdefault("checked", {}).update(check_cem_ra(cem_ra))  # (the robot-aware line's own check)
         if cb.get("sample"):
             out["cpu_baseline"] = cb
         # split-precision vs exact fp32 vs the oracle, on the same first train step and the same checked candidates

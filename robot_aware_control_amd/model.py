@@ -383,6 +383,9 @@ class SVGConvModel(nn.Module):
             self._flatten()
         ops._STALE.clear()
         if not (lazy and self._lazy_params):
+            # an optimiser update still running on a side stream (optim.FusedAdam.overlap_next_forward) READS the late
+            # weights' gradients: a whole-buffer fill on this stream must come behind it (the lazy form never touches them)
+            ops.param_wait()
             self._flat_grad.zero_()
         for p in self.parameters():
             off = p._rac_off
@@ -406,6 +409,9 @@ class SVGConvModel(nn.Module):
                 m.pending_updates = 0
 
     def state_dict(self, *a, **k):
+        # (an optimiser update still in flight -- FusedAdam's late weights on a side stream, ShardedAdam's all-gather --
+        # must land before anyone reads the parameters through the returned views)
+        ops.param_wait()
         self._flush_bn_counters()
         sd = super().state_dict(*a, **k)
         return sd
@@ -591,6 +597,9 @@ class SVGConvModel(nn.Module):
         """`staged`: the caller waits for the later parameter groups itself (forward_sequence_maps: the recurrent core takes
         its chains' weights as they arrive); otherwise everything is waited for behind the encoder."""
         gate = ops.PARAM_GATE  # an optimiser update still in flight: optim.ShardedAdam's all-gather, FusedAdam's late groups
+        if gate is not None and getattr(gate, "_model", self) is not self:
+            gate.wait_params()  # another model's optimiser (a previous trainer of this process): let it land and drop it
+            gate = ops.PARAM_GATE = None
         if gate is not None:
             gate.wait_params(upto=self._encoder_extent())
         out = self._encode_now(image, mask, heatmap, zero_mask, n_updates, groups)

@@ -49,6 +49,8 @@ class FusedAdam(torch.optim.Optimizer):
             return
         flat, _ = self._model.flat_parameters()
         lo = (t.data_ptr() - flat.data_ptr()) // 4
+        if lo < 0 or lo >= flat.numel():
+            return  # not a view of this model's flat parameter buffer
         hi = lo + t.numel()
         hit = [k for k, (_, spans) in enumerate(self._late) if any(off < hi and lo < off + n for off, n in spans)]
         if not hit:
@@ -63,6 +65,8 @@ class FusedAdam(torch.optim.Optimizer):
             return True
         flat, _ = self._model.flat_parameters()
         lo = (t.data_ptr() - flat.data_ptr()) // 4
+        if lo < 0 or lo >= flat.numel():
+            return True  # not a view of this model's flat parameter buffer
         hi = lo + t.numel()
         return all(not (off < hi and lo < off + n) for _, spans in self._late for off, n in spans)
 

@@ -651,6 +651,11 @@ class PredictionTrainer(object):
                 if test_hook is not None:
                     test_hook(self, epoch)
         self._save_checkpoint()
+        # nothing of this loop's optimiser stays installed behind it (ops.PARAM_GATE is process-global: it would pin the
+        # trainer's 4 GB and be asked about the next model's parameters)
+        self.optimizer.wait_params()
+        if ops.PARAM_GATE is self.optimizer:
+            ops.PARAM_GATE = None
         return info
 
     def _setup_data(self):

@@ -217,6 +217,14 @@ def test_bench_two_ranks_rehearsal():
     assert modes["headline"] == "allreduce" and modes["allreduce"]["ms_per_step"] == out["ms_per_step"]
     assert modes["sharded"].get("ms_per_step", 0) > 0, modes["sharded"]
     assert modes["sharded"]["allreduce_exposed"] is not None and len(modes["sharded"]["rank_ms_per_step"]) == 2
+    # each mode line names the optimiser class that really ran (a world size the sharded step cannot cut falls back)
+    assert modes["allreduce"]["optimizer"] == "FusedAdam" and modes["sharded"]["optimizer"] == "ShardedAdam"
+    assert "fallback" not in modes["sharded"] and out["optimizer"]["optimizer"] == "FusedAdam"
+    # what the collective library saw: backend, world size, the card behind every rank
+    d = out["dist"]
+    assert d["backend"] == "gloo" and d["world_size"] == 2 and [c["rank"] for c in d["devices"]] == [0, 1]
+    assert all(c["index"] == 0 and c["name"] for c in d["devices"])  # (the rehearsal: both ranks on this box's one card)
+    assert all(isinstance(v, (int, float)) for v in out["time_breakdown_ms"].values())
     cem = out["cem"]
     assert cem["config"]["parallelism"] == "candidate-shard2" and cem["config"]["candidates"] == 128
     assert cem["ranks"]["cost_allgather_ms"] is not None and len(cem["ranks"]["s_per_iteration"]) == 2

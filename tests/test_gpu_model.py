@@ -870,3 +870,62 @@ def test_device_prefetcher_matches_process_batch(dev):
         for k in ("images", "masks", "states", "actions", "qpos"):
             assert got[k].shape == ref[k].shape and got[k].is_contiguous() and torch.equal(got[k], ref[k]), k
         assert got["robot"] == ref["robot"]
+
+
+@pytest.mark.parametrize("lazy,late_groups", [(True, "0"), (False, "0"), (True, "1")])
+def test_overlapped_optimizer_update_end_to_end(dev, tmp_path, monkeypatch, lazy, late_groups):
+    """optim.FusedAdam.overlap_next_forward (on in PredictionTrainer.train and bench.py): the large weights' update runs on
+    a side stream under the next step's encoder.  The whole ordering chain -- ops.PARAM_GATE, the encoder's staged wait, the
+    recurrent core's per-chain waits, `ops.param_wait()` before the decoder, the per-step (scheduled-sampling) path, an
+    evaluation between two steps, `state_dict()` right after a step, `_save_checkpoint`, a plain (whole-buffer) zero_grad,
+    the staged late groups -- against the same loop with the update on the main stream.  The step is deterministic up to the
+    fp32 atomics of the bias column sums, so the two runs agree to rounding (held to 1e-6 norm-wise per tensor); a reader
+    that missed its wait sees a weight one optimiser step old: >= 1e-3 at this learning rate."""
+    from robot_aware_control_amd import ops
+    monkeypatch.setattr(ops, "LAZY_ZERO_GRAD", lazy)
+    monkeypatch.setenv("RAC_ADAM_LATE_GROUPS", late_groups)
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-3, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=3, randomize_bn_stats=False)
+
+    def run(overlap):
+        tr = make_trainer(cfg, sd, dev, log_dir=str(tmp_path / f"overlap{int(overlap)}"), n_eval=5, test_batch_size=4)
+        tr.optimizer.overlap_next_forward = overlap
+        gen = torch.Generator().manual_seed(17)
+        tr.model.eps_source = lambda shape: torch.randn(shape, generator=gen)
+        seen_late, sd_mid, ev = 0, None, None
+        for step in range(6):
+            data = syn.synth_video(seed=50 + step, T=5, B=4)
+            sched = step % 2 == 1  # every other window feeds predicted frames back: the per-step autograd path
+            tr.model.used_recurrent_core = False
+            tr._train_step(data, use_truth=[True, True, False, True, False] if sched else None)
+            assert tr.model.used_recurrent_core != sched
+            seen_late += int(ops.PARAM_GATE is tr.optimizer)
+            if step == 2:  # a direct reader between two steps: the late weights must have landed in what it returns
+                sd_mid = {k: v.detach().clone() for k, v in tr.model.state_dict().items()}
+            if step == 3:  # an evaluation between two steps (frozen model: folded BatchNorm, per-image scales)
+                tr.model.eval()
+                ev = tr._eval_video({**syn.synth_video(seed=77, T=5, B=4)}, autoregressive=True)
+                tr.model.train()
+            if step == 4:
+                tr._step = 4
+                path = tr._save_checkpoint()
+        assert (seen_late >= 3) == overlap, seen_late  # (the first steps take plain Adam: parts not current yet)
+        flat = tr.model.flat_parameters()[0]
+        tr.optimizer.wait_params()
+        torch.cuda.synchronize()
+        out = {"flat": flat.detach().clone(), "m": tr.optimizer._m.clone(), "v": tr.optimizer._v.clone(),
+               "ev": torch.tensor([ev[k] for k in sorted(ev)])}
+        out.update({"mid:" + k: v.float() for k, v in sd_mid.items()})
+        ck = torch.load(path, map_location=dev)
+        out.update({"ckpt:" + k: v.float() for k, v in ck["model"].items()})
+        st = ck["optimizer"]["state"]
+        out["ckpt_m"] = torch.cat([st[i]["exp_avg"].reshape(-1) for i in sorted(st)])
+        ops.PARAM_GATE = None
+        return out
+
+    ref, got = run(False), run(True)
+    assert set(ref) == set(got)
+    for k, b in ref.items():
+        a = got[k]
+        err = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        assert err < 1e-6, (k, err)

@@ -75,3 +75,9 @@ def test_bench_under_torchrun_one_rank_rccl():
     assert out["fp32_exact"]["train"]["ms_per_step"] > 0 and out["fp32_exact"]["cem"]["rollouts_per_s"] > 0
     assert out["side"]["cfg5"]["value"] > 0 and "128x128" in out["side"]["cfg5"]["config"]["workload"]
     assert out["ddp_modes"]["sharded"].get("ms_per_step", 0) > 0, out["ddp_modes"]
+    assert out["ddp_modes"]["sharded"]["optimizer"] == "ShardedAdam"
+    # the side lines of the paths the reference's own command lines take: scheduled sampling, the deployed GroupNorm model
+    for key in ("sched", "sched_mix", "deployed_train", "deployed_train_sched"):
+        assert out["side"][key]["value"] > 0 and 0 < out["side"][key]["step_frac"] < 1, key
+    assert out["side"]["deployed_cem"]["value"] > 0 and 0 < out["side"]["deployed_cem"]["frac_of_split_peak"] < 1
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["world_size"] == 1 and out["dist"]["devices"][0]["uuid"]
