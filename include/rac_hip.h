@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 9
+#define RAC_ABI_VERSION 10
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -270,13 +270,16 @@ int rac_slice_channels(const float* src, int32_t Csrc, int32_t off, int32_t n, f
 /* dst[m] = [a[m][0:Ca] | b[m][0:Cb]]  (a or b NULL: zeros) -- the gradient of the split above */
 int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, float* dst, int64_t M, uint32_t* out_amax,
                       void* stream);
-/* out[c] += sum_m x[m][c]   (bias gradients) */
-int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream);
+/* out[c] += sum_m x[m][c]   (bias gradients).  `parts`: scratch of rac_colsum_blocks(M, C) * C floats -- every workgroup
+ * stores its row block's sums there and a second launch adds the blocks in a fixed order (a bit-reproducible gradient);
+ * NULL: one fp32 atomic per (workgroup, column), whose order is not. */
+int rac_colsum_acc(const float* x, float* out, float* parts, int64_t M, int32_t C, void* stream);
+int64_t rac_colsum_blocks(int64_t M, int32_t C);
 
 /* out[c] += sum_{t < T} sum_m xs[t][m][c]: the bias gradient of a conv applied at T time steps (T <= RAC_WGRAD_MAX_STEPS,
  * `xs` a HOST array of T device pointers to [M][C] tensors) in one launch: rac_colsum_acc with every workgroup walking
- * its rows in all T tensors. */
-int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, int32_t C, void* stream);
+ * its rows in all T tensors (`parts` as above). */
+int rac_colsum_steps(const float* const* xs, int32_t T, float* out, float* parts, int64_t M, int32_t C, void* stream);
 
 /* out[i] = sum_s slabs[s*slab_stride + i] + bias[i % N]   (deterministic split-K combine; bias may be NULL) */
 int rac_slab_reduce(const float* slabs, int32_t n_slabs, int64_t slab_stride, const float* bias, float* out,

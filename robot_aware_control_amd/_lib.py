@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 9  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 10  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -104,12 +104,13 @@ _SIGS = {
     "rac_pad_rows": [vp, i32, vp, i32, i64, vp],
     "rac_unpad_add": [vp, i32, vp, i32, i64, vp],
     "rac_slice_channels": [vp, i32, i32, i32, vp, i64, vp],
-    "rac_colsum_acc": [vp, vp, i64, i32, vp],
+    "rac_colsum_acc": [vp, vp, vp, i64, i32, vp],
+    "rac_colsum_blocks": [i64, i32],
     "rac_slab_reduce": [vp, i32, i64, vp, vp, i64, i32, vp, vp],
     "rac_slab_reduce_stats": [vp, i32, i64, vp, vp, i64, i32, i32, vp, vp],
     "rac_slab_reduce2": [vp, i32, i64, vp, vp, vp, i64, i32, i32, vp, vp, vp],
     "rac_cat2_channels": [vp, i32, vp, i32, vp, i64, vp, vp],
-    "rac_colsum_steps": [C.POINTER(vp), i32, vp, i64, i32, vp],
+    "rac_colsum_steps": [C.POINTER(vp), i32, vp, vp, i64, i32, vp],
     "rac_col_stats": [vp, vp, i64, i32, i32, vp],
     "rac_act_bwd": [vp, vp, i32, vp, i64, vp],
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
@@ -151,7 +152,7 @@ _SIGS = {
     "rac_device_arch": [],
     "rac_last_error": [],
 }
-_RET = {"rac_device_arch": C.c_char_p, "rac_last_error": C.c_char_p, "rac_absmax_blocks": i64,
+_RET = {"rac_device_arch": C.c_char_p, "rac_last_error": C.c_char_p, "rac_absmax_blocks": i64, "rac_colsum_blocks": i64,
         "rac_weight_frag_blocks": i64}
 EXPORTS = tuple(_SIGS)
 

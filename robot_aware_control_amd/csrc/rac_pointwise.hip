@@ -466,7 +466,9 @@ struct ColsumSteps {
   const float* x[RAC_WGRAD_MAX_STEPS];
   int T;
 };
-__global__ void colsum_steps_kernel(ColsumSteps p, float* out, long M, int C, int rows_per_block) {
+// `parts` given: the workgroup's column sums are STORED at parts[blockIdx.x][c] (colsum_parts_add_kernel then adds the
+// row blocks in a fixed order: a bit-reproducible bias gradient); NULL: one fp32 atomic per (workgroup, column).
+__global__ void colsum_steps_kernel(ColsumSteps p, float* out, float* parts, long M, int C, int rows_per_block) {
   __shared__ float s1[256];
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;  // 4 row lanes
@@ -480,13 +482,27 @@ __global__ void colsum_steps_kernel(ColsumSteps p, float* out, long M, int C, in
     }
   s1[threadIdx.x] = a;
   __syncthreads();
-  if (threadIdx.x < 64 && c < C) atomicAdd(out + c, (s1[threadIdx.x] + s1[threadIdx.x + 64]) +
-                                                        (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]));
+  if (threadIdx.x < 64 && c < C) {
+    const float v = (s1[threadIdx.x] + s1[threadIdx.x + 64]) + (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]);
+    if (parts)
+      parts[(long)blockIdx.x * C + c] = v;
+    else
+      atomicAdd(out + c, v);
+  }
+}
+
+// out[c] += parts[0][c] + parts[1][c] + ... in that order (the second stage of the deterministic column sums)
+__global__ void colsum_parts_add_kernel(const float* parts, int nb, float* out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f;
+  for (int b = 0; b < nb; ++b) a += parts[(long)b * C + c];
+  out[c] += a;
 }
 
 // grid = (row blocks, 64-channel groups): bias gradients of the 4g-wide gate tensors have few rows (B*64) and many
 // channels, so both dimensions are needed to fill the chip.
-__global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int rows_per_block) {
+__global__ void colsum_acc_kernel(const float* x, float* out, float* parts, long M, int C, int rows_per_block) {
   __shared__ float s1[256];
   const int c = blockIdx.y * 64 + (threadIdx.x & 63);
   const int rl = threadIdx.x >> 6;  // 4 row lanes
@@ -497,8 +513,13 @@ __global__ void colsum_acc_kernel(const float* x, float* out, long M, int C, int
     for (long r = r_begin + rl; r < r_end; r += 4) a += x[r * C + c];
   s1[threadIdx.x] = a;
   __syncthreads();
-  if (threadIdx.x < 64 && c < C) atomicAdd(out + c, (s1[threadIdx.x] + s1[threadIdx.x + 64]) +
-                                                        (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]));
+  if (threadIdx.x < 64 && c < C) {
+    const float v = (s1[threadIdx.x] + s1[threadIdx.x + 64]) + (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]);
+    if (parts)
+      parts[(long)blockIdx.x * C + c] = v;
+    else
+      atomicAdd(out + c, v);
+  }
 }
 
 __global__ void slab_reduce_kernel(const float* slabs, int n_slabs, long slab_stride, const float* bias, float* out,
@@ -919,6 +940,21 @@ static int rows_per_block_for(long M, int* nblocks) {
   return rpb;
 }
 
+// Workgroups (all groups together) of a per-channel reduction over `bytes` of operands that ends in 2 C fp64 atomics per
+// workgroup: t(nb) = bytes / (nb x ~30 GB/s per workgroup: 32 KB in flight over a ~1 us round trip)  +  nb x 2 C x ~0.25 ns
+// is least at nb = 0.35 sqrt(bytes / 2 C) per group (RAC_BN_REDUCE_COEF: the factor, for tools/bench_bn_reduce.py); never fewer than 8 per group, never more than 1024 in all (the large tensors:
+// enough workgroups to stream at the HBM rate, whose atomics then hide under the other workgroups' loads).
+static int reduce_blocks_for(long bytes, int C, int groups) {
+  static const bool old = getenv("RAC_BN_REDUCE_OLD") && getenv("RAC_BN_REDUCE_OLD")[0] == '1';  // A/B: round 5's counts
+  if (old) return bytes / 2 <= (24L << 20) ? 256 : 1024;
+  static const double coef = [] { const char* e = getenv("RAC_BN_REDUCE_COEF"); return e ? atof(e) : 0.35; }();
+  const double per_group = (double)bytes / groups;
+  long nb = (long)(coef * sqrt(per_group / (2.0 * C)) + 0.5);
+  if (nb < 8) nb = 8;
+  nb *= groups;
+  return (int)(nb > 1024 ? 1024 : nb);
+}
+
 // the row-walking BatchNorm backward kernels: C = 4 * 2^k <= 1024; `bpg` workgroups per statistics group (about
 // `max_blocks` in total), each a whole number of 256 / (C / 4)-row passes
 static bool bn_rows_form(int C, long Mg, int groups, int max_blocks, int* bpg, int* rows_per_block) {
@@ -945,15 +981,14 @@ int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const
   int rpb;
   const long Mg = M / groups;
   int bpg_rows, rpb_rows;
-  // Every workgroup ends in 8 fp64 atomics per channel quad onto the same 2 C addresses of its group.  A large tensor wants
-  // ~1024 workgroups for its bytes; a small one (the 8x8 / 16x16 layers: 10-21 MB) is not bound by bytes at all -- its pass
-  // took 27 us warm or cold, against 13 for the apply pass over the same tensors -- but by that contention: 256 workgroups
-  // (47 per group instead of 128) run it in 16 us (tools/bench_bn_reduce.py; in the train step the pass runs beside the side
-  // stream's weight gradients and the step time does not move: 23.04 / 23.00 / 23.05 ms).  (Copies of the accumulators, a
-  // workgroup adding into copy index mod R, were built and measured: the reduce pass gains what the apply pass then loses
-  // summing the copies.)
+  // Every workgroup ends in 8 fp64 atomics per channel quad onto the same 2 C addresses of its group: what bounds the pass
+  // on all but the largest tensors is the NUMBER of those atomics (workgroups x 2 C; measured ~0.25 ns each: the 8x8 x 512
+  // layer of one time step, 4 MB of operands, took 25 us on 128 workgroups = 131 k atomics), not the bytes -- see
+  // reduce_blocks_for: the workgroup count that balances a workgroup's streaming time against the atomics behind it.
+  // (Copies of the accumulators, a workgroup adding into copy index mod R, were built and measured in round 4: the reduce
+  // pass gains what the apply pass then loses summing the copies.)
   static const int reduce_blocks_env = [] { const char* e = getenv("RAC_BN_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int reduce_blocks = reduce_blocks_env > 0 ? reduce_blocks_env : ((long)M * C * 4 <= (24L << 20) ? 256 : 1024);
+  const int reduce_blocks = reduce_blocks_env > 0 ? reduce_blocks_env : reduce_blocks_for(2L * M * C * 4, C, groups);
   if (bn_rows_form(C, Mg, groups, reduce_blocks, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
       aligned16(shift) && aligned16(mean) && aligned16(invstd)) {
     hipLaunchKernelGGL(bn_bwd_reduce_rows_kernel, dim3(bpg_rows * groups), dim3(256), 0, ST(stream), (const f32x4*)dy,
@@ -1087,7 +1122,13 @@ int rac_cat2_channels(const float* a, int32_t Ca, const float* b, int32_t Cb, fl
   return check_launch("rac_cat2_channels");
 }
 
-int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, int32_t C, void* stream) {
+int64_t rac_colsum_blocks(int64_t M, int32_t C) {
+  if (M <= 0 || C <= 0) return 0;
+  int rpb;
+  return (int64_t)reduce_grid(M, C, &rpb).x;
+}
+
+int rac_colsum_steps(const float* const* xs, int32_t T, float* out, float* parts, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(xs && out && T >= 1 && T <= RAC_WGRAD_MAX_STEPS && M > 0 && C > 0, "rac_colsum_steps: bad args");
   ColsumSteps p{};
   p.T = T;
@@ -1097,15 +1138,19 @@ int rac_colsum_steps(const float* const* xs, int32_t T, float* out, int64_t M, i
   }
   int rpb;
   dim3 grid = reduce_grid(M, C, &rpb);
-  hipLaunchKernelGGL(colsum_steps_kernel, grid, dim3(256), 0, ST(stream), p, out, (long)M, C, rpb);
+  hipLaunchKernelGGL(colsum_steps_kernel, grid, dim3(256), 0, ST(stream), p, out, parts, (long)M, C, rpb);
+  if (parts)
+    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
   return check_launch("rac_colsum_steps");
 }
 
-int rac_colsum_acc(const float* x, float* out, int64_t M, int32_t C, void* stream) {
+int rac_colsum_acc(const float* x, float* out, float* parts, int64_t M, int32_t C, void* stream) {
   RAC_REQUIRE(x && out && M > 0 && C > 0, "rac_colsum_acc: bad args");
   int rpb;
   dim3 grid = reduce_grid(M, C, &rpb);
-  hipLaunchKernelGGL(colsum_acc_kernel, grid, dim3(256), 0, ST(stream), x, out, (long)M, C, rpb);
+  hipLaunchKernelGGL(colsum_acc_kernel, grid, dim3(256), 0, ST(stream), x, out, parts, (long)M, C, rpb);
+  if (parts)
+    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
   return check_launch("rac_colsum_acc");
 }
 
@@ -1148,7 +1193,9 @@ int rac_slab_reduce_stats(const float* slabs, int32_t n_slabs, int64_t slab_stri
   RAC_REQUIRE(slabs && out && stats && n_slabs >= 1 && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
               "rac_slab_reduce_stats: bad args");
   int bpg, rpb;
-  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, out_amax ? 512 : 2048, &bpg, &rpb) && slab_stride % 4 == 0 &&
+  // (the statistics' fp64 atomics bound this pass too: see reduce_blocks_for; the slabs read + the map written)
+  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, reduce_blocks_for((long)(n_slabs + 1) * M * C * 4, C, groups), &bpg, &rpb) &&
+                  slab_stride % 4 == 0 &&
                   aligned16(slabs) && aligned16(out),
               "rac_slab_reduce_stats: C must be 4 * 2^k <= 1024, 16-byte aligned slabs (use rac_slab_reduce + rac_col_stats)");
   hipLaunchKernelGGL(slab_reduce_stats_rows_kernel, dim3(bpg * groups), dim3(256), 0, ST(stream), (const f32x4*)slabs,

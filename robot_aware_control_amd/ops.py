@@ -320,7 +320,20 @@ def bias_grad_acc(dy, bias):
     if _DEFERRED is not None and M <= _COLSUM_STEPS_MAX_ROWS:
         _DEFERRED_BIAS.setdefault(id(bias), (bias, []))[1].append(dy)
         return
-    call("rac_colsum_acc", ptr(dy), ptr(grad_buffer(bias)), M, dy.shape[-1], stream_ptr())
+    call("rac_colsum_acc", ptr(dy), ptr(grad_buffer(bias)), ptr(_colsum_parts(dy.device, M, dy.shape[-1])), M,
+         dy.shape[-1], stream_ptr())
+
+
+# bias gradients are summed in two stages -- per row block, then the blocks in a fixed order -- so that a train step is
+# bit-reproducible (one fp32 atomic per workgroup and column was the step's last order-dependent fp32 sum);
+# RAC_COLSUM_ATOMIC=1: the atomics
+COLSUM_ATOMIC = os.environ.get("RAC_COLSUM_ATOMIC", "0") == "1"
+
+
+def _colsum_parts(device, M: int, Cc: int):
+    if COLSUM_ATOMIC:
+        return None
+    return torch.empty(int(_lib.load().rac_colsum_blocks(M, Cc)) * Cc, device=device, dtype=torch.float32)
 
 
 _COLSUM_STEPS_MAX_ROWS = 16384
@@ -339,7 +352,7 @@ def _flush_bias_grads():
             chunk = dys[lo:lo + _lib.WGRAD_MAX_STEPS]
             assert all(d.shape == dys[0].shape and d.is_contiguous() for d in chunk)
             xs = (C.c_void_p * len(chunk))(*[ptr(d) for d in chunk])
-            call("rac_colsum_steps", xs, len(chunk), ptr(g), M, Cc, sp)
+            call("rac_colsum_steps", xs, len(chunk), ptr(g), ptr(_colsum_parts(g.device, M, Cc)), M, Cc, sp)
 
 
 # --------------------------------------------------------------------------- #
@@ -1079,12 +1092,14 @@ def flush_deferred_wgrads_early(weights=None) -> None:
         return
     if weights is None:  # everything recorded so far (each record's operands exist: they were produced in program order)
         items = list(_DEFERRED.values())
+        bias_only = not items and bool(_DEFERRED_BIAS)
         _DEFERRED.clear()
     else:
         items = [_DEFERRED.pop(id(w)) for w in weights if id(w) in _DEFERRED]
-    if not items:
+        bias_only = False
+    if not items and not bias_only:
         return
-    dev = items[0][0].device
+    dev = items[0][0].device if items else next(iter(_DEFERRED_BIAS.values()))[0].device
     _amax_reserve(dev, 8192)
     main = torch.cuda.current_stream()
     if _SIDE["stream"] is None or _SIDE["stream"].device != dev:
@@ -1137,18 +1152,37 @@ def wgrad_on_side_stream(launch, operands, need_amax=True) -> None:
     _SIDE["done"] = done
 
 
+_FLUSH_AFTER = None  # deferred_wgrad(flush_after=n): a weight's records are launched (side stream) once n of them exist
+_VGG_STEPS = False   # ... and the vgg layers' weight gradients are recorded per step too (the encoder / decoder ran per step)
+VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
+
+
 @contextlib.contextmanager
-def deferred_wgrad(on_ready=None):
+def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
-    in stream order): the trainer starts that slice's data-parallel all-reduce there."""
-    global _DEFERRED
+    in stream order): the trainer starts that slice's data-parallel all-reduce there.
+    `flush_after` = n (the per-step autograd path of a T-frame window: n = T - 1): as soon as a weight has n recorded
+    steps they are launched on the side stream -- the backward pass walks the window from its last step to its first, so
+    all but the first step's share of every time-batched weight gradient runs under the first step's backward pass instead of
+    behind the whole pass (where 4.8 ms of them stood exposed at cfg2 with every frame fed back: profiles/r06a_*); the first
+    step's records follow when the context exits.  The hand-scheduled core launches its chains' gradients itself.
+    `vgg_steps`: the encoder and the decoder ran once per step too (a window that feeds predicted frames back): their
+    layers' weight gradients are time-batched the same way -- one launch over n steps' pixels instead of n launches of a
+    fifth of the rows each (0.06-0.12 of the pipe at 16 images per launch)."""
+    global _DEFERRED, _FLUSH_AFTER, _VGG_STEPS
     if not DEFER_WGRAD or _DEFERRED is not None:
         yield
         return
     _DEFERRED = {}
+    _FLUSH_AFTER = int(flush_after) if (flush_after and flush_after > 0 and WGRAD_STREAM and WGRAD_CHAIN_FLUSH) else None
+    _VGG_STEPS = bool(vgg_steps) and _FLUSH_AFTER is not None and VGG_WGRAD_BATCH
     _SIDE["on_ready"] = on_ready
     try:
         yield
+        if _FLUSH_AFTER is not None and (_DEFERRED or _DEFERRED_BIAS):
+            # the rest of what was launched early goes to the SAME stream: a weight's (and a bias's) two launches both
+            # read-modify-write its gradient, and only stream order keeps them apart
+            flush_deferred_wgrads_early(None)  # (also when only bias column sums are left)
         pending, _DEFERRED = _DEFERRED, None
         # largest first: their all-reduces are the longest and overlap the remaining launches
         # (ties broken by address: every data-parallel rank issues its all-reduces in the same order)
@@ -1159,6 +1193,8 @@ def deferred_wgrad(on_ready=None):
         _flush_bias_grads()
     finally:
         _DEFERRED = None
+        _FLUSH_AFTER = None
+        _VGG_STEPS = False
         _DEFERRED_BIAS.clear()
         if _SIDE["done"] is not None:  # (also on an exception: nothing may outlive the side stream's reads)
             torch.cuda.current_stream().wait_event(_SIDE["done"])
@@ -1171,7 +1207,17 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
     """weight.grad += dW on the split-precision pipe.
     `defer`: inside `deferred_wgrad()` only record the operands (the caller must not modify them afterwards)."""
     if defer and _DEFERRED is not None:
-        _DEFERRED.setdefault(id(weight), (weight, []))[1].append((dy, x0, x1))
+        rec = _DEFERRED.setdefault(id(weight), (weight, []))[1]
+        rec.append((dy, x0, x1))
+        if _FLUSH_AFTER is not None and len(rec) == _FLUSH_AFTER:
+            for t_ in (dy, x0, x1):  # operand maxima on THIS stream (a reduction launched on the side stream would leave a
+                if t_ is not None:   # tag this stream's consumers could read unordered)
+                    amax_for(t_)
+            for dy_, x0_, x1_ in rec[:-1]:
+                for t_ in (dy_, x0_, x1_):
+                    if t_ is not None:
+                        amax_for(t_)
+            flush_deferred_wgrads_early([weight])
         return
     _wgrad_split_batch([(dy, x0, x1)], weight)
 
@@ -1622,7 +1668,10 @@ class VggLayer(torch.autograd.Function):
                 else:
                     conv_wgrad_acc(draw, x0, x1, weight)
             # (the layer's weight gradient leaves the data-gradient chain: side stream, see deferred_wgrad)
-            wgrad_on_side_stream(wgrad, (draw, x0, x1), need_amax=split)
+            if _VGG_STEPS and split and not padded and wgrad_split_ok(x0, x1, weight):
+                conv_wgrad_split_acc(draw, x0, x1, weight, defer=True)  # one launch over the window's steps
+            else:
+                wgrad_on_side_stream(wgrad, (draw, x0, x1), need_amax=split)
         return dx0, dx1, None, None, None, None, None, None, None, None, None
 
 

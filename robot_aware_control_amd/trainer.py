@@ -320,7 +320,9 @@ class PredictionTrainer(object):
         truths = [True] + [(self._use_true_token() if use_truth is None else bool(use_truth[i]))
                            for i in range(2, n_steps + 1)]
         H, W = x.shape[-2], x.shape[-1]
+        sequence_taken = False
         if SEQUENCE_PATH and all(truths) and self.model.sequence_ok(bs, H, W) and x.shape[1] == bs:
+            sequence_taken = True
             # every input frame is ground truth: encoder and decoder run once over the whole window
             T = n_steps
             m_all = torch.cat([mask[:T], mask[1:T + 1]], 2) if cf.model_use_future_mask else mask[:T]
@@ -390,9 +392,14 @@ class PredictionTrainer(object):
                 reducer = ShardReducer(self.model.flat_parameters()[1], *self.optimizer.plan())
             else:
                 reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
-        # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce
+        # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce.  A window
+        # that went step by step (scheduled sampling, GroupNorm cells) launches all but its first step's share as soon as
+        # the backward pass has left the second step; the hand-scheduled core launches its chains' itself
+        stepped = not (sequence_taken and self.model.used_recurrent_core)
         try:
-            with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None):
+            with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None,
+                                    flush_after=(n_steps - 1) if stepped and n_steps > 1 else None,
+                                    vgg_steps=not sequence_taken):
                 torch.autograd.backward(roots, seeds)
                 self._mark("backward")
         finally:

@@ -878,9 +878,11 @@ def test_overlapped_optimizer_update_end_to_end(dev, tmp_path, monkeypatch, lazy
     a side stream under the next step's encoder.  The whole ordering chain -- ops.PARAM_GATE, the encoder's staged wait, the
     recurrent core's per-chain waits, `ops.param_wait()` before the decoder, the per-step (scheduled-sampling) path, an
     evaluation between two steps, `state_dict()` right after a step, `_save_checkpoint`, a plain (whole-buffer) zero_grad,
-    the staged late groups -- against the same loop with the update on the main stream.  The step is deterministic up to the
-    fp32 atomics of the bias column sums, so the two runs agree to rounding (held to 1e-6 norm-wise per tensor); a reader
-    that missed its wait sees a weight one optimiser step old: >= 1e-3 at this learning rate."""
+    the staged late groups -- against the same loop with the update on the main stream.  A train step is bit-reproducible
+    (every fp32 sum has a fixed order: the bias gradients' column sums are two-stage since round 6; what is left are fp64
+    atomics of fp32 addends, whose order does not reach an fp32 result), so the two loops must agree to the BIT -- parameters,
+    Adam moments, the mid-run state_dict, the evaluation, the checkpoint: a reader that missed its wait sees a weight one
+    optimiser step old.  (tools/debug_overlap.py prints the per-step divergence and the run-to-run floor.)"""
     from robot_aware_control_amd import ops
     monkeypatch.setattr(ops, "LAZY_ZERO_GRAD", lazy)
     monkeypatch.setenv("RAC_ADAM_LATE_GROUPS", late_groups)
@@ -927,5 +929,28 @@ def test_overlapped_optimizer_update_end_to_end(dev, tmp_path, monkeypatch, lazy
     assert set(ref) == set(got)
     for k, b in ref.items():
         a = got[k]
-        err = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
-        assert err < 1e-6, (k, err)
+        assert torch.equal(a, b), (k, float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)))
+
+
+def test_train_step_is_bit_reproducible(dev):
+    """Two runs of the same three optimiser steps (teacher-forced and fed-back windows) from the same weights, data and
+    noise: the same bits in every parameter and gradient.  No fp32 sum of the step depends on the order in which workgroups
+    finish (weight gradients combine their K split through slabs in a fixed order, bias gradients sum row blocks in a fixed
+    order; BatchNorm's fp64 atomics add fp32 values whose fp64 sum rounds to the same fp32 whatever the order)."""
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-3, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=3, randomize_bn_stats=False)
+
+    def run():
+        tr = make_trainer(cfg, sd, dev)
+        gen = torch.Generator().manual_seed(5)
+        tr.model.eps_source = lambda shape: torch.randn(shape, generator=gen)
+        out = []
+        for step in range(3):
+            tr._train_step(syn.synth_video(seed=60 + step, T=5, B=4), use_truth=[True, True, False, True, False] if step == 1 else None)
+            flat, grad = tr.model.flat_parameters()
+            out.append((flat.detach().clone(), grad.detach().clone()))
+        return out
+    a, b = run(), run()
+    for step, ((fa, ga), (fb, gb)) in enumerate(zip(a, b)):
+        assert torch.equal(ga, gb), (step, "gradients")
+        assert torch.equal(fa, fb), (step, "parameters")
