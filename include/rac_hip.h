@@ -238,6 +238,12 @@ int rac_bn_finalize(const double* stats, int64_t count, const float* gamma, cons
 /* y[m][c] = act(x[m][c]*scale[c] + shift[c]) */
 int rac_affine_act(const float* x, const float* scale, const float* shift, int32_t act, float* y, int64_t M,
                    int32_t C, int32_t groups, uint32_t* y_amax, void* stream);
+/* rac_bn_finalize followed by rac_affine_act on x in ONE launch (C = 4 * 2^k <= 1024, 16-byte aligned maps): the same
+ * arithmetic, value for value -- scale / shift / mean / invstd are still written (the backward pass reads them). */
+int rac_bn_apply_act(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int32_t n_updates, const float* x, int32_t act, float* y,
+                     float* scale, float* shift, float* mean, float* invstd, int64_t M, int32_t C, int32_t groups,
+                     uint32_t* y_amax, void* stream);
 /* sums = fp64 [2][C]: sum dz, sum dz*xhat  with z = x*scale+shift, dz = dy*(z>0?1:0.2), xhat=(x-mean)*invstd.
  * `sums` must be zero on entry. */
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
@@ -315,6 +321,15 @@ int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, c
  * NormConvLSTMCell (--lstm_group_norm True, lstm.py:151-198): GroupNorm(16, C) on NHWC maps and the
  * cell arithmetic split around the cell-state normalisation.
  * ------------------------------------------------------------------------ */
+/* The whole cell behind its two gate convs, without a tape (the frozen model: planner rollouts, evaluation), in ONE launch:
+ *   gates = GroupNorm(16, 4g)(g_ih) + GroupNorm(16, 4g)(g_hh);  i, f, o = sigmoid, g~ = tanh  (chunk order i, f, o, g~)
+ *   c = GroupNorm(16, g)(f * c_prev + i * g~);  h = o * tanh(c)                                (lstm.py:174-198)
+ * g_ih / g_hh = the convs' outputs incl. bias, [B][HW][4g]; c_prev, h, c = [B][HW][g]; g = 16 * 2^k; 16-byte aligned.
+ * One workgroup per (image, quarter of the channels): an image's result does not depend on the batch. */
+int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_prev, const float* gamma_ih,
+                           const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
+                           const float* beta_c, float* h, float* c, int32_t B, int32_t HW, int32_t g, float eps,
+                           void* stream);
 /* y = (x - mean_{b,g}) * rstd_{b,g} * gamma_c + beta_c over groups of C/G channels x HW pixels (biased variance,
  * eps); mean/rstd = fp32 [B][G] saved for the backward pass. */
 int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

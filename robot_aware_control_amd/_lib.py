@@ -94,6 +94,7 @@ _SIGS = {
     "rac_slab_accumulate": [vp, i32, i64, vp, i64, vp],
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
     "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp, vp],
+    "rac_bn_apply_act": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
     "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
     "rac_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, vp],
@@ -116,6 +117,7 @@ _SIGS = {
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "rac_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
+    "rac_norm_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "rac_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],
     "rac_lstm_out_bwd": [vp, vp, vp, vp, vp, i64, i32, vp],

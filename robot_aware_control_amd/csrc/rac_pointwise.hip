@@ -96,6 +96,77 @@ __global__ void affine_act_kernel1(const float* x, const float* scale, const flo
   if (amax) amax_commit_block(mx, amax);
 }
 
+// rac_bn_finalize + rac_affine_act in ONE launch (row-walking form, C = 4 * 2^k <= 1024): every workgroup derives the
+// (scale, shift) of its thread's four channels from the fp64 statistics itself -- bn_finalize_kernel's arithmetic, term for
+// term -- and streams its rows; the first workgroup of a group also stores the group's scale / shift / mean / invstd (what
+// the backward pass reads), workgroup 0 applies the running statistics' momentum updates of all groups in order.
+__global__ __launch_bounds__(256) void bn_apply_act_rows_kernel(const double* stats, long count, const float* gamma,
+                                                                const float* beta, float* rmean, float* rvar, float momentum,
+                                                                float eps, int n_updates, const f32x4* x, f32x4* y,
+                                                                float* scale_o, float* shift_o, float* mean_o, float* invstd_o,
+                                                                long Mg, int C4, int G, int act, int rows_per_block, int bpg,
+                                                                unsigned* amax) {
+  const int tid = threadIdx.x, C = 4 * C4;
+  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int g = blockIdx.x / bpg;
+  const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
+  const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
+  f32x4 sc, sh;
+  const bool writer = (blockIdx.x - g * bpg) == 0 && rl == 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * c4 + e;
+    const double* st = stats + (long)g * 2 * C;
+    const double mean = st[c] / (double)count;
+    double var = st[C + c] / (double)count - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    sc[e] = gamma[c] * invstd;
+    sh[e] = beta[c] - meanf * sc[e];
+    if (writer) {
+      scale_o[g * C + c] = sc[e];
+      shift_o[g * C + c] = sh[e];
+      mean_o[g * C + c] = meanf;
+      invstd_o[g * C + c] = invstd;
+    }
+  }
+  if (blockIdx.x == 0 && rl == 0 && rmean) {  // running statistics: every group's update, in order (bn_finalize_kernel)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 4 * c4 + e;
+      float rm = rmean[c], rv = rvar[c];
+      for (int gg = 0; gg < G; ++gg) {
+        const double* st = stats + (long)gg * 2 * C;
+        const double mean = st[c] / (double)count;
+        double var = st[C + c] / (double)count - mean * mean;
+        if (var < 0) var = 0;
+        const float meanf = (float)mean;
+        const float unbiased = (float)(count > 1 ? var * (double)count / (double)(count - 1) : var);
+        for (int i = 0; i < n_updates; ++i) {
+          rm = (1.f - momentum) * rm + momentum * meanf;
+          rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+      }
+      rmean[c] = rm;
+      rvar[c] = rv;
+    }
+  }
+  unsigned mx = 0;
+#pragma unroll 4
+  for (long r = r_begin + rl; r < r_end; r += rpi) {
+    const f32x4 v = x[r * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = act_apply(v[e] * sc[e] + sh[e], act);
+      mx = max(mx, absbits(o[e]));
+    }
+    y[r * C4 + c4] = o;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
 // Per-channel reductions over M rows.  grid = (row blocks, 64-channel groups), block = 4 row lanes x 64 channel
 // lanes; partials combined through LDS, then one fp64 atomic per (block, channel).
 // grid.x = G groups x `bpg` row blocks; `Mg` rows per group; sums [G][2][C], scale.. [G][C]
@@ -974,6 +1045,22 @@ static bool bn_rows_form(int C, long Mg, int groups, int max_blocks, int* bpg, i
   return true;
 }
 
+int rac_bn_apply_act(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                     float* running_var, float momentum, float eps, int32_t n_updates, const float* x, int32_t act, float* y,
+                     float* scale, float* shift, float* mean, float* invstd, int64_t M, int32_t C, int32_t groups,
+                     uint32_t* y_amax, void* stream) {
+  RAC_REQUIRE(stats && gamma && beta && x && y && scale && shift && mean && invstd && C > 0 && count > 0 && groups >= 1 &&
+                  M > 0 && M % groups == 0 && (running_mean == nullptr) == (running_var == nullptr),
+              "rac_bn_apply_act: bad args");
+  int bpg, rpb;
+  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, y_amax ? 512 : 2048, &bpg, &rpb) && aligned16(x) && aligned16(y),
+              "rac_bn_apply_act: C must be 4 * 2^k <= 1024 and the maps 16-byte aligned (use rac_bn_finalize + rac_affine_act)");
+  hipLaunchKernelGGL(bn_apply_act_rows_kernel, dim3(bpg * groups), dim3(256), 0, ST(stream), stats, (long)count, gamma, beta,
+                     running_mean, running_var, momentum, eps, n_updates, (const f32x4*)x, (f32x4*)y, scale, shift, mean,
+                     invstd, (long)(M / groups), C / 4, groups, act, rpb, bpg, y_amax);
+  return check_launch("rac_bn_apply_act");
+}
+
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
                       const float* invstd, double* sums, int64_t M, int32_t C, int32_t groups, void* stream) {
   RAC_REQUIRE(dy && x && scale && shift && mean && invstd && sums && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
@@ -1378,6 +1465,156 @@ __global__ void groupnorm_fwd_kernel(const float* x, const float* gamma, const f
   }
 }
 
+// NormConvLSTMCell without a tape (lstm.py:174-198) in ONE launch: GroupNorm(16, 4g) of the two gate convs' outputs, the
+// gate activations, c_raw = f c_prev + i g~, GroupNorm(16, g) of c_raw and h = o tanh(c) -- five launches and four more
+// trips of the 4g-wide gate tensors through memory otherwise (23 + 7 + 1.5 ms of a 322 ms planner iteration on the
+// deployed model).  The work decomposes exactly: quarter q of the channels, [q g/4, (q + 1) g/4), needs gate groups q,
+// 4 + q, 8 + q, 12 + q of both convs (gate k of channel c is channel k g + c: group 4 k + q) and cell groups 4 q .. 4 q + 3,
+// all of them whole.  grid (4, B), 256 threads: one (image, quarter) per workgroup, its 8 + 1 slabs of HW x g/4 values read
+// three times (mean; centred squares, as groupnorm_fwd_kernel; gates) -- the first time from memory, then from the caches.
+// An image's arithmetic touches nothing of another image: batch-invariant by construction.
+__global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_ih, const float* g_hh, const float* c_prev,
+                                                                 const float* gam_ih, const float* bet_ih,
+                                                                 const float* gam_hh, const float* bet_hh,
+                                                                 const float* gam_c, const float* bet_c, float* h_out,
+                                                                 float* c_out, int HW, int g, float eps) {
+  __shared__ float red[4][12];
+  const int q = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Cq = g >> 2, Q4 = Cq >> 2;          // channels of the quarter, 16-byte vectors per pixel of it
+  const int nq = HW * Q4;                       // vectors per slab
+  const int cg = g >> 4;                        // channels per cell group
+  const long row4 = 4L * g;                     // gate tensors: floats per pixel
+  const float* ih = g_ih + (long)b * HW * row4 + q * Cq;
+  const float* hh = g_hh + (long)b * HW * row4 + q * Cq;
+  const float inv_n = 1.0f / (float)(HW * Cq);
+  auto block8 = [&](float (&v)[8]) {            // sums of 8 values over the workgroup, in every thread
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[wv][k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  };
+  float mean[8], rstd[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mean[k] = 0.f;
+  for (int i = tid; i < nq; i += 256) {
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o = (long)p * row4 + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ih + o + (long)k * g);
+      const f32x4 h = *reinterpret_cast<const f32x4*>(hh + o + (long)k * g);
+      mean[k] += (a.x + a.y) + (a.z + a.w);
+      mean[4 + k] += (h.x + h.y) + (h.z + h.w);
+    }
+  }
+  block8(mean);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) mean[k] *= inv_n, rstd[k] = 0.f;
+  for (int i = tid; i < nq; i += 256) {
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o = (long)p * row4 + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ih + o + (long)k * g);
+      const f32x4 h = *reinterpret_cast<const f32x4*>(hh + o + (long)k * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float da = a[e] - mean[k], dh = h[e] - mean[4 + k];
+        rstd[k] += da * da;
+        rstd[4 + k] += dh * dh;
+      }
+    }
+  }
+  block8(rstd);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) rstd[k] = 1.0f / sqrtf(rstd[k] * inv_n + eps);
+  // gates and the raw cell; the quarter's four cell groups: a thread's vectors all lie in ONE group when Q4 divides 256
+  // or 256 divides Q4's multiples -- the launcher's condition (Q4 a power of two <= 256), so one accumulator serves
+  const float* cp = c_prev + (long)b * HW * g + q * Cq;
+  float* co = c_out + (long)b * HW * g + q * Cq;
+  float* ho = h_out + (long)b * HW * g + q * Cq;
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < nq; i += 256) {
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o = (long)p * row4 + 4 * c4;
+    f32x4 pre[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(ih + o + (long)k * g);
+      const f32x4 h = *reinterpret_cast<const f32x4*>(hh + o + (long)k * g);
+      const int ch = k * g + q * Cq + 4 * c4;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam_ih + ch), ba = *reinterpret_cast<const f32x4*>(bet_ih + ch);
+      const f32x4 gh = *reinterpret_cast<const f32x4*>(gam_hh + ch), bh = *reinterpret_cast<const f32x4*>(bet_hh + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        pre[k][e] = ((a[e] - mean[k]) * rstd[k] * ga[e] + ba[e]) + ((h[e] - mean[4 + k]) * rstd[4 + k] * gh[e] + bh[e]);
+    }
+    const f32x4 cv = *reinterpret_cast<const f32x4*>(cp + (long)p * g + 4 * c4);
+    f32x4 cr;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      cr[e] = sigmoid_acc(pre[1][e]) * cv[e] + sigmoid_acc(pre[0][e]) * tanhf(pre[3][e]);
+    *reinterpret_cast<f32x4*>(co + (long)p * g + 4 * c4) = cr;  // (raw; normalised below by the thread that wrote it)
+    const int grp = (4 * c4) / cg;
+    const float s4 = (cr.x + cr.y) + (cr.z + cr.w);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) csum[j] += grp == j ? s4 : 0.f;
+  }
+  float m8[8] = {csum[0], csum[1], csum[2], csum[3], 0.f, 0.f, 0.f, 0.f};
+  block8(m8);
+  const float inv_c = 1.0f / (float)(HW * cg);
+  float cmean[4], cr2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) cmean[j] = m8[j] * inv_c;
+  for (int i = tid; i < nq; i += 256) {
+    const int p = i / Q4, c4 = i - p * Q4;
+    const f32x4 cr = *reinterpret_cast<const f32x4*>(co + (long)p * g + 4 * c4);
+    const int grp = (4 * c4) / cg;
+    float mg = cmean[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) mg = grp == j ? cmean[j] : mg;
+    float d2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d2 += (cr[e] - mg) * (cr[e] - mg);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cr2[j] += grp == j ? d2 : 0.f;
+  }
+  block8(cr2);
+  float crstd[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) crstd[j] = 1.0f / sqrtf(cr2[j] * inv_c + eps);
+  for (int i = tid; i < nq; i += 256) {
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o = (long)p * row4 + 4 * c4;
+    const f32x4 cr = *reinterpret_cast<const f32x4*>(co + (long)p * g + 4 * c4);
+    const int grp = (4 * c4) / cg;
+    float mg = cmean[0], rg = crstd[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) mg = grp == j ? cmean[j] : mg, rg = grp == j ? crstd[j] : rg;
+    const int ch = q * Cq + 4 * c4;
+    const f32x4 gc = *reinterpret_cast<const f32x4*>(gam_c + ch), bc = *reinterpret_cast<const f32x4*>(bet_c + ch);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(ih + o + 2L * g);
+    const f32x4 h = *reinterpret_cast<const f32x4*>(hh + o + 2L * g);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gam_ih + 2 * g + ch), ba = *reinterpret_cast<const f32x4*>(bet_ih + 2 * g + ch);
+    const f32x4 gh = *reinterpret_cast<const f32x4*>(gam_hh + 2 * g + ch), bh = *reinterpret_cast<const f32x4*>(bet_hh + 2 * g + ch);
+    f32x4 cn, hn;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      cn[e] = (cr[e] - mg) * rg * gc[e] + bc[e];
+      const float po = ((a[e] - mean[2]) * rstd[2] * ga[e] + ba[e]) + ((h[e] - mean[6]) * rstd[6] * gh[e] + bh[e]);
+      hn[e] = sigmoid_acc(po) * tanhf(cn[e]);
+    }
+    *reinterpret_cast<f32x4*>(co + (long)p * g + 4 * c4) = cn;
+    *reinterpret_cast<f32x4*>(ho + (long)p * g + 4 * c4) = hn;
+  }
+}
+
 __global__ void groupnorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean_i,
                                      const float* rstd_i, float* dx, float* dgamma, float* dbeta, int HW, int C,
                                      int G) {
@@ -1478,6 +1715,24 @@ int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, flo
   hipLaunchKernelGGL(groupnorm_fwd_kernel, dim3(G, B), dim3(256), 0, ST(stream), x, gamma, beta, y, mean, rstd, HW, C,
                      G, eps);
   return check_launch("rac_groupnorm_fwd");
+}
+
+int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_prev, const float* gamma_ih,
+                           const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
+                           const float* beta_c, float* h, float* c, int32_t B, int32_t HW, int32_t g, float eps,
+                           void* stream) {
+  RAC_REQUIRE(g_ih && g_hh && c_prev && gamma_ih && beta_ih && gamma_hh && beta_hh && gamma_c && beta_c && h && c && B > 0 &&
+                  HW > 0 && g > 0,
+              "rac_norm_lstm_cell_fwd: bad args");
+  const int Q4 = g / 16;
+  RAC_REQUIRE(g % 16 == 0 && Q4 >= 1 && Q4 <= 256 && (Q4 & (Q4 - 1)) == 0 && B <= 65535,
+              "rac_norm_lstm_cell_fwd: g must be 16 * 2^k <= 4096 (GroupNorm(16, .) groups of whole 16-byte vectors)");
+  RAC_REQUIRE(aligned16(g_ih) && aligned16(g_hh) && aligned16(c_prev) && aligned16(h) && aligned16(c) && aligned16(gamma_ih) &&
+                  aligned16(beta_ih) && aligned16(gamma_hh) && aligned16(beta_hh) && aligned16(gamma_c) && aligned16(beta_c),
+              "rac_norm_lstm_cell_fwd: 16-byte aligned operands");
+  hipLaunchKernelGGL(norm_lstm_cell_fwd_kernel, dim3(4, B), dim3(256), 0, ST(stream), g_ih, g_hh, c_prev, gamma_ih, beta_ih,
+                     gamma_hh, beta_hh, gamma_c, beta_c, h, c, HW, g, eps);
+  return check_launch("rac_norm_lstm_cell_fwd");
 }
 
 int rac_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

@@ -515,6 +515,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   }
   const int TM = FULL ? 128 : p.tile_m;
   const int nmb = FULL ? 8 : TM >> 4;  // live 16-row blocks of the tile's 8
+  // A short tile's live blocks are dealt out EVENLY over the wave rows (round 6): RBL blocks per wave row, wave row wm
+  // holding blocks wm RBL ... -- a 6x8 map's tile (two images, 6 live blocks) gave wave row 0 four blocks and wave row 1
+  // two, so the tile took the time of a full one for 96 rows; now 3 + 3: a quarter of the MFMA time of every conv on the
+  // reference's default 48x64 frame's latent maps.  A full tile: RBL = RB (compile time, nothing changes).
+  const int RBL = FULL ? RB : (nmb + WM - 1) / WM;
+  const int mbw = FULL ? wm * RB : wm * RBL;  // the wave's first block
   const int m0 = bx * TM, n0 = by * SBN;
   const int kc_begin = bz * p.cps;
   const int kc_end = min(kc_begin + p.cps, p.nchunks);
@@ -577,11 +583,11 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   unsigned amask[RB];  // per 16-row block: one bit per tap for the shifted pixel's validity
 #pragma unroll
   for (int t = 0; t < RB; ++t) {
-    const int r = (wm * RB + t) * 16 + lr;
+    const int r = (mbw + t) * 16 + lr;
     const int im = r / p.HW;
     const int q = r - im * p.HW;
     // (YM: block t is image row wm * RB + t, the lane's pixel is x = lr & 7 of it)
-    const int y = YM ? wm * RB + t : q / p.W, x = YM ? (lr & 7) : q - (q / p.W) * p.W;
+    const int y = YM ? mbw + t : q / p.W, x = YM ? (lr & 7) : q - (q / p.W) * p.W;
     unsigned mk = 0;
     for (int tp = 0; tp < p.taps; ++tp) {
       const int yy = y + tp / p.ks - p.pad, xx = x + tp % p.ks - p.pad;
@@ -590,8 +596,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
     amask[t] = mk;
   }
   // fragment base of the lane: block t adds t * 256 -- (YM) image row wm * RB + t: t * 16 T16Y_PITCH
-  const int abase = YM ? lq * CP + (wm * RB * T16Y_PITCH + (lr >> 3 ? T16Y_S1 : T16Y_S0) + (lr & 7)) * 16
-                       : lq * CP + (wm * RB * 16 + lr) * 16;
+  const int abase = YM ? lq * CP + (mbw * T16Y_PITCH + (lr >> 3 ? T16Y_S1 : T16Y_S0) + (lr & 7)) * 16
+                       : lq * CP + (mbw * 16 + lr) * 16;
   const int zrow = lq * CP + 128 * 16;
   const rsrc_t w_rsrc = make_rsrc(p.w, (unsigned)(2 * p.w_ps * 2));
   const unsigned w_pstride = (unsigned)(p.w_ps * 2);
@@ -702,12 +708,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
           const int mb = 4 * h + t;
-          if (!FULL && wm * RB + mb >= nmb) continue;  // wave-uniform
+          if (!FULL && (mb >= RBL || mbw + mb >= nmb)) continue;  // wave-uniform
 #if !RAC_TILE_READ_ALL  // (reading dead blocks too -- straight-line LDS traffic, exact waits -- measured +0 % on 5x5, +1 % on 3x3)
           // the tap leaves the image: no work.  (Dropping the test for the taps of the kernel's centre row, which never leave
           // -- a compile-time fact in the unrolled instances -- merges such a step's four row blocks into one basic block of 48
           // MFMAs, and the compiler's schedule of that block is SLOWER: 12.55 -> 13.2 ms on the 5x5 gate GEMM at M = 64 000.)
-          if (YM && (unsigned)(wm * RB + mb + ky - p.pad) >= (unsigned)p.H) continue;
+          if (YM && (unsigned)(mbw + mb + ky - p.pad) >= (unsigned)p.H) continue;
 #endif
           const int ao = YM ? shift + mb * (16 * T16Y_PITCH) : ((amask[mb] & bit) ? shift + mb * 256 : zr);
 #pragma unroll
@@ -718,8 +724,8 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            if (!FULL && wm * RB + 4 * h + t >= nmb) continue;
-            if (YM && (unsigned)(wm * RB + 4 * h + t + ky - p.pad) >= (unsigned)p.H) continue;
+            if (!FULL && (4 * h + t >= RBL || mbw + 4 * h + t >= nmb)) continue;
+            if (YM && (unsigned)(mbw + 4 * h + t + ky - p.pad) >= (unsigned)p.H) continue;
             acc[4 * h + t][nb] = mma3(fa[t], fb[nb], acc[4 * h + t][nb]);
           }
       }
@@ -830,12 +836,12 @@ __global__ __launch_bounds__(256, 2) void conv16_tile_kernel(Conv16P p) {
   if (p.per_image) __syncthreads();  // ia_sh (a workgroup with an empty K range has not passed a barrier yet)
   if constexpr (WM == 2) {
     if (p.lstm_h) {
-      conv16_lstm_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, pow2f(-ka), pow2f(-kw),
+      conv16_lstm_epilogue(p, acc, m0, mbw, min(nmb, mbw + RBL), n0 + wn * NT * 32, pow2f(-ka), pow2f(-kw),
                            p.per_image ? ia_sh : nullptr, YM ? p.HW : 0);
       return;
     }
   }
-  conv16_epilogue(p, acc, m0, wm * RB, nmb, n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), nullptr,
+  conv16_epilogue(p, acc, m0, mbw, min(nmb, mbw + RBL), n0 + wn * NT * 32, bz, pow2f(-ka), pow2f(-kw), nullptr,
                   p.per_image ? ia_sh : nullptr, p.out_amax, YM ? p.HW : 0);
 }
 

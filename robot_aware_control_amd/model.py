@@ -194,6 +194,13 @@ class _NormLstmCell(nn.Module):
         h_prev, c_prev = state
         ci, ch = self.ih_gates[0], self.hh_gates[0]
         frozen = not torch.is_grad_enabled()
+        if frozen and x.is_cuda and ops.norm_cell_frozen_ok(x.shape[3]):
+            # no tape: everything behind the two gate convs is one launch (rac_norm_lstm_cell_fwd)
+            n_ih, n_hh, n_c = self.ih_gates[1], self.hh_gates[1], self.c_norm
+            h, c = ops.norm_cell_frozen(ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, True),
+                                        ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, True), c_prev,
+                                        (n_ih.weight, n_ih.bias), (n_hh.weight, n_hh.bias), (n_c.weight, n_c.bias))
+            return ops.tag_amax(h, ops.amax_one(h.device, h.shape[0])), c  # |h| = |o * tanh(c)| < 1
         g_ih = self.ih_gates[1](ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, frozen))
         g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, frozen))
         c_raw, act = ops.NormCellCore.apply(g_ih, g_hh, c_prev)

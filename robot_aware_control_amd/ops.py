@@ -1161,11 +1161,12 @@ VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
 def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
     in stream order): the trainer starts that slice's data-parallel all-reduce there.
-    `flush_after` = n (the per-step autograd path of a T-frame window: n = T - 1): as soon as a weight has n recorded
-    steps they are launched on the side stream -- the backward pass walks the window from its last step to its first, so
-    all but the first step's share of every time-batched weight gradient runs under the first step's backward pass instead of
-    behind the whole pass (where 4.8 ms of them stood exposed at cfg2 with every frame fed back: profiles/r06a_*); the first
-    step's records follow when the context exits.  The hand-scheduled core launches its chains' gradients itself.
+    `flush_after` = n (the per-step autograd path of a T-step window: n = T): as soon as a weight has n recorded steps --
+    its last operand exists -- its time-batched launch starts on the side stream, under the rest of the backward pass (which
+    walks the window from its last step to its first: the frame predictor's weights are complete three chains and an encoder
+    pass before the end) instead of behind the whole pass, where 4.8 ms of them stood exposed at cfg2 with every frame fed
+    back (profiles/r06a_*).  Whatever has fewer records follows when the context exits, on the same stream.  The
+    hand-scheduled core launches its chains' gradients itself.
     `vgg_steps`: the encoder and the decoder ran once per step too (a window that feeds predicted frames back): their
     layers' weight gradients are time-batched the same way -- one launch over n steps' pixels instead of n launches of a
     fifth of the rows each (0.06-0.12 of the pipe at 16 images per launch)."""
@@ -1575,6 +1576,27 @@ class ConvTHead(torch.autograd.Function):
         return dx, None, None, None
 
 
+BN_FUSED_APPLY = os.environ.get("RAC_BN_FUSED_APPLY", "1") == "1"  # BatchNorm finalize + affine + LeakyReLU in one launch
+
+
+def bn_apply_act(raw, stats, gamma, beta, rmean, rvar, n_updates, M, Cc, G):
+    """y = LeakyReLU(0.2)(BatchNorm_train(raw)) from the fp64 batch statistics (vgg_64.py:12-14): (y, aff) with aff =
+    [scale, shift, mean, invstd] per group for the backward pass; running statistics updated `n_updates` times per group."""
+    dev = raw.device
+    aff = torch.empty((4, G, Cc), device=dev, dtype=torch.float32)
+    y = torch.empty_like(raw)
+    slot = amax_slot(dev)
+    sp = stream_ptr()
+    if BN_FUSED_APPLY and Cc % 4 == 0 and (Cc // 4) & (Cc // 4 - 1) == 0 and Cc <= 1024:
+        call("rac_bn_apply_act", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
+             n_updates, ptr(raw), ACT_LEAKY, ptr(y), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), M, Cc, G, ptr(slot), sp)
+    else:
+        call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
+             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cc, G, sp)
+        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cc, G, ptr(slot), sp)
+    return tag_amax(y, slot), aff
+
+
 class VggLayer(torch.autograd.Function):
     """Conv3x3(no bias) -> BatchNorm2d -> LeakyReLU(0.2) over [x0 | x1]  (vgg_64.py:8-18).
 
@@ -1615,13 +1637,7 @@ class VggLayer(torch.autograd.Function):
             raw = conv_forward(x0, x1, weight, None, stats=stats, groups=G)
         M = raw.numel() // Cout
         assert M % G == 0 and (G == 1 or (M // G) % 128 == 0), (M, G)
-        aff = torch.empty((4, G, Cout), device=dev, dtype=torch.float32)  # scale, shift, mean, invstd per group
-        call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
-             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Cout, G, stream_ptr())
-        y = torch.empty_like(raw)
-        slot = amax_slot(dev)
-        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, Cout, G, ptr(slot), stream_ptr())
-        tag_amax(y, slot)
+        y, aff = bn_apply_act(raw, stats, gamma, beta, rmean, rvar, n_updates, M, Cout, G)
         ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
         ctx.amax = (amax_tag(x0), amax_tag(x1))
         return y
@@ -1700,13 +1716,7 @@ class FirstVggLayer(torch.autograd.Function):
         M = B * H * W
         stats = zeros64((G, 2, 64), dev)
         call("rac_col_stats", ptr(raw), ptr(stats), M, 64, G, sp)
-        aff = torch.empty((4, G, 64), device=dev, dtype=torch.float32)
-        call("rac_bn_finalize", ptr(stats), M // G, ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), BN_MOMENTUM, BN_EPS,
-             n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), 64, G, sp)
-        y = torch.empty_like(raw)
-        slot = amax_slot(dev)
-        call("rac_affine_act", ptr(raw), ptr(aff[0]), ptr(aff[1]), ACT_LEAKY, ptr(y), M, 64, G, ptr(slot), sp)
-        tag_amax(y, slot)
+        y, aff = bn_apply_act(raw, stats, gamma, beta, rmean, rvar, n_updates, M, 64, G)
         ctx.save_for_backward(img, zero_mask, mask, weight, gamma, beta, raw, aff)
         ctx.groups = G
         return y
@@ -2447,6 +2457,29 @@ class RecurrentCore(torch.autograd.Function):
         flat = lambda t_: t_.view((T * B, H, W, g))
         d_prior_all, d_post_all = tag_amax(flat(d_prior_all), slot_prior), tag_amax(flat(d_post_all), slot_post)
         return (None, flat(d_h_all), d_prior_all, d_post_all) + (None,) * (len(ctx.needs_input_grad) - 4)
+
+
+NORM_CELL_FUSED = os.environ.get("RAC_NORM_CELL_FUSED", "1") == "1"  # the frozen NormConvLSTMCell's pointwise part in one launch
+
+
+def norm_cell_frozen_ok(g: int) -> bool:
+    return NORM_CELL_FUSED and g % 16 == 0 and (g // 16) & (g // 16 - 1) == 0 and g <= 4096
+
+
+def norm_cell_frozen(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c):
+    """(h, c) of a NormConvLSTMCell behind its two gate convs, without a tape (lstm.py:174-198): both GroupNorm(16, 4g),
+    the gate activations, the cell update, GroupNorm(16, g) of the cell and h = o tanh(c) in ONE launch
+    (rac_norm_lstm_cell_fwd) instead of GroupNorm x 3 + cell + output kernels.  `gn_*` = (weight, bias) of the norms."""
+    B, H, W, g4 = g_ih.shape
+    g = g4 // 4
+    g_ih = g_ih if g_ih.is_contiguous() else g_ih.contiguous()
+    g_hh = g_hh if g_hh.is_contiguous() else g_hh.contiguous()
+    c_prev = c_prev if c_prev.is_contiguous() else c_prev.contiguous()
+    h = torch.empty((B, H, W, g), device=g_ih.device, dtype=torch.float32)
+    c = torch.empty_like(h)
+    call("rac_norm_lstm_cell_fwd", ptr(g_ih), ptr(g_hh), ptr(c_prev), ptr(gn_ih[0]), ptr(gn_ih[1]), ptr(gn_hh[0]),
+         ptr(gn_hh[1]), ptr(gn_c[0]), ptr(gn_c[1]), ptr(h), ptr(c), B, H * W, g, 1e-5, stream_ptr())
+    return h, c
 
 
 class GroupNorm(torch.autograd.Function):

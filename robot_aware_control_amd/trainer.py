@@ -392,14 +392,14 @@ class PredictionTrainer(object):
                 reducer = ShardReducer(self.model.flat_parameters()[1], *self.optimizer.plan())
             else:
                 reducer = GradReducer(self.model.flat_parameters()[1], getattr(cf, "ddp_bucket_mb", 64))
-        # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce.  A window
-        # that went step by step (scheduled sampling, GroupNorm cells) launches all but its first step's share as soon as
-        # the backward pass has left the second step; the hand-scheduled core launches its chains' itself
+        # ConvLSTM weight gradients: one time-batched launch per weight, each followed by its slice's all-reduce.  In a window
+        # that went step by step (scheduled sampling, GroupNorm cells) a weight's launch starts -- on the side stream -- the
+        # moment its last step's operands exist (the backward pass reaches the window's first step last), under the rest of
+        # that step's backward pass; the hand-scheduled core launches its chains' gradients itself
         stepped = not (sequence_taken and self.model.used_recurrent_core)
         try:
             with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None,
-                                    flush_after=(n_steps - 1) if stepped and n_steps > 1 else None,
-                                    vgg_steps=not sequence_taken):
+                                    flush_after=n_steps if stepped else None, vgg_steps=not sequence_taken):
                 torch.autograd.backward(roots, seeds)
                 self._mark("backward")
         finally:

@@ -929,7 +929,11 @@ def test_overlapped_optimizer_update_end_to_end(dev, tmp_path, monkeypatch, lazy
     assert set(ref) == set(got)
     for k, b in ref.items():
         a = got[k]
-        assert torch.equal(a, b), (k, float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30)))
+        err = float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+        if k == "ev":  # (the evaluation's PSNR / SSIM sums use fp32 atomics: the same numbers, not the same bits)
+            assert err < 1e-6, (k, err)
+        else:
+            assert torch.equal(a, b), (k, err)
 
 
 def test_train_step_is_bit_reproducible(dev):

@@ -1082,3 +1082,62 @@ def test_frozen_cell_in_the_gate_conv_epilogue(dev, B, H, W, g, k, monkeypatch):
     i, f, o, gg = gz.chunk(4, 1)
     cz_ref = torch.sigmoid(i) * torch.tanh(gg)
     assert relerr(from_map(cz), cz_ref) < 6e-6 and relerr(from_map(hz), torch.sigmoid(o) * torch.tanh(cz_ref)) < 6e-6
+
+
+@pytest.mark.parametrize("M,Cc,G", [(1024, 512, 1), (5 * 1024, 512, 5), (2 * 4096, 64, 2), (3 * 768, 256, 3)])
+def test_bn_apply_act_is_finalize_plus_affine(dev, monkeypatch, M, Cc, G):
+    """rac_bn_apply_act (BatchNorm finalize + affine + LeakyReLU in one launch) against rac_bn_finalize + rac_affine_act:
+    the same bits in the activated map, in scale / shift / mean / invstd, in the running statistics (two momentum updates
+    per group, groups in order) and in the map's maximum."""
+    from robot_aware_control_amd import ops
+    raw = (rnd(3, M, Cc) * 1.7 + 0.3).to(dev).view(G, M // G, 1, Cc)
+    gamma, beta = (1 + rnd(4, Cc, scale=0.1)).to(dev), rnd(5, Cc, scale=0.1).to(dev)
+    stats = torch.zeros(G, 2, Cc, device=dev, dtype=torch.float64)
+    ops.call("rac_col_stats", ops.ptr(raw), ops.ptr(stats), M, Cc, G, ops.stream_ptr())
+    out = {}
+    for fused in (False, True):
+        monkeypatch.setattr(ops, "BN_FUSED_APPLY", fused)
+        rm, rv = rnd(6, Cc, scale=0.1).to(dev), (1 + rnd(7, Cc, scale=0.1).abs()).to(dev)
+        y, aff = ops.bn_apply_act(raw, stats, gamma, beta, rm, rv, 2, M, Cc, G)
+        torch.cuda.synchronize()
+        out[fused] = (y.clone(), aff.clone(), rm.clone(), rv.clone(), ops.amax_tag(y).clone())
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    y, aff = out[True][0], out[True][1]
+    x = raw.double().view(G, M // G, Cc)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    ref = (x - mean[:, None]) / torch.sqrt(var[:, None] + 1e-5) * gamma.double() + beta.double()
+    ref = torch.where(ref > 0, ref, 0.2 * ref)
+    assert float((y.double().view(G, M // G, Cc) - ref).abs().max()) < 1e-4
+    assert int(out[True][4].item()) == int(y.abs().max().view(torch.int32).item())
+
+
+@pytest.mark.parametrize("B,H,W,g", [(5, 6, 8, 256), (3, 8, 8, 64), (2, 8, 8, 512)])
+def test_norm_lstm_cell_fused_forward(dev, monkeypatch, B, H, W, g):
+    """rac_norm_lstm_cell_fwd (the frozen NormConvLSTMCell behind its gate convs in one launch) against torch's GroupNorm /
+    sigmoid / tanh in fp64 (lstm.py:174-198) and against this package's unfused kernels; an image's result is the same bits
+    alone and in a batch."""
+    from robot_aware_control_amd import ops
+    g_ih = (rnd(1, B, H, W, 4 * g) * 1.3 + 0.2).to(dev)
+    g_hh = (rnd(2, B, H, W, 4 * g) * 0.7 - 0.1).to(dev)
+    c_prev = rnd(3, B, H, W, g).to(dev)
+    gn = [((1 + rnd(10 + i, n, scale=0.1)).to(dev), rnd(20 + i, n, scale=0.1).to(dev)) for i, n in enumerate((4 * g, 4 * g, g))]
+    h, c = ops.norm_cell_frozen(g_ih, g_hh, c_prev, *gn)
+    planes = lambda t: t.permute(0, 3, 1, 2).double().cpu()
+    gates = (F.group_norm(planes(g_ih), 16, gn[0][0].double().cpu(), gn[0][1].double().cpu(), 1e-5)
+             + F.group_norm(planes(g_hh), 16, gn[1][0].double().cpu(), gn[1][1].double().cpu(), 1e-5))
+    i_, f_, o_, gg = gates.chunk(4, 1)
+    c_ref = F.group_norm(torch.sigmoid(f_) * planes(c_prev) + torch.sigmoid(i_) * torch.tanh(gg), 16,
+                         gn[2][0].double().cpu(), gn[2][1].double().cpu(), 1e-5)
+    h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+    assert relerr(planes(c), c_ref) < 2e-6 and relerr(planes(h), h_ref) < 2e-6
+    # the unfused kernels (GroupNorm x 3, cell core, output)
+    with torch.no_grad():
+        n_ih = ops.GroupNorm.apply(g_ih, gn[0][0], gn[0][1], 16)
+        n_hh = ops.GroupNorm.apply(g_hh, gn[1][0], gn[1][1], 16)
+        c_raw, act = ops.NormCellCore.apply(n_ih, n_hh, c_prev)
+        c2 = ops.GroupNorm.apply(c_raw, gn[2][0], gn[2][1], 16)
+        h2 = ops.LstmOut.apply(act, c2)
+    assert relerr(c, c2) < 2e-6 and relerr(h, h2) < 2e-6
+    h1, c1 = ops.norm_cell_frozen(g_ih[1:2].contiguous(), g_hh[1:2].contiguous(), c_prev[1:2].contiguous(), *gn)
+    assert torch.equal(h1[0], h[1]) and torch.equal(c1[0], c[1])
