@@ -1152,7 +1152,8 @@ def wgrad_on_side_stream(launch, operands, need_amax=True) -> None:
     _SIDE["done"] = done
 
 
-_FLUSH_AFTER = None  # deferred_wgrad(flush_after=n): a weight's records are launched (side stream) once n of them exist
+_FLUSH_AFTER = None  # deferred_wgrad(flush_after=n | (n1, n2, ..)): a weight's records are launched (side stream) whenever
+_FLUSH_SEEN = {}     # the number of steps recorded for it so far (counted here) reaches one of these
 _VGG_STEPS = False   # ... and the vgg layers' weight gradients are recorded per step too (the encoder / decoder ran per step)
 VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
 
@@ -1161,12 +1162,13 @@ VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
 def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
     in stream order): the trainer starts that slice's data-parallel all-reduce there.
-    `flush_after` = n (the per-step autograd path of a T-step window: n = T): as soon as a weight has n recorded steps --
-    its last operand exists -- its time-batched launch starts on the side stream, under the rest of the backward pass (which
-    walks the window from its last step to its first: the frame predictor's weights are complete three chains and an encoder
-    pass before the end) instead of behind the whole pass, where 4.8 ms of them stood exposed at cfg2 with every frame fed
-    back (profiles/r06a_*).  Whatever has fewer records follows when the context exits, on the same stream.  The
-    hand-scheduled core launches its chains' gradients itself.
+    `flush_after` = n or (n1, n2, ..) (the per-step autograd path of a T-step window: (T - 1, T)): whenever a weight has that
+    many recorded steps, what is recorded is launched -- time-batched -- on the side stream, under the rest of the backward
+    pass (which walks the window from its last step to its first).  With (T - 1, T) four fifths of every weight's gradient
+    run under the first step's backward pass and its last fifth starts the moment its operands exist, instead of all of it
+    behind the whole pass, where 4.8 ms stood exposed at cfg2 with every frame fed back (profiles/r06a_*; T alone leaves
+    3.5 ms: every weight completes inside the last fifth of the pass).  Whatever is left follows when the context exits, on
+    the same stream.  The hand-scheduled core launches its chains' gradients itself.
     `vgg_steps`: the encoder and the decoder ran once per step too (a window that feeds predicted frames back): their
     layers' weight gradients are time-batched the same way -- one launch over n steps' pixels instead of n launches of a
     fifth of the rows each (0.06-0.12 of the pipe at 16 images per launch)."""
@@ -1175,7 +1177,12 @@ def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
         yield
         return
     _DEFERRED = {}
-    _FLUSH_AFTER = int(flush_after) if (flush_after and flush_after > 0 and WGRAD_STREAM and WGRAD_CHAIN_FLUSH) else None
+    if flush_after and WGRAD_STREAM and WGRAD_CHAIN_FLUSH:
+        pts = (flush_after,) if isinstance(flush_after, int) else tuple(flush_after)
+        _FLUSH_AFTER = frozenset(int(v) for v in pts if v and v > 0) or None
+    else:
+        _FLUSH_AFTER = None
+    _FLUSH_SEEN.clear()
     _VGG_STEPS = bool(vgg_steps) and _FLUSH_AFTER is not None and VGG_WGRAD_BATCH
     _SIDE["on_ready"] = on_ready
     try:
@@ -1210,7 +1217,8 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
     if defer and _DEFERRED is not None:
         rec = _DEFERRED.setdefault(id(weight), (weight, []))[1]
         rec.append((dy, x0, x1))
-        if _FLUSH_AFTER is not None and len(rec) == _FLUSH_AFTER:
+        seen = _FLUSH_SEEN[id(weight)] = _FLUSH_SEEN.get(id(weight), 0) + 1
+        if _FLUSH_AFTER is not None and seen in _FLUSH_AFTER:
             for t_ in (dy, x0, x1):  # operand maxima on THIS stream (a reduction launched on the side stream would leave a
                 if t_ is not None:   # tag this stream's consumers could read unordered)
                     amax_for(t_)
