@@ -241,10 +241,13 @@ __global__ void bn_bwd_apply_kernel(const float* dy, const float* x, const float
 // (which ran at 2.4-2.8 TB/s: instruction bound) -- and streams 16-byte vectors of rows r0 + tid / C4, + 256 / C4, ...
 __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const f32x4* dy, const f32x4* x, const f32x4* scale,
                                                                  const f32x4* shift, const f32x4* mean, const f32x4* invstd,
-                                                                 double* sums, long Mg, int C4, int rows_per_block, int bpg) {
+                                                                 double* sums, long Mg, int C4, int C4s, int rows_per_block,
+                                                                 int bpg) {
+  // blockIdx.y = channel slice of C4s quads (C4s = C4: one slice, round 4's form): a workgroup ends in 8 fp64 atomics per
+  // quad of ITS SLICE only, so a launch of W workgroups costs W / slices x 2 C atomics instead of W x 2 C (reduce_plan)
   __shared__ f32x4 s1[256], s2[256];
   const int tid = threadIdx.x;
-  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int cl = tid & (C4s - 1), c4 = blockIdx.y * C4s + cl, rl = tid / C4s, rpi = 256 / C4s;
   const int g = blockIdx.x / bpg;
   const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
   const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
@@ -265,10 +268,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_rows_kernel(const f32x4* dy
   s1[tid] = a1;
   s2[tid] = a2;
   __syncthreads();
-  if (tid < C4) {
+  if (tid < C4s) {
     f32x4 t1 = s1[tid], t2 = s2[tid];
-    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4 + tid], t2 += s2[k * C4 + tid];
-    double* sg = sums + (long)g * 8 * C4 + 4 * tid;
+    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4s + tid], t2 += s2[k * C4s + tid];
+    double* sg = sums + (long)g * 8 * C4 + 4 * c4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       atomicAdd(sg + e, (double)t1[e]);
@@ -646,11 +649,12 @@ __global__ void slab_reduce2_kernel4(const f32x4* slabs, int n_slabs, long slab_
 // split-K combine of a train-mode vgg layer's conv + its BatchNorm batch statistics in one pass (row-walking form, C =
 // 4 * 2^k): out = sum of slabs; stats[g][0][c] += sum over the group's rows, stats[g][1][c] += sum of squares (fp64 atomics)
 __global__ __launch_bounds__(256) void slab_reduce_stats_rows_kernel(const f32x4* slabs, int n_slabs, long slab_stride4,
-                                                                     f32x4* out, double* stats, long Mg, int C4,
+                                                                     f32x4* out, double* stats, long Mg, int C4, int C4s,
                                                                      int rows_per_block, int bpg, unsigned* amax) {
+  // (blockIdx.y = channel slice of C4s quads, as bn_bwd_reduce_rows_kernel)
   __shared__ f32x4 s1[256], s2[256];
   const int tid = threadIdx.x;
-  const int c4 = tid & (C4 - 1), rl = tid / C4, rpi = 256 / C4;
+  const int cl = tid & (C4s - 1), c4 = blockIdx.y * C4s + cl, rl = tid / C4s, rpi = 256 / C4s;
   const int g = blockIdx.x / bpg;
   const long r_begin = (long)g * Mg + (long)(blockIdx.x - g * bpg) * rows_per_block;
   const long r_end = min(r_begin + rows_per_block, (long)(g + 1) * Mg);
@@ -670,10 +674,10 @@ __global__ __launch_bounds__(256) void slab_reduce_stats_rows_kernel(const f32x4
   s1[tid] = a1;
   s2[tid] = a2;
   __syncthreads();
-  if (tid < C4) {
+  if (tid < C4s) {
     f32x4 t1 = s1[tid], t2 = s2[tid];
-    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4 + tid], t2 += s2[k * C4 + tid];
-    double* sg = stats + (long)g * 8 * C4 + 4 * tid;
+    for (int k = 1; k < rpi; ++k) t1 += s1[k * C4s + tid], t2 += s2[k * C4s + tid];
+    double* sg = stats + (long)g * 8 * C4 + 4 * c4;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       atomicAdd(sg + e, (double)t1[e]);
@@ -1011,19 +1015,33 @@ static int rows_per_block_for(long M, int* nblocks) {
   return rpb;
 }
 
-// Workgroups (all groups together) of a per-channel reduction over `bytes` of operands that ends in 2 C fp64 atomics per
-// workgroup: t(nb) = bytes / (nb x ~30 GB/s per workgroup: 32 KB in flight over a ~1 us round trip)  +  nb x 2 C x ~0.25 ns
-// is least at nb = 0.35 sqrt(bytes / 2 C) per group (RAC_BN_REDUCE_COEF: the factor, for tools/bench_bn_reduce.py); never fewer than 8 per group, never more than 1024 in all (the large tensors:
-// enough workgroups to stream at the HBM rate, whose atomics then hide under the other workgroups' loads).
-static int reduce_blocks_for(long bytes, int C, int groups) {
-  static const bool old = getenv("RAC_BN_REDUCE_OLD") && getenv("RAC_BN_REDUCE_OLD")[0] == '1';  // A/B: round 5's counts
-  if (old) return bytes / 2 <= (24L << 20) ? 256 : 1024;
-  static const double coef = [] { const char* e = getenv("RAC_BN_REDUCE_COEF"); return e ? atof(e) : 0.35; }();
+// Grid of a per-channel reduction (rows form, C = 4 * 2^k <= 1024) that ends in fp64 atomics: channel slices of 64 channels
+// (blockIdx.y) x `bpg` row blocks per statistics group.  A workgroup's atomics cover its slice only, so W workgroups per
+// group cost W / slices x 2 C atomics (~0.25 ns each, measured: they, not the bytes, bounded these passes on everything but
+// the 64x64 layers) against bytes / (W x ~30 GB/s) of streaming: least at W = 0.365 sqrt(bytes x slices / 2 C).
+static bool reduce_plan(int C, long Mg, int groups, long bytes, int* bpg, int* rows_per_block, int* C4s) {
+  const int C4 = C / 4;
+  if (C % 4 || C4 < 1 || C4 > 256 || (C4 & (C4 - 1))) return false;
+  static const bool off = getenv("RAC_BN_ROWS") && getenv("RAC_BN_ROWS")[0] == '0';
+  if (off) return false;
+  static const bool old = getenv("RAC_BN_REDUCE_OLD") && getenv("RAC_BN_REDUCE_OLD")[0] == '1';  // A/B: one slice
+  static const double coef = [] { const char* e = getenv("RAC_BN_REDUCE_COEF"); return e ? atof(e) : 0.365; }();
+  const int slice = (old || C4 <= 16) ? C4 : 16;
+  const int n_slices = C4 / slice;
+  const int rpi = 256 / slice;
   const double per_group = (double)bytes / groups;
-  long nb = (long)(coef * sqrt(per_group / (2.0 * C)) + 0.5);
-  if (nb < 8) nb = 8;
-  nb *= groups;
-  return (int)(nb > 1024 ? 1024 : nb);
+  long W = old ? (bytes / 2 <= (24L << 20) ? 256 : 1024) / groups : (long)(coef * sqrt(per_group * n_slices / (2.0 * C)) + 0.5);
+  long nb = W / n_slices;
+  if (nb < 1) nb = 1;
+  if (nb * n_slices * groups > 2048) nb = 2048 / (n_slices * groups) > 0 ? 2048 / (n_slices * groups) : 1;
+  const long most = (Mg + 2L * rpi - 1) / (2L * rpi);  // at least two passes per workgroup
+  if (nb > most) nb = most;
+  long rpb = (Mg + nb - 1) / nb;
+  rpb = (rpb + rpi - 1) / rpi * rpi;
+  *rows_per_block = (int)rpb;
+  *bpg = (int)((Mg + rpb - 1) / rpb);
+  *C4s = slice;
+  return true;
 }
 
 // the row-walking BatchNorm backward kernels: C = 4 * 2^k <= 1024; `bpg` workgroups per statistics group (about
@@ -1071,16 +1089,15 @@ int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const
   // Every workgroup ends in 8 fp64 atomics per channel quad onto the same 2 C addresses of its group: what bounds the pass
   // on all but the largest tensors is the NUMBER of those atomics (workgroups x 2 C; measured ~0.25 ns each: the 8x8 x 512
   // layer of one time step, 4 MB of operands, took 25 us on 128 workgroups = 131 k atomics), not the bytes -- see
-  // reduce_blocks_for: the workgroup count that balances a workgroup's streaming time against the atomics behind it.
+  // reduce_plan: channel slices, and the workgroup count that balances streaming time against the atomics behind it.
   // (Copies of the accumulators, a workgroup adding into copy index mod R, were built and measured in round 4: the reduce
   // pass gains what the apply pass then loses summing the copies.)
-  static const int reduce_blocks_env = [] { const char* e = getenv("RAC_BN_REDUCE_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int reduce_blocks = reduce_blocks_env > 0 ? reduce_blocks_env : reduce_blocks_for(2L * M * C * 4, C, groups);
-  if (bn_rows_form(C, Mg, groups, reduce_blocks, &bpg_rows, &rpb_rows) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
+  int c4s;
+  if (reduce_plan(C, Mg, groups, 2L * M * C * 4, &bpg_rows, &rpb_rows, &c4s) && aligned16(dy) && aligned16(x) && aligned16(scale) &&
       aligned16(shift) && aligned16(mean) && aligned16(invstd)) {
-    hipLaunchKernelGGL(bn_bwd_reduce_rows_kernel, dim3(bpg_rows * groups), dim3(256), 0, ST(stream), (const f32x4*)dy,
-                       (const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)mean, (const f32x4*)invstd,
-                       sums, Mg, C / 4, rpb_rows, bpg_rows);
+    hipLaunchKernelGGL(bn_bwd_reduce_rows_kernel, dim3(bpg_rows * groups, C / 4 / c4s), dim3(256), 0, ST(stream),
+                       (const f32x4*)dy, (const f32x4*)x, (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)mean,
+                       (const f32x4*)invstd, sums, Mg, C / 4, c4s, rpb_rows, bpg_rows);
     return check_launch("rac_bn_bwd_reduce");
   }
   dim3 grid = reduce_grid(Mg, C, &rpb);
@@ -1279,14 +1296,14 @@ int rac_slab_reduce_stats(const float* slabs, int32_t n_slabs, int64_t slab_stri
                           int32_t C, int32_t groups, uint32_t* out_amax, void* stream) {
   RAC_REQUIRE(slabs && out && stats && n_slabs >= 1 && M > 0 && C > 0 && groups >= 1 && M % groups == 0,
               "rac_slab_reduce_stats: bad args");
-  int bpg, rpb;
-  // (the statistics' fp64 atomics bound this pass too: see reduce_blocks_for; the slabs read + the map written)
-  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, reduce_blocks_for((long)(n_slabs + 1) * M * C * 4, C, groups), &bpg, &rpb) &&
-                  slab_stride % 4 == 0 &&
+  int bpg, rpb, c4s;
+  // (the statistics' fp64 atomics bound this pass too: see reduce_plan; bytes = the slabs read + the map written)
+  RAC_REQUIRE(reduce_plan(C, M / groups, groups, (long)(n_slabs + 1) * M * C * 4, &bpg, &rpb, &c4s) && slab_stride % 4 == 0 &&
                   aligned16(slabs) && aligned16(out),
               "rac_slab_reduce_stats: C must be 4 * 2^k <= 1024, 16-byte aligned slabs (use rac_slab_reduce + rac_col_stats)");
-  hipLaunchKernelGGL(slab_reduce_stats_rows_kernel, dim3(bpg * groups), dim3(256), 0, ST(stream), (const f32x4*)slabs,
-                     n_slabs, (long)(slab_stride / 4), (f32x4*)out, stats, (long)(M / groups), C / 4, rpb, bpg, out_amax);
+  hipLaunchKernelGGL(slab_reduce_stats_rows_kernel, dim3(bpg * groups, C / 4 / c4s), dim3(256), 0, ST(stream),
+                     (const f32x4*)slabs, n_slabs, (long)(slab_stride / 4), (f32x4*)out, stats, (long)(M / groups), C / 4, c4s,
+                     rpb, bpg, out_amax);
   return check_launch("rac_slab_reduce_stats");
 }
 

@@ -1162,13 +1162,14 @@ VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
 def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     """`on_ready(weight)` is called after each weight's batched launch is enqueued (its gradient is then complete
     in stream order): the trainer starts that slice's data-parallel all-reduce there.
-    `flush_after` = n or (n1, n2, ..) (the per-step autograd path of a T-step window: (T - 1, T)): whenever a weight has that
-    many recorded steps, what is recorded is launched -- time-batched -- on the side stream, under the rest of the backward
-    pass (which walks the window from its last step to its first).  With (T - 1, T) four fifths of every weight's gradient
-    run under the first step's backward pass and its last fifth starts the moment its operands exist, instead of all of it
-    behind the whole pass, where 4.8 ms stood exposed at cfg2 with every frame fed back (profiles/r06a_*; T alone leaves
-    3.5 ms: every weight completes inside the last fifth of the pass).  Whatever is left follows when the context exits, on
-    the same stream.  The hand-scheduled core launches its chains' gradients itself.
+    `flush_after` = n or (n1, n2, ..) (the per-step autograd path of a T-step window: T): whenever a weight has that many
+    recorded steps, what is recorded is launched -- time-batched -- on the side stream, under the rest of the backward pass
+    (which walks the window from its last step to its first): with T a weight's launch starts the moment its last operand
+    exists, instead of behind the whole pass, where 4.8 ms stood exposed at cfg2 with every frame fed back
+    (profiles/r06a_*).  Measured at cfg2, every frame fed back, same-day boxes: at exit 1.586 x the teacher-forced step, T
+    1.469 x (3.5 ms still exposed: every weight completes inside the last fifth of the pass), (T - 1, T) 1.536 x -- the
+    earlier launches take from the latency-bound data-gradient chain more than they hide.  Whatever is left follows when
+    the context exits, on the same stream.  The hand-scheduled core launches its chains' gradients itself.
     `vgg_steps`: the encoder and the decoder ran once per step too (a window that feeds predicted frames back): their
     layers' weight gradients are time-batched the same way -- one launch over n steps' pixels instead of n launches of a
     fifth of the rows each (0.06-0.12 of the pipe at 16 images per launch)."""

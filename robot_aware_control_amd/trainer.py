@@ -399,7 +399,7 @@ class PredictionTrainer(object):
         stepped = not (sequence_taken and self.model.used_recurrent_core)
         try:
             with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None,
-                                    flush_after=(n_steps - 1, n_steps) if stepped else None,
+                                    flush_after=n_steps if stepped else None,
                                     vgg_steps=not sequence_taken):
                 torch.autograd.backward(roots, seeds)
                 self._mark("backward")
