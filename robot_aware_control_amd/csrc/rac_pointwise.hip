@@ -565,13 +565,19 @@ __global__ void colsum_steps_kernel(ColsumSteps p, float* out, float* parts, lon
   }
 }
 
-// out[c] += parts[0][c] + parts[1][c] + ... in that order (the second stage of the deterministic column sums)
-__global__ void colsum_parts_add_kernel(const float* parts, int nb, float* out, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] += sum over the row blocks of parts[b][c], in a FIXED association (the second stage of the deterministic column
+// sums): a workgroup takes 64 columns, its four row lanes each add every fourth block in order, then lane sums 0 + 1 + 2 + 3.
+__global__ __launch_bounds__(256) void colsum_parts_add_kernel(const float* parts, int nb, float* out, int C) {
+  __shared__ float s1[256];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
   float a = 0.f;
-  for (int b = 0; b < nb; ++b) a += parts[(long)b * C + c];
-  out[c] += a;
+  if (c < C)
+    for (int b = rl; b < nb; b += 4) a += parts[(long)b * C + c];
+  s1[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < C)
+    out[c] += (s1[threadIdx.x] + s1[threadIdx.x + 64]) + (s1[threadIdx.x + 128] + s1[threadIdx.x + 192]);
 }
 
 // grid = (row blocks, 64-channel groups): bias gradients of the 4g-wide gate tensors have few rows (B*64) and many
@@ -1244,7 +1250,7 @@ int rac_colsum_steps(const float* const* xs, int32_t T, float* out, float* parts
   dim3 grid = reduce_grid(M, C, &rpb);
   hipLaunchKernelGGL(colsum_steps_kernel, grid, dim3(256), 0, ST(stream), p, out, parts, (long)M, C, rpb);
   if (parts)
-    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
+    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
   return check_launch("rac_colsum_steps");
 }
 
@@ -1254,7 +1260,7 @@ int rac_colsum_acc(const float* x, float* out, float* parts, int64_t M, int32_t 
   dim3 grid = reduce_grid(M, C, &rpb);
   hipLaunchKernelGGL(colsum_acc_kernel, grid, dim3(256), 0, ST(stream), x, out, parts, (long)M, C, rpb);
   if (parts)
-    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 256)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
+    hipLaunchKernelGGL(colsum_parts_add_kernel, dim3(cdiv(C, 64)), dim3(256), 0, ST(stream), parts, (int)grid.x, out, C);
   return check_launch("rac_colsum_acc");
 }
 

@@ -1073,6 +1073,30 @@ WGRAD_ALLKY = os.environ.get("RAC_WGRAD_ALLKY", "1") == "1"
 WGRAD_STREAM = os.environ.get("RAC_WGRAD_STREAM", "1") == "1"
 WGRAD_CHAIN_FLUSH = os.environ.get("RAC_WGRAD_CHAIN_FLUSH", "1") == "1"  # per ConvLSTM chain (0: once, behind the core)
 _SIDE = {"stream": None, "done": None, "keep": [], "on_ready": None}
+WGRAD_LOW_PRIORITY = os.environ.get("RAC_WGRAD_LOW_PRIORITY", "0") == "1"  # (experiment: the side stream below default priority)
+WGRAD_CU_MASK = os.environ.get("RAC_WGRAD_CU_MASK", "")  # (experiment: hex CU mask of the side stream, e.g. 3/4 of every XCD)
+
+
+def _side_stream(dev):
+    """The stream the weight gradients run on, beside the data-gradient chain."""
+    st = _SIDE["stream"]
+    if st is None or st.device != torch.device(dev):
+        st = None
+        if WGRAD_CU_MASK:
+            try:
+                hip = C.CDLL("libamdhip64.so")
+                words = [int(WGRAD_CU_MASK[max(0, i - 8):i], 16) for i in range(len(WGRAD_CU_MASK), 0, -8)]
+                arr = (C.c_uint32 * len(words))(*words)
+                with torch.cuda.device(dev):
+                    h = C.c_void_p()
+                    if hip.hipExtStreamCreateWithCUMask(C.byref(h), C.c_uint32(len(words)), arr) == 0 and h.value:
+                        st = torch.cuda.ExternalStream(h.value, device=dev)
+            except (OSError, AttributeError):
+                st = None
+        if st is None:
+            st = low_priority_stream(dev) if WGRAD_LOW_PRIORITY else torch.cuda.Stream(device=dev)
+        _SIDE["stream"] = st
+    return st
 
 
 def _amax_reserve(device, n: int) -> None:
@@ -1102,9 +1126,7 @@ def flush_deferred_wgrads_early(weights=None) -> None:
     dev = items[0][0].device if items else next(iter(_DEFERRED_BIAS.values()))[0].device
     _amax_reserve(dev, 8192)
     main = torch.cuda.current_stream()
-    if _SIDE["stream"] is None or _SIDE["stream"].device != dev:
-        _SIDE["stream"] = torch.cuda.Stream(device=dev)
-    side = _SIDE["stream"]
+    side = _side_stream(dev)
     ready = torch.cuda.Event()
     ready.record(main)
     side.wait_event(ready)  # everything enqueued so far (the operands) precedes the side stream's launches
@@ -1138,9 +1160,7 @@ def wgrad_on_side_stream(launch, operands, need_amax=True) -> None:
     _amax_reserve(operands[0].device, 64)
     main = torch.cuda.current_stream()
     dev = operands[0].device
-    if _SIDE["stream"] is None or _SIDE["stream"].device != dev:
-        _SIDE["stream"] = torch.cuda.Stream(device=dev)
-    side = _SIDE["stream"]
+    side = _side_stream(dev)
     ready = torch.cuda.Event()
     ready.record(main)
     side.wait_event(ready)

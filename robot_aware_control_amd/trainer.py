@@ -398,8 +398,10 @@ class PredictionTrainer(object):
         # that step's backward pass; the hand-scheduled core launches its chains' gradients itself
         stepped = not (sequence_taken and self.model.used_recurrent_core)
         try:
+            fl = os.environ.get("RAC_SCHED_FLUSH")  # (experiments: "4,5" = flush points; default: the window's step count)
+            points = tuple(int(v) for v in fl.split(",")) if fl else n_steps
             with ops.deferred_wgrad(on_ready=reducer.ready if reducer is not None else None,
-                                    flush_after=n_steps if stepped else None,
+                                    flush_after=points if stepped else None,
                                     vgg_steps=not sequence_taken):
                 torch.autograd.backward(roots, seeds)
                 self._mark("backward")
