@@ -589,7 +589,10 @@ class SVGConvModel(nn.Module):
 
     def _encoder_extent(self) -> int:
         """Flat-buffer element index behind the encoder's last parameter (the encoder is registered first)."""
-        return max(p._rac_off + p.numel() for p in self.encoder.parameters())
+        ext = getattr(self, "_enc_extent", None)
+        if ext is None or ext[0] is not self._flat:  # (cached per flat buffer: walking the modules costs 50 us per call)
+            ext = self._enc_extent = (self._flat, max(p._rac_off + p.numel() for p in self.encoder.parameters()))
+        return ext[1]
 
     def late_update_groups(self):
         """Parameters behind the encoder's in the order a teacher-forced window first reads them (optim.FusedAdam updates

@@ -150,6 +150,9 @@ def thin_wgrad_acc(wide, thin, ct: int, weight):
     call("rac_slab_accumulate", ptr(parts), n_parts, n, ptr(weight_mem(grad_buffer(weight))), n, sp)
 
 
+MAX_SPLIT_K = int(os.environ.get("RAC_MAX_SPLIT_K", "8"))  # most K splits of a split-precision forward / data-gradient launch
+
+
 def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> int:
     """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
     choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
@@ -166,7 +169,7 @@ def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> in
         # x 3 = 480 workgroups 78 us against 88 (x 4 = 640: a quarter-full second round) and 97 (x 2); 320 tiles x 3 = 960
         # 89 us against 98 (x 1: half the slots idle) and 96 (x 4); the gate GEMMs keep 128 x 4 and 64 x 8 = 512.
         best, best_eff = 1, -1.0
-        for s in range(1, min(8, cap) + 1):
+        for s in range(1, min(MAX_SPLIT_K, cap) + 1):
             rounds = t128 * s / 512.0
             eff = (rounds / -(-rounds // 1) if rounds > 1 else rounds) * (1.0 - 0.03 * (s - 1))
             if eff > best_eff + 1e-9:
