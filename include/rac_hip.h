@@ -31,7 +31,7 @@ extern "C" {
 #define RAC_EINVAL (-1)   /* bad argument (shape / alignment / null pointer) */
 #define RAC_ELAUNCH (-2)  /* hipLaunch failed */
 
-#define RAC_ABI_VERSION 10
+#define RAC_ABI_VERSION 11
 
 int rac_version(void);
 const char* rac_device_arch(void); /* "gfx950" */
@@ -325,11 +325,14 @@ int rac_lstm_cell_bwd(const float* dh, const float* dc_next, const float* act, c
  *   gates = GroupNorm(16, 4g)(g_ih) + GroupNorm(16, 4g)(g_hh);  i, f, o = sigmoid, g~ = tanh  (chunk order i, f, o, g~)
  *   c = GroupNorm(16, g)(f * c_prev + i * g~);  h = o * tanh(c)                                (lstm.py:174-198)
  * g_ih / g_hh = the convs' outputs incl. bias, [B][HW][4g]; c_prev, h, c = [B][HW][g]; g = 16 * 2^k; 16-byte aligned.
- * One workgroup per (image, quarter of the channels): an image's result does not depend on the batch. */
+ * One workgroup per (image, quarter of the channels): an image's result does not depend on the batch.
+ * Training (all five or none): act [B][HW][4g] = the activated gates, c_raw [B][HW][g] = the cell before its norm, stat_ih /
+ * stat_hh / stat_c [2][B][16] = mean and 1 / std of every (image, group) -- the operands of rac_lstm_out_bwd,
+ * rac_groupnorm_bwd and rac_lstm_core_bwd. */
 int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_prev, const float* gamma_ih,
                            const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
-                           const float* beta_c, float* h, float* c, int32_t B, int32_t HW, int32_t g, float eps,
-                           void* stream);
+                           const float* beta_c, float* h, float* c, float* act, float* c_raw, float* stat_ih, float* stat_hh,
+                           float* stat_c, int32_t B, int32_t HW, int32_t g, float eps, void* stream);
 /* y = (x - mean_{b,g}) * rstd_{b,g} * gamma_c + beta_c over groups of C/G channels x HW pixels (biased variance,
  * eps); mean/rstd = fp32 [B][G] saved for the backward pass. */
 int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

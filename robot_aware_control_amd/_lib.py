@@ -31,7 +31,7 @@ class ConvArgs(C.Structure):
 
 
 WGRAD_MAX_STEPS = 16
-ABI_VERSION = 10  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
+ABI_VERSION = 11  # RAC_ABI_VERSION of include/rac_hip.h this binding was written against
 
 
 class AbsmaxJob(C.Structure):
@@ -117,7 +117,7 @@ _SIGS = {
     "rac_lstm_cell_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_cell_bwd": [vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "rac_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
-    "rac_norm_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
+    "rac_norm_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "rac_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
     "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],
     "rac_lstm_out_bwd": [vp, vp, vp, vp, vp, i64, i32, vp],

@@ -1500,7 +1500,11 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
                                                                  const float* gam_ih, const float* bet_ih,
                                                                  const float* gam_hh, const float* bet_hh,
                                                                  const float* gam_c, const float* bet_c, float* h_out,
-                                                                 float* c_out, int HW, int g, float eps) {
+                                                                 float* c_out, float* act_out, float* craw_out,
+                                                                 float* stat_ih, float* stat_hh, float* stat_c, int HW, int g,
+                                                                 float eps) {
+  // (training: act_out [B][HW][4g] = the activated gates, craw_out = the cell before its norm, stat_* [2][B][16] = mean and
+  // 1 / std of every (image, group) -- what rac_lstm_out_bwd / rac_groupnorm_bwd / rac_lstm_core_bwd read; NULL: the frozen model)
   __shared__ float red[4][12];
   const int q = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1557,6 +1561,14 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   block8(rstd);
 #pragma unroll
   for (int k = 0; k < 8; ++k) rstd[k] = 1.0f / sqrtf(rstd[k] * inv_n + eps);
+  if (stat_ih && tid == 0) {
+    const int nB = gridDim.y;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      stat_ih[b * 16 + 4 * k + q] = mean[k], stat_ih[(nB + b) * 16 + 4 * k + q] = rstd[k];
+      stat_hh[b * 16 + 4 * k + q] = mean[4 + k], stat_hh[(nB + b) * 16 + 4 * k + q] = rstd[4 + k];
+    }
+  }
   // gates and the raw cell; the quarter's four cell groups: a thread's vectors all lie in ONE group when Q4 divides 256
   // or 256 divides Q4's multiples -- the launcher's condition (Q4 a power of two <= 256), so one accumulator serves
   const float* cp = c_prev + (long)b * HW * g + q * Cq;
@@ -1579,11 +1591,24 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
         pre[k][e] = ((a[e] - mean[k]) * rstd[k] * ga[e] + ba[e]) + ((h[e] - mean[4 + k]) * rstd[4 + k] * gh[e] + bh[e]);
     }
     const f32x4 cv = *reinterpret_cast<const f32x4*>(cp + (long)p * g + 4 * c4);
-    f32x4 cr;
+    f32x4 cr, gi, gf, gg;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      cr[e] = sigmoid_acc(pre[1][e]) * cv[e] + sigmoid_acc(pre[0][e]) * tanhf(pre[3][e]);
+    for (int e = 0; e < 4; ++e) {
+      gi[e] = sigmoid_acc(pre[0][e]), gf[e] = sigmoid_acc(pre[1][e]), gg[e] = tanhf(pre[3][e]);
+      cr[e] = gf[e] * cv[e] + gi[e] * gg[e];
+    }
     *reinterpret_cast<f32x4*>(co + (long)p * g + 4 * c4) = cr;  // (raw; normalised below by the thread that wrote it)
+    if (act_out) {
+      float* ao = act_out + ((long)b * HW + p) * row4 + q * Cq + 4 * c4;
+      f32x4 go;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) go[e] = sigmoid_acc(pre[2][e]);
+      *reinterpret_cast<f32x4*>(ao) = gi;
+      *reinterpret_cast<f32x4*>(ao + g) = gf;
+      *reinterpret_cast<f32x4*>(ao + 2L * g) = go;
+      *reinterpret_cast<f32x4*>(ao + 3L * g) = gg;
+      *reinterpret_cast<f32x4*>(craw_out + ((long)b * HW + p) * g + q * Cq + 4 * c4) = cr;
+    }
     const int grp = (4 * c4) / cg;
     const float s4 = (cr.x + cr.y) + (cr.z + cr.w);
 #pragma unroll
@@ -1612,6 +1637,11 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   float crstd[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) crstd[j] = 1.0f / sqrtf(cr2[j] * inv_c + eps);
+  if (stat_c && tid == 0) {
+    const int nB = gridDim.y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) stat_c[b * 16 + 4 * q + j] = cmean[j], stat_c[(nB + b) * 16 + 4 * q + j] = crstd[j];
+  }
   for (int i = tid; i < nq; i += 256) {
     const int p = i / Q4, c4 = i - p * Q4;
     const long o = (long)p * row4 + 4 * c4;
@@ -1742,11 +1772,15 @@ int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, flo
 
 int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_prev, const float* gamma_ih,
                            const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
-                           const float* beta_c, float* h, float* c, int32_t B, int32_t HW, int32_t g, float eps,
-                           void* stream) {
+                           const float* beta_c, float* h, float* c, float* act, float* c_raw, float* stat_ih, float* stat_hh,
+                           float* stat_c, int32_t B, int32_t HW, int32_t g, float eps, void* stream) {
   RAC_REQUIRE(g_ih && g_hh && c_prev && gamma_ih && beta_ih && gamma_hh && beta_hh && gamma_c && beta_c && h && c && B > 0 &&
                   HW > 0 && g > 0,
               "rac_norm_lstm_cell_fwd: bad args");
+  RAC_REQUIRE((act != nullptr) == (c_raw != nullptr) && (act != nullptr) == (stat_ih != nullptr) &&
+                  (act != nullptr) == (stat_hh != nullptr) && (act != nullptr) == (stat_c != nullptr) &&
+                  (!act || (aligned16(act) && aligned16(c_raw))),
+              "rac_norm_lstm_cell_fwd: act / c_raw / stat_ih / stat_hh / stat_c come together (training) or not at all");
   const int Q4 = g / 16;
   RAC_REQUIRE(g % 16 == 0 && Q4 >= 1 && Q4 <= 256 && (Q4 & (Q4 - 1)) == 0 && B <= 65535,
               "rac_norm_lstm_cell_fwd: g must be 16 * 2^k <= 4096 (GroupNorm(16, .) groups of whole 16-byte vectors)");
@@ -1754,7 +1788,7 @@ int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_
                   aligned16(beta_ih) && aligned16(gamma_hh) && aligned16(beta_hh) && aligned16(gamma_c) && aligned16(beta_c),
               "rac_norm_lstm_cell_fwd: 16-byte aligned operands");
   hipLaunchKernelGGL(norm_lstm_cell_fwd_kernel, dim3(4, B), dim3(256), 0, ST(stream), g_ih, g_hh, c_prev, gamma_ih, beta_ih,
-                     gamma_hh, beta_hh, gamma_c, beta_c, h, c, HW, g, eps);
+                     gamma_hh, beta_hh, gamma_c, beta_c, h, c, act, c_raw, stat_ih, stat_hh, stat_c, HW, g, eps);
   return check_launch("rac_norm_lstm_cell_fwd");
 }
 

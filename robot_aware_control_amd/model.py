@@ -201,6 +201,12 @@ class _NormLstmCell(nn.Module):
                                         ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, True), c_prev,
                                         (n_ih.weight, n_ih.bias), (n_hh.weight, n_hh.bias), (n_c.weight, n_c.bias))
             return ops.tag_amax(h, ops.amax_one(h.device, h.shape[0])), c  # |h| = |o * tanh(c)| < 1
+        if not frozen and ops.norm_cell_node_ok(x, ci.weight, ch.weight):
+            # training: the whole cell is one autograd node (same kernels, none of the bookkeeping between seven nodes)
+            n_ih, n_hh, n_c = self.ih_gates[1], self.hh_gates[1], self.c_norm
+            h, c = ops.NormLstmCell.apply(x, h_prev, c_prev, ci.weight, ci.bias, n_ih.weight, n_ih.bias, ch.weight, ch.bias,
+                                          n_hh.weight, n_hh.bias, n_c.weight, n_c.bias)
+            return ops.tag_amax(h, ops.amax_one(h.device)), c  # |h| = |o * tanh(c)| < 1
         g_ih = self.ih_gates[1](ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, frozen))
         g_hh = self.hh_gates[1](ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, frozen))
         c_raw, act = ops.NormCellCore.apply(g_ih, g_hh, c_prev)

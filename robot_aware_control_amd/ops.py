@@ -2502,16 +2502,105 @@ def norm_cell_frozen(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c):
     """(h, c) of a NormConvLSTMCell behind its two gate convs, without a tape (lstm.py:174-198): both GroupNorm(16, 4g),
     the gate activations, the cell update, GroupNorm(16, g) of the cell and h = o tanh(c) in ONE launch
     (rac_norm_lstm_cell_fwd) instead of GroupNorm x 3 + cell + output kernels.  `gn_*` = (weight, bias) of the norms."""
+    return _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, False)[:2]
+
+
+def _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, training):
     B, H, W, g4 = g_ih.shape
     g = g4 // 4
     g_ih = g_ih if g_ih.is_contiguous() else g_ih.contiguous()
     g_hh = g_hh if g_hh.is_contiguous() else g_hh.contiguous()
     c_prev = c_prev if c_prev.is_contiguous() else c_prev.contiguous()
-    h = torch.empty((B, H, W, g), device=g_ih.device, dtype=torch.float32)
+    dev = g_ih.device
+    h = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
     c = torch.empty_like(h)
+    act = c_raw = stats = None
+    if training:
+        act = torch.empty((B, H, W, g4), device=dev, dtype=torch.float32)
+        c_raw = torch.empty_like(h)
+        stats = torch.empty((3, 2, B, 16), device=dev, dtype=torch.float32)  # [ih | hh | c][mean | rstd][image][group]
     call("rac_norm_lstm_cell_fwd", ptr(g_ih), ptr(g_hh), ptr(c_prev), ptr(gn_ih[0]), ptr(gn_ih[1]), ptr(gn_hh[0]),
-         ptr(gn_hh[1]), ptr(gn_c[0]), ptr(gn_c[1]), ptr(h), ptr(c), B, H * W, g, 1e-5, stream_ptr())
-    return h, c
+         ptr(gn_hh[1]), ptr(gn_c[0]), ptr(gn_c[1]), ptr(h), ptr(c), ptr(act), ptr(c_raw),
+         ptr(stats[0]) if training else None, ptr(stats[1]) if training else None, ptr(stats[2]) if training else None,
+         B, H * W, g, 1e-5, stream_ptr())
+    return h, c, act, c_raw, stats, g_ih, g_hh, c_prev
+
+
+NORM_CELL_NODE = os.environ.get("RAC_NORM_CELL_NODE", "1") == "1"  # training: the whole NormConvLSTMCell as ONE autograd node
+
+
+def norm_cell_node_ok(x, w_ih, w_hh) -> bool:
+    B, H, W, g = x.shape
+    k = w_ih.shape[2]
+    return (NORM_CELL_NODE and x.is_cuda and norm_cell_frozen_ok(g) and SPLIT_GEMM and g % 32 == 0
+            and tuple(w_ih.shape[:2]) == (4 * g, g) and tuple(w_hh.shape) == tuple(w_ih.shape)
+            and split_supported(H, W, k, g, 4 * g, 0))
+
+
+class NormLstmCell(torch.autograd.Function):
+    """NormConvLSTMCell (lstm.py:151-198) as ONE autograd node: the two gate convs (split-precision pipe), GroupNorm(16, 4g)
+    of each, the gate activations, the cell update, GroupNorm(16, g) of the cell and h = o tanh(c).  Forward: two conv
+    launches + rac_norm_lstm_cell_fwd; backward: rac_lstm_out_bwd, rac_groupnorm_bwd (cell), rac_lstm_core_bwd,
+    rac_groupnorm_bwd x 2, the two data gradients, the deferred (time-batched) weight gradients.  The same kernels as the
+    seven-node form (ConvBias x 2, GroupNorm x 3, NormCellCore, LstmOut) minus the bookkeeping between them: at the deployed
+    model's size (g 256, 6x8 maps, batch 16) the HOST, not the GPU, bounded the train step (tools/host_breakdown.py)."""
+
+    @staticmethod
+    def forward(ctx, x, h_prev, c_prev, w_ih, b_ih, gam_ih, bet_ih, w_hh, b_hh, gam_hh, bet_hh, gam_c, bet_c):
+        g_ih = conv_forward_split(x, None, w_ih, b_ih)
+        g_hh = conv_forward_split(h_prev, None, w_hh, b_hh)
+        h, c, act, c_raw, stats, g_ih, g_hh, c_prev_c = _norm_cell_launch(g_ih, g_hh, c_prev, (gam_ih, bet_ih), (gam_hh, bet_hh),
+                                                                           (gam_c, bet_c), True)
+        ctx.save_for_backward(x, h_prev, c_prev_c, w_ih, b_ih, gam_ih, bet_ih, w_hh, b_hh, gam_hh, bet_hh, gam_c, bet_c,
+                              g_ih, g_hh, act, c_raw, c, stats)
+        ctx.amax = (amax_tag(x), amax_tag(h_prev))
+        ctx.h_zero = is_zero(h_prev)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        (x, h_prev, c_prev, w_ih, b_ih, gam_ih, bet_ih, w_hh, b_hh, gam_hh, bet_hh, gam_c, bet_c, g_ih, g_hh, act, c_raw, c,
+         stats) = ctx.saved_tensors
+        retag(x, ctx.amax[0]), retag(h_prev, ctx.amax[1])
+        B, H, W, g = x.shape
+        M, HW = B * H * W, H * W
+        dev = x.device
+        sp = stream_ptr()
+        want = gam_ih.requires_grad
+        # h = o * tanh(c): gradient on the o slot of the activations and on the normalised cell (+ what the next step sent)
+        d_act = dc_n = None
+        if dh is not None:
+            d_act = torch.empty_like(act)
+            dc_n = torch.empty_like(c)
+            call("rac_lstm_out_bwd", ptr(dh.contiguous()), ptr(act), ptr(c), ptr(d_act), ptr(dc_n), M, g, sp)
+        if dc is not None:
+            dc_n = dc.contiguous() if dc_n is None else dc_n.add_(dc)
+        dc_raw = None
+        if dc_n is not None:
+            dc_raw = torch.empty_like(c)
+            call("rac_groupnorm_bwd", ptr(dc_n), ptr(c_raw), ptr(gam_c), ptr(stats[2, 0]), ptr(stats[2, 1]), ptr(dc_raw),
+                 ptr(grad_buffer(gam_c)) if want else None, ptr(grad_buffer(bet_c)) if want else None, B, HW, g, 16, sp)
+        dgates = torch.empty_like(act)
+        dc_prev = torch.empty_like(c)
+        call("rac_lstm_core_bwd", ptr(dc_raw), ptr(d_act), ptr(act), ptr(c_prev), ptr(dgates), ptr(dc_prev), M, g, sp)
+        dg_ih, dg_hh = torch.empty_like(act), torch.empty_like(act)
+        call("rac_groupnorm_bwd", ptr(dgates), ptr(g_ih), ptr(gam_ih), ptr(stats[0, 0]), ptr(stats[0, 1]), ptr(dg_ih),
+             ptr(grad_buffer(gam_ih)) if want else None, ptr(grad_buffer(bet_ih)) if want else None, B, HW, 4 * g, 16, sp)
+        call("rac_groupnorm_bwd", ptr(dgates), ptr(g_hh), ptr(gam_hh), ptr(stats[1, 0]), ptr(stats[1, 1]), ptr(dg_hh),
+             ptr(grad_buffer(gam_hh)) if want else None, ptr(grad_buffer(bet_hh)) if want else None, B, HW, 4 * g, 16, sp)
+        dx = dh_prev = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = conv_dgrad_split(dg_ih, w_ih, g, 0)
+        if ctx.needs_input_grad[1] and not ctx.h_zero:
+            dh_prev, _ = conv_dgrad_split(dg_hh, w_hh, g, 0)
+        if w_ih.requires_grad:
+            conv_wgrad_split_acc(dg_ih, x, None, w_ih, defer=True)
+            bias_grad_acc(dg_ih, b_ih)
+        if w_hh.requires_grad:
+            if not ctx.h_zero:  # (an all-zero hidden state: the weight's gradient gets nothing from this step)
+                conv_wgrad_split_acc(dg_hh, h_prev, None, w_hh, defer=True)
+            bias_grad_acc(dg_hh, b_hh)
+        return (dx, dh_prev, dc_prev) + (None,) * 10
 
 
 class GroupNorm(torch.autograd.Function):

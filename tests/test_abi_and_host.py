@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 30
     assert declared == set(rac.EXPORTS), declared ^ set(rac.EXPORTS)
     lib = rac.load()  # dlopen + every symbol typed; raises on a missing one
-    assert lib.rac_version() == 10
+    assert lib.rac_version() == 11
     assert lib.rac_device_arch() == b"gfx950"
 
 

@@ -1141,3 +1141,37 @@ def test_norm_lstm_cell_fused_forward(dev, monkeypatch, B, H, W, g):
     assert relerr(c, c2) < 2e-6 and relerr(h, h2) < 2e-6
     h1, c1 = ops.norm_cell_frozen(g_ih[1:2].contiguous(), g_hh[1:2].contiguous(), c_prev[1:2].contiguous(), *gn)
     assert torch.equal(h1[0], h[1]) and torch.equal(c1[0], c[1])
+
+
+@pytest.mark.parametrize("B,H,W,g", [(4, 6, 8, 256), (2, 8, 8, 64)])
+def test_norm_lstm_cell_one_node_matches_seven(dev, monkeypatch, B, H, W, g):
+    """ops.NormLstmCell (the training NormConvLSTMCell as one autograd node around rac_norm_lstm_cell_fwd) against the
+    seven-node form (ConvBias x 2, GroupNorm x 3, NormCellCore, LstmOut): h, c and every gradient -- inputs, both conv
+    weights and biases, the three norms' affines -- over two chained steps (the second feeds on the first's state)."""
+    import argparse
+    from robot_aware_control_amd import model as mdl, ops
+    out = {}
+    for node in (True, False):
+        monkeypatch.setattr(ops, "NORM_CELL_NODE", node)
+        torch.manual_seed(0)
+        cell = mdl._NormLstmCell(g, 5).to(dev)
+        with torch.no_grad():
+            for i, p in enumerate(cell.parameters()):
+                src = rnd(40 + i, *p.shape, scale=(1.0 / np.sqrt(g * 25)) if p.dim() == 4 else 0.1)
+                p.copy_((src if p.dim() != 1 or "norm" not in "" else src).to(dev))
+            for gn in (cell.ih_gates[1], cell.hh_gates[1], cell.c_norm):
+                gn.weight.add_(1.0)
+        x1 = rnd(1, B, H, W, g).to(dev).requires_grad_(True)
+        x2 = rnd(2, B, H, W, g).to(dev).requires_grad_(True)
+        h0 = (rnd(3, B, H, W, g) * 0.5).to(dev).requires_grad_(True)
+        c0 = rnd(4, B, H, W, g).to(dev).requires_grad_(True)
+        with ops.deferred_wgrad():
+            h1, c1 = cell(x1, (ops.tag_amax(h0, ops.amax_of(h0)), c0))
+            h2, c2 = cell(x2, (h1, c1))
+            loss_h, loss_c = rnd(5, B, H, W, g).to(dev), rnd(6, B, H, W, g).to(dev)
+            torch.autograd.backward([h2, c2, h1], [loss_h, loss_c, 0.3 * loss_h])
+        torch.cuda.synchronize()
+        out[node] = ([h1, c1, h2, c2, x1.grad, x2.grad, h0.grad, c0.grad]
+                     + [p.grad for p in cell.parameters()])
+    for i, (a, b) in enumerate(zip(out[True], out[False])):
+        assert relerr(a, b) < 5e-6, i
