@@ -333,6 +333,15 @@ int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_
                            const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
                            const float* beta_c, float* h, float* c, float* act, float* c_raw, float* stat_ih, float* stat_hh,
                            float* stat_c, int32_t B, int32_t HW, int32_t g, float eps, void* stream);
+/* The adjoint of rac_norm_lstm_cell_fwd in ONE launch: from dh and dc (gradients of h and of the normalised cell; either
+ * may be NULL) and the forward pass's act / c / c_raw / stats to dg_ih, dg_hh (gradients of the two gate convs' outputs,
+ * their max |.| folded into the two slots), dc_prev, and -- all six or none -- the three norms' affine gradients (+=). */
+int rac_norm_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c, const float* c_raw,
+                           const float* c_prev, const float* g_ih, const float* g_hh, const float* stat_ih,
+                           const float* stat_hh, const float* stat_c, const float* gamma_ih, const float* gamma_hh,
+                           const float* gamma_c, float* dg_ih, float* dg_hh, float* dc_prev, float* dgamma_ih, float* dbeta_ih,
+                           float* dgamma_hh, float* dbeta_hh, float* dgamma_c, float* dbeta_c, uint32_t* dg_ih_amax,
+                           uint32_t* dg_hh_amax, int32_t B, int32_t HW, int32_t g, void* stream);
 /* y = (x - mean_{b,g}) * rstd_{b,g} * gamma_c + beta_c over groups of C/G channels x HW pixels (biased variance,
  * eps); mean/rstd = fp32 [B][G] saved for the backward pass. */
 int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -119,6 +119,7 @@ _SIGS = {
     "rac_groupnorm_fwd": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp],
     "rac_norm_lstm_cell_fwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, vp],
     "rac_groupnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    "rac_norm_lstm_cell_bwd": [vp] * 25 + [i32, i32, i32, vp],
     "rac_lstm_out_fwd": [vp, vp, vp, i64, i32, vp],
     "rac_lstm_out_bwd": [vp, vp, vp, vp, vp, i64, i32, vp],
     "rac_lstm_core_bwd": [vp, vp, vp, vp, vp, vp, i64, i32, vp],

@@ -1668,6 +1668,199 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   }
 }
 
+// Backward of the whole NormConvLSTMCell behind its gate convs (the adjoint of norm_lstm_cell_fwd_kernel) in ONE launch:
+// h = o tanh(c), c = GroupNorm(16, g)(c_raw), c_raw = f c_prev + i g~, gates = act(GroupNorm(16, 4g)(g_ih) + GroupNorm(16, 4g)(g_hh)).
+// In: dh, dc_in (gradients of h and of the normalised cell; either may be NULL), the forward pass's act / c / c_raw / stats.
+// Out: dg_ih, dg_hh (gradients of the two convs' outputs, with their max |.| folded into two slots), dc_prev, and the
+// three norms' affine gradients (+=: fp32 atomics, one per (workgroup, channel), as rac_groupnorm_bwd's).
+// grid (4, B) as the forward kernel: quarter q of the channels owns gate groups q, 4 + q, 8 + q, 12 + q and cell groups
+// 4 q .. 4 q + 3.  Pass 1: the cell norm's two group sums; pass 2: the gate pre-activation gradients (parked in dg_ih) and
+// the gate norms' 16 group sums; pass 3: both conv-output gradients.
+__global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
+    const float* dh, const float* dc_in, const float* act, const float* c_norm, const float* c_raw, const float* c_prev,
+    const float* g_ih, const float* g_hh, const float* stat_ih, const float* stat_hh, const float* stat_c,
+    const float* gam_ih, const float* gam_hh, const float* gam_c, float* dg_ih, float* dg_hh, float* dc_prev,
+    float* dgam_ih, float* dbet_ih, float* dgam_hh, float* dbet_hh, float* dgam_c, float* dbet_c, unsigned* amax_ih,
+    unsigned* amax_hh, int HW, int g) {
+  __shared__ float red[4][16];
+  extern __shared__ float chan[];  // [18][Cq]: dgamma / dbeta of the cell norm (2), the ih gates (8), the hh gates (8)
+  const int q = blockIdx.x, b = blockIdx.y, nB = gridDim.y;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int Cq = g >> 2, Q4 = Cq >> 2, nq = HW * Q4, cg = g >> 4;
+  const long row4 = 4L * g;
+  const long base4 = (long)b * HW * row4 + q * Cq, base1 = (long)b * HW * g + q * Cq;
+  auto block16 = [&](float (&v)[16]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+      for (int k = 0; k < 16; ++k) red[wv][k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  };
+  for (int i = tid; i < 18 * Cq; i += 256) chan[i] = 0.f;
+  float mu_c[4], rs_c[4], mu_g[8], rs_g[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mu_c[j] = stat_c[b * 16 + 4 * q + j], rs_c[j] = stat_c[(nB + b) * 16 + 4 * q + j];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    mu_g[k] = stat_ih[b * 16 + 4 * k + q], rs_g[k] = stat_ih[(nB + b) * 16 + 4 * k + q];
+    mu_g[4 + k] = stat_hh[b * 16 + 4 * k + q], rs_g[4 + k] = stat_hh[(nB + b) * 16 + 4 * k + q];
+  }
+  __syncthreads();
+  // the gradient reaching the normalised cell at one vector: dh o (1 - tanh^2 c) + dc_in
+  auto dcn_of = [&](int p, int c4, f32x4& tc) {
+    const long o1 = base1 + (long)p * g + 4 * c4;
+    const f32x4 cn = *reinterpret_cast<const f32x4*>(c_norm + o1);
+    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tc[e] = tanhf(cn[e]);
+    if (dh) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dh + o1);
+      const f32x4 go = *reinterpret_cast<const f32x4*>(act + base4 + (long)p * row4 + 2L * g + 4 * c4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] = dv[e] * go[e] * (1.f - tc[e] * tc[e]);
+    }
+    if (dc_in) {
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dc_in + o1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) d[e] += dv[e];
+    }
+    return d;
+  };
+  float s16[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s16[k] = 0.f;
+  for (int i = tid; i < nq; i += 256) {  // pass 1: sum(dcn gamma), sum(dcn gamma c^) per cell group; dgamma_c / dbeta_c
+    const int p = i / Q4, c4 = i - p * Q4;
+    f32x4 tc;
+    const f32x4 d = dcn_of(p, c4, tc);
+    const f32x4 cr = *reinterpret_cast<const f32x4*>(c_raw + base1 + (long)p * g + 4 * c4);
+    const f32x4 gc = *reinterpret_cast<const f32x4*>(gam_c + q * Cq + 4 * c4);
+    const int grp = (4 * c4) / cg;
+    float mg = mu_c[0], rg = rs_c[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) mg = grp == j ? mu_c[j] : mg, rg = grp == j ? rs_c[j] : rg;
+    float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (cr[e] - mg) * rg, dg = d[e] * gc[e];
+      a1 += dg, a2 += dg * xh;
+      if (dgam_c) {
+        atomicAdd(&chan[4 * c4 + e], d[e] * xh);
+        atomicAdd(&chan[Cq + 4 * c4 + e], d[e]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s16[2 * j] += grp == j ? a1 : 0.f, s16[2 * j + 1] += grp == j ? a2 : 0.f;
+  }
+  block16(s16);
+  float m1c[4], m2c[4];
+  const float inv_c = 1.0f / (float)(HW * cg), inv_n = 1.0f / (float)(HW * Cq);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) m1c[j] = s16[2 * j] * inv_c, m2c[j] = s16[2 * j + 1] * inv_c;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s16[k] = 0.f;
+  for (int i = tid; i < nq; i += 256) {  // pass 2: dc_raw, dc_prev, the gate pre-activation gradients and their group sums
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o4 = base4 + (long)p * row4 + 4 * c4, o1 = base1 + (long)p * g + 4 * c4;
+    f32x4 tc;
+    const f32x4 d = dcn_of(p, c4, tc);
+    const f32x4 cr = *reinterpret_cast<const f32x4*>(c_raw + o1);
+    const f32x4 gc = *reinterpret_cast<const f32x4*>(gam_c + q * Cq + 4 * c4);
+    const f32x4 cp = *reinterpret_cast<const f32x4*>(c_prev + o1);
+    const int grp = (4 * c4) / cg;
+    float mg = mu_c[0], rg = rs_c[0], m1 = m1c[0], m2 = m2c[0];
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      mg = grp == j ? mu_c[j] : mg, rg = grp == j ? rs_c[j] : rg, m1 = grp == j ? m1c[j] : m1, m2 = grp == j ? m2c[j] : m2;
+    const f32x4 gi = *reinterpret_cast<const f32x4*>(act + o4), gf = *reinterpret_cast<const f32x4*>(act + o4 + g);
+    const f32x4 go = *reinterpret_cast<const f32x4*>(act + o4 + 2L * g), gg = *reinterpret_cast<const f32x4*>(act + o4 + 3L * g);
+    f32x4 dpre[4], dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (cr[e] - mg) * rg;
+      const float dcr = rg * (d[e] * gc[e] - m1 - xh * m2);
+      const float dov = dh ? dh[o1 + e] * tc[e] : 0.f;
+      dpre[0][e] = dcr * gg[e] * gi[e] * (1.f - gi[e]);
+      dpre[1][e] = dcr * cp[e] * gf[e] * (1.f - gf[e]);
+      dpre[2][e] = dov * go[e] * (1.f - go[e]);
+      dpre[3][e] = dcr * gi[e] * (1.f - gg[e] * gg[e]);
+      dcp[e] = dcr * gf[e];
+    }
+    *reinterpret_cast<f32x4*>(dc_prev + o1) = dcp;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      *reinterpret_cast<f32x4*>(dg_ih + o4 + (long)k * g) = dpre[k];  // (parked: pass 3 turns it into the conv's gradient)
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(g_ih + o4 + (long)k * g);
+      const f32x4 xb = *reinterpret_cast<const f32x4*>(g_hh + o4 + (long)k * g);
+      const int ch = k * g + q * Cq + 4 * c4;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam_ih + ch), gb = *reinterpret_cast<const f32x4*>(gam_hh + ch);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ha = (xa[e] - mu_g[k]) * rs_g[k], hb = (xb[e] - mu_g[4 + k]) * rs_g[4 + k];
+        s16[2 * k] += dpre[k][e] * ga[e];
+        s16[2 * k + 1] += dpre[k][e] * ga[e] * ha;
+        s16[8 + 2 * k] += dpre[k][e] * gb[e];
+        s16[8 + 2 * k + 1] += dpre[k][e] * gb[e] * hb;
+        if (dgam_ih) {
+          atomicAdd(&chan[(2 + k) * Cq + 4 * c4 + e], dpre[k][e] * ha);
+          atomicAdd(&chan[(6 + k) * Cq + 4 * c4 + e], dpre[k][e]);
+          atomicAdd(&chan[(10 + k) * Cq + 4 * c4 + e], dpre[k][e] * hb);
+        }
+      }
+    }
+  }
+  block16(s16);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s16[k] *= inv_n;
+  unsigned mxa = 0, mxb = 0;
+  for (int i = tid; i < nq; i += 256) {  // pass 3: the two convs' output gradients
+    const int p = i / Q4, c4 = i - p * Q4;
+    const long o4 = base4 + (long)p * row4 + 4 * c4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f32x4 dp = *reinterpret_cast<const f32x4*>(dg_ih + o4 + (long)k * g);
+      const f32x4 xa = *reinterpret_cast<const f32x4*>(g_ih + o4 + (long)k * g);
+      const f32x4 xb = *reinterpret_cast<const f32x4*>(g_hh + o4 + (long)k * g);
+      const int ch = k * g + q * Cq + 4 * c4;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gam_ih + ch), gb = *reinterpret_cast<const f32x4*>(gam_hh + ch);
+      f32x4 oa, ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ha = (xa[e] - mu_g[k]) * rs_g[k], hb = (xb[e] - mu_g[4 + k]) * rs_g[4 + k];
+        oa[e] = rs_g[k] * (dp[e] * ga[e] - s16[2 * k] - ha * s16[2 * k + 1]);
+        ob[e] = rs_g[4 + k] * (dp[e] * gb[e] - s16[8 + 2 * k] - hb * s16[8 + 2 * k + 1]);
+        mxa = max(mxa, absbits(oa[e]));
+        mxb = max(mxb, absbits(ob[e]));
+      }
+      *reinterpret_cast<f32x4*>(dg_ih + o4 + (long)k * g) = oa;
+      *reinterpret_cast<f32x4*>(dg_hh + o4 + (long)k * g) = ob;
+    }
+  }
+  if (amax_ih) amax_commit_block(mxa, amax_ih);
+  if (amax_hh) {
+    __syncthreads();
+    amax_commit_block(mxb, amax_hh);
+  }
+  __syncthreads();
+  if (dgam_c)
+    for (int i = tid; i < Cq; i += 256) {
+      atomicAdd(dgam_c + q * Cq + i, chan[i]);
+      atomicAdd(dbet_c + q * Cq + i, chan[Cq + i]);
+    }
+  if (dgam_ih)
+    for (int i = tid; i < 4 * Cq; i += 256) {
+      const int k = i / Cq, cc = i - k * Cq, ch = k * g + q * Cq + cc;
+      atomicAdd(dgam_ih + ch, chan[(2 + k) * Cq + cc]);
+      atomicAdd(dbet_ih + ch, chan[(6 + k) * Cq + cc]);
+      atomicAdd(dgam_hh + ch, chan[(10 + k) * Cq + cc]);
+      atomicAdd(dbet_hh + ch, chan[(6 + k) * Cq + cc]);  // (dbeta of both gate norms is the same sum of dpre)
+    }
+}
+
 __global__ void groupnorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean_i,
                                      const float* rstd_i, float* dx, float* dgamma, float* dbeta, int HW, int C,
                                      int G) {
@@ -1790,6 +1983,34 @@ int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_
   hipLaunchKernelGGL(norm_lstm_cell_fwd_kernel, dim3(4, B), dim3(256), 0, ST(stream), g_ih, g_hh, c_prev, gamma_ih, beta_ih,
                      gamma_hh, beta_hh, gamma_c, beta_c, h, c, act, c_raw, stat_ih, stat_hh, stat_c, HW, g, eps);
   return check_launch("rac_norm_lstm_cell_fwd");
+}
+
+int rac_norm_lstm_cell_bwd(const float* dh, const float* dc, const float* act, const float* c, const float* c_raw,
+                           const float* c_prev, const float* g_ih, const float* g_hh, const float* stat_ih,
+                           const float* stat_hh, const float* stat_c, const float* gamma_ih, const float* gamma_hh,
+                           const float* gamma_c, float* dg_ih, float* dg_hh, float* dc_prev, float* dgamma_ih, float* dbeta_ih,
+                           float* dgamma_hh, float* dbeta_hh, float* dgamma_c, float* dbeta_c, uint32_t* dg_ih_amax,
+                           uint32_t* dg_hh_amax, int32_t B, int32_t HW, int32_t g, void* stream) {
+  RAC_REQUIRE(act && c && c_raw && c_prev && g_ih && g_hh && stat_ih && stat_hh && stat_c && gamma_ih && gamma_hh && gamma_c &&
+                  dg_ih && dg_hh && dc_prev && B > 0 && HW > 0 && g > 0,
+              "rac_norm_lstm_cell_bwd: bad args");
+  const int Q4 = g / 16;
+  RAC_REQUIRE(g % 16 == 0 && Q4 >= 1 && Q4 <= 256 && (Q4 & (Q4 - 1)) == 0 && B <= 65535,
+              "rac_norm_lstm_cell_bwd: g must be 16 * 2^k <= 4096");
+  const bool aff = dgamma_ih != nullptr;
+  RAC_REQUIRE(aff == (dbeta_ih != nullptr) && aff == (dgamma_hh != nullptr) && aff == (dbeta_hh != nullptr) &&
+                  aff == (dgamma_c != nullptr) && aff == (dbeta_c != nullptr),
+              "rac_norm_lstm_cell_bwd: the six affine gradients come together or not at all");
+  RAC_REQUIRE((!dh || aligned16(dh)) && (!dc || aligned16(dc)) && aligned16(act) && aligned16(c) && aligned16(c_raw) &&
+                  aligned16(c_prev) && aligned16(g_ih) && aligned16(g_hh) && aligned16(dg_ih) && aligned16(dg_hh) &&
+                  aligned16(dc_prev) && aligned16(gamma_ih) && aligned16(gamma_hh) && aligned16(gamma_c),
+              "rac_norm_lstm_cell_bwd: 16-byte aligned operands");
+  const size_t lds = (size_t)18 * (g / 4) * sizeof(float);
+  RAC_REQUIRE(lds <= 48 * 1024, "rac_norm_lstm_cell_bwd: g too wide for the per-channel accumulators");
+  hipLaunchKernelGGL(norm_lstm_cell_bwd_kernel, dim3(4, B), dim3(256), lds, ST(stream), dh, dc, act, c, c_raw, c_prev, g_ih,
+                     g_hh, stat_ih, stat_hh, stat_c, gamma_ih, gamma_hh, gamma_c, dg_ih, dg_hh, dc_prev, dgamma_ih, dbeta_ih,
+                     dgamma_hh, dbeta_hh, dgamma_c, dbeta_c, dg_ih_amax, dg_hh_amax, HW, g);
+  return check_launch("rac_norm_lstm_cell_bwd");
 }
 
 int rac_groupnorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

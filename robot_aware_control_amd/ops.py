@@ -156,7 +156,11 @@ MAX_SPLIT_K = int(os.environ.get("RAC_MAX_SPLIT_K", "8"))  # most K splits of a 
 def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> int:
     """K-splits of a FWD/DGRAD launch so that >= ~2 workgroups land on each of the 256 CUs.  Mirrors the tile
     choice of rac_conv2d (128x128 when tiles*split >= 192, else 64x64, 128x32 for narrow N)."""
-    forced = os.environ.get("RAC_SPLIT")
+    return _plan_split_k(M, N, nchunks, tile128_only, os.environ.get("RAC_SPLIT"), MAX_SPLIT_K)
+
+
+@functools.lru_cache(maxsize=None)
+def _plan_split_k(M, N, nchunks, tile128_only, forced, max_split):
     if forced:
         return max(1, min(int(forced), nchunks))
     cap = max(1, nchunks // 8)  # keep >= 8 chunks per split: the pipeline prologue/epilogue must amortise
@@ -169,7 +173,7 @@ def plan_split_k(M: int, N: int, nchunks: int, tile128_only: bool = False) -> in
         # x 3 = 480 workgroups 78 us against 88 (x 4 = 640: a quarter-full second round) and 97 (x 2); 320 tiles x 3 = 960
         # 89 us against 98 (x 1: half the slots idle) and 96 (x 4); the gate GEMMs keep 128 x 4 and 64 x 8 = 512.
         best, best_eff = 1, -1.0
-        for s in range(1, min(MAX_SPLIT_K, cap) + 1):
+        for s in range(1, min(max_split, cap) + 1):
             rounds = t128 * s / 512.0
             eff = (rounds / -(-rounds // 1) if rounds > 1 else rounds) * (1.0 - 0.03 * (s - 1))
             if eff > best_eff + 1e-9:
@@ -1266,7 +1270,11 @@ def wgrad_split_ok(x0, x1, weight) -> bool:
 def plan_wgrad_split(tiles: int, groups: int) -> int:
     """K splits of a weight-gradient launch: 512 workgroups run at a time (2 per CU); pick the split whose last round
     is fullest (each extra split costs a slab write + read of the gradient)."""
-    forced = os.environ.get("RAC_WGRAD_SPLITK")
+    return _plan_wgrad_split(tiles, groups, os.environ.get("RAC_WGRAD_SPLITK"))
+
+
+@functools.lru_cache(maxsize=None)
+def _plan_wgrad_split(tiles, groups, forced):
     if forced:
         return max(1, min(int(forced), groups))
     if tiles >= 768:
@@ -2526,6 +2534,7 @@ def _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, training):
     return h, c, act, c_raw, stats, g_ih, g_hh, c_prev
 
 
+NORM_CELL_BWD_FUSED = os.environ.get("RAC_NORM_CELL_BWD_FUSED", "1") == "1"  # ... and its pointwise backward as ONE launch
 NORM_CELL_NODE = os.environ.get("RAC_NORM_CELL_NODE", "1") == "1"  # training: the whole NormConvLSTMCell as ONE autograd node
 
 
@@ -2567,27 +2576,40 @@ class NormLstmCell(torch.autograd.Function):
         dev = x.device
         sp = stream_ptr()
         want = gam_ih.requires_grad
-        # h = o * tanh(c): gradient on the o slot of the activations and on the normalised cell (+ what the next step sent)
-        d_act = dc_n = None
-        if dh is not None:
-            d_act = torch.empty_like(act)
-            dc_n = torch.empty_like(c)
-            call("rac_lstm_out_bwd", ptr(dh.contiguous()), ptr(act), ptr(c), ptr(d_act), ptr(dc_n), M, g, sp)
-        if dc is not None:
-            dc_n = dc.contiguous() if dc_n is None else dc_n.add_(dc)
-        dc_raw = None
-        if dc_n is not None:
-            dc_raw = torch.empty_like(c)
-            call("rac_groupnorm_bwd", ptr(dc_n), ptr(c_raw), ptr(gam_c), ptr(stats[2, 0]), ptr(stats[2, 1]), ptr(dc_raw),
-                 ptr(grad_buffer(gam_c)) if want else None, ptr(grad_buffer(bet_c)) if want else None, B, HW, g, 16, sp)
-        dgates = torch.empty_like(act)
-        dc_prev = torch.empty_like(c)
-        call("rac_lstm_core_bwd", ptr(dc_raw), ptr(d_act), ptr(act), ptr(c_prev), ptr(dgates), ptr(dc_prev), M, g, sp)
         dg_ih, dg_hh = torch.empty_like(act), torch.empty_like(act)
-        call("rac_groupnorm_bwd", ptr(dgates), ptr(g_ih), ptr(gam_ih), ptr(stats[0, 0]), ptr(stats[0, 1]), ptr(dg_ih),
-             ptr(grad_buffer(gam_ih)) if want else None, ptr(grad_buffer(bet_ih)) if want else None, B, HW, 4 * g, 16, sp)
-        call("rac_groupnorm_bwd", ptr(dgates), ptr(g_hh), ptr(gam_hh), ptr(stats[1, 0]), ptr(stats[1, 1]), ptr(dg_hh),
-             ptr(grad_buffer(gam_hh)) if want else None, ptr(grad_buffer(bet_hh)) if want else None, B, HW, 4 * g, 16, sp)
+        dc_prev = torch.empty_like(c)
+        if NORM_CELL_BWD_FUSED:
+            # everything between the incoming gradients and the two convs' output gradients: one launch
+            sa, sb = amax_slot(dev), amax_slot(dev)
+            dh_c = dh.contiguous() if dh is not None else None  # (locals: the copies must outlive the launch)
+            dc_c = dc.contiguous() if dc is not None else None
+            call("rac_norm_lstm_cell_bwd", ptr(dh_c), ptr(dc_c), ptr(act), ptr(c), ptr(c_raw), ptr(c_prev), ptr(g_ih),
+                 ptr(g_hh), ptr(stats[0]), ptr(stats[1]), ptr(stats[2]), ptr(gam_ih), ptr(gam_hh), ptr(gam_c), ptr(dg_ih),
+                 ptr(dg_hh), ptr(dc_prev), ptr(grad_buffer(gam_ih)) if want else None,
+                 ptr(grad_buffer(bet_ih)) if want else None, ptr(grad_buffer(gam_hh)) if want else None,
+                 ptr(grad_buffer(bet_hh)) if want else None, ptr(grad_buffer(gam_c)) if want else None,
+                 ptr(grad_buffer(bet_c)) if want else None, ptr(sa), ptr(sb), B, HW, g, sp)
+            tag_amax(dg_ih, sa), tag_amax(dg_hh, sb)
+        else:
+            # h = o * tanh(c): gradient on the o slot of the activations and on the normalised cell (+ what the next step sent)
+            d_act = dc_n = None
+            if dh is not None:
+                d_act = torch.empty_like(act)
+                dc_n = torch.empty_like(c)
+                call("rac_lstm_out_bwd", ptr(dh.contiguous()), ptr(act), ptr(c), ptr(d_act), ptr(dc_n), M, g, sp)
+            if dc is not None:
+                dc_n = dc.contiguous() if dc_n is None else dc_n.add_(dc)
+            dc_raw = None
+            if dc_n is not None:
+                dc_raw = torch.empty_like(c)
+                call("rac_groupnorm_bwd", ptr(dc_n), ptr(c_raw), ptr(gam_c), ptr(stats[2, 0]), ptr(stats[2, 1]), ptr(dc_raw),
+                     ptr(grad_buffer(gam_c)) if want else None, ptr(grad_buffer(bet_c)) if want else None, B, HW, g, 16, sp)
+            dgates = torch.empty_like(act)
+            call("rac_lstm_core_bwd", ptr(dc_raw), ptr(d_act), ptr(act), ptr(c_prev), ptr(dgates), ptr(dc_prev), M, g, sp)
+            call("rac_groupnorm_bwd", ptr(dgates), ptr(g_ih), ptr(gam_ih), ptr(stats[0, 0]), ptr(stats[0, 1]), ptr(dg_ih),
+                 ptr(grad_buffer(gam_ih)) if want else None, ptr(grad_buffer(bet_ih)) if want else None, B, HW, 4 * g, 16, sp)
+            call("rac_groupnorm_bwd", ptr(dgates), ptr(g_hh), ptr(gam_hh), ptr(stats[1, 0]), ptr(stats[1, 1]), ptr(dg_hh),
+                 ptr(grad_buffer(gam_hh)) if want else None, ptr(grad_buffer(bet_hh)) if want else None, B, HW, 4 * g, 16, sp)
         dx = dh_prev = None
         if ctx.needs_input_grad[0]:
             dx, _ = conv_dgrad_split(dg_ih, w_ih, g, 0)
