@@ -1496,7 +1496,7 @@ __global__ void groupnorm_fwd_kernel(const float* x, const float* gamma, const f
 // all of them whole.  grid (4, B), 256 threads: one (image, quarter) per workgroup, its 8 + 1 slabs of HW x g/4 values read
 // three times (mean; centred squares, as groupnorm_fwd_kernel; gates) -- the first time from memory, then from the caches.
 // An image's arithmetic touches nothing of another image: batch-invariant by construction.
-__global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_ih, const float* g_hh, const float* c_prev,
+__global__ __launch_bounds__(512) void norm_lstm_cell_fwd_kernel(const float* g_ih, const float* g_hh, const float* c_prev,
                                                                  const float* gam_ih, const float* bet_ih,
                                                                  const float* gam_hh, const float* bet_hh,
                                                                  const float* gam_c, const float* bet_c, float* h_out,
@@ -1505,7 +1505,8 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
                                                                  float eps) {
   // (training: act_out [B][HW][4g] = the activated gates, craw_out = the cell before its norm, stat_* [2][B][16] = mean and
   // 1 / std of every (image, group) -- what rac_lstm_out_bwd / rac_groupnorm_bwd / rac_lstm_core_bwd read; NULL: the frozen model)
-  __shared__ float red[4][12];
+  __shared__ float red[8][12];
+  const int NT = blockDim.x, NW = NT >> 6;  // 256 threads, or 512 for small batches (few workgroups: more loads in flight each)
   const int q = blockIdx.x, b = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int Cq = g >> 2, Q4 = Cq >> 2;          // channels of the quarter, 16-byte vectors per pixel of it
@@ -1524,12 +1525,16 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
       for (int k = 0; k < 8; ++k) red[wv][k] = v[k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    for (int k = 0; k < 8; ++k) {
+      float t = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      if (NW == 8) t += (red[4][k] + red[5][k]) + (red[6][k] + red[7][k]);
+      v[k] = t;
+    }
   };
   float mean[8], rstd[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) mean[k] = 0.f;
-  for (int i = tid; i < nq; i += 256) {
+  for (int i = tid; i < nq; i += NT) {
     const int p = i / Q4, c4 = i - p * Q4;
     const long o = (long)p * row4 + 4 * c4;
 #pragma unroll
@@ -1543,7 +1548,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   block8(mean);
 #pragma unroll
   for (int k = 0; k < 8; ++k) mean[k] *= inv_n, rstd[k] = 0.f;
-  for (int i = tid; i < nq; i += 256) {
+  for (int i = tid; i < nq; i += NT) {
     const int p = i / Q4, c4 = i - p * Q4;
     const long o = (long)p * row4 + 4 * c4;
 #pragma unroll
@@ -1575,7 +1580,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   float* co = c_out + (long)b * HW * g + q * Cq;
   float* ho = h_out + (long)b * HW * g + q * Cq;
   float csum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int i = tid; i < nq; i += 256) {
+  for (int i = tid; i < nq; i += NT) {
     const int p = i / Q4, c4 = i - p * Q4;
     const long o = (long)p * row4 + 4 * c4;
     f32x4 pre[4];
@@ -1620,7 +1625,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
   float cmean[4], cr2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int j = 0; j < 4; ++j) cmean[j] = m8[j] * inv_c;
-  for (int i = tid; i < nq; i += 256) {
+  for (int i = tid; i < nq; i += NT) {
     const int p = i / Q4, c4 = i - p * Q4;
     const f32x4 cr = *reinterpret_cast<const f32x4*>(co + (long)p * g + 4 * c4);
     const int grp = (4 * c4) / cg;
@@ -1642,7 +1647,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
 #pragma unroll
     for (int j = 0; j < 4; ++j) stat_c[b * 16 + 4 * q + j] = cmean[j], stat_c[(nB + b) * 16 + 4 * q + j] = crstd[j];
   }
-  for (int i = tid; i < nq; i += 256) {
+  for (int i = tid; i < nq; i += NT) {
     const int p = i / Q4, c4 = i - p * Q4;
     const long o = (long)p * row4 + 4 * c4;
     const f32x4 cr = *reinterpret_cast<const f32x4*>(co + (long)p * g + 4 * c4);
@@ -1676,14 +1681,18 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_fwd_kernel(const float* g_
 // grid (4, B) as the forward kernel: quarter q of the channels owns gate groups q, 4 + q, 8 + q, 12 + q and cell groups
 // 4 q .. 4 q + 3.  Pass 1: the cell norm's two group sums; pass 2: the gate pre-activation gradients (parked in dg_ih) and
 // the gate norms' 16 group sums; pass 3: both conv-output gradients.
-__global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
+__global__ __launch_bounds__(512) void norm_lstm_cell_bwd_kernel(
     const float* dh, const float* dc_in, const float* act, const float* c_norm, const float* c_raw, const float* c_prev,
     const float* g_ih, const float* g_hh, const float* stat_ih, const float* stat_hh, const float* stat_c,
     const float* gam_ih, const float* gam_hh, const float* gam_c, float* dg_ih, float* dg_hh, float* dc_prev,
     float* dgam_ih, float* dbet_ih, float* dgam_hh, float* dbet_hh, float* dgam_c, float* dbet_c, unsigned* amax_ih,
     unsigned* amax_hh, int HW, int g) {
-  __shared__ float red[4][16];
-  extern __shared__ float chan[];  // [18][Cq]: dgamma / dbeta of the cell norm (2), the ih gates (8), the hh gates (8)
+  __shared__ float red[8][16];
+  const int NT = blockDim.x, NW = NT >> 6;
+  // dgamma / dbeta: a thread's vectors all carry ONE channel quad (its index strides by 256, a multiple of Q4), so it sums
+  // its 14 quads -- cell norm (dgamma, dbeta), gates k = 0..3 (dgamma_ih, dbeta, dgamma_hh) -- in registers; the 256 / Q4
+  // threads of a quad meet in LDS ([14][256] vectors) once, at the end.  (LDS atomics per value: 107 us per launch.)
+  extern __shared__ f32x4 chan4[];
   const int q = blockIdx.x, b = blockIdx.y, nB = gridDim.y;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int Cq = g >> 2, Q4 = Cq >> 2, nq = HW * Q4, cg = g >> 4;
@@ -1698,9 +1707,15 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
       for (int k = 0; k < 16; ++k) red[wv][k] = v[k];
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    for (int k = 0; k < 16; ++k) {
+      float t = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      if (NW == 8) t += (red[4][k] + red[5][k]) + (red[6][k] + red[7][k]);
+      v[k] = t;
+    }
   };
-  for (int i = tid; i < 18 * Cq; i += 256) chan[i] = 0.f;
+  f32x4 acc[14];
+#pragma unroll
+  for (int v = 0; v < 14; ++v) acc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
   float mu_c[4], rs_c[4], mu_g[8], rs_g[8];
 #pragma unroll
   for (int j = 0; j < 4; ++j) mu_c[j] = stat_c[b * 16 + 4 * q + j], rs_c[j] = stat_c[(nB + b) * 16 + 4 * q + j];
@@ -1733,7 +1748,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
   float s16[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) s16[k] = 0.f;
-  for (int i = tid; i < nq; i += 256) {  // pass 1: sum(dcn gamma), sum(dcn gamma c^) per cell group; dgamma_c / dbeta_c
+  for (int i = tid; i < nq; i += NT) {  // pass 1: sum(dcn gamma), sum(dcn gamma c^) per cell group; dgamma_c / dbeta_c
     const int p = i / Q4, c4 = i - p * Q4;
     f32x4 tc;
     const f32x4 d = dcn_of(p, c4, tc);
@@ -1748,10 +1763,8 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
     for (int e = 0; e < 4; ++e) {
       const float xh = (cr[e] - mg) * rg, dg = d[e] * gc[e];
       a1 += dg, a2 += dg * xh;
-      if (dgam_c) {
-        atomicAdd(&chan[4 * c4 + e], d[e] * xh);
-        atomicAdd(&chan[Cq + 4 * c4 + e], d[e]);
-      }
+      acc[0][e] += d[e] * xh;
+      acc[1][e] += d[e];
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) s16[2 * j] += grp == j ? a1 : 0.f, s16[2 * j + 1] += grp == j ? a2 : 0.f;
@@ -1763,7 +1776,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
   for (int j = 0; j < 4; ++j) m1c[j] = s16[2 * j] * inv_c, m2c[j] = s16[2 * j + 1] * inv_c;
 #pragma unroll
   for (int k = 0; k < 16; ++k) s16[k] = 0.f;
-  for (int i = tid; i < nq; i += 256) {  // pass 2: dc_raw, dc_prev, the gate pre-activation gradients and their group sums
+  for (int i = tid; i < nq; i += NT) {  // pass 2: dc_raw, dc_prev, the gate pre-activation gradients and their group sums
     const int p = i / Q4, c4 = i - p * Q4;
     const long o4 = base4 + (long)p * row4 + 4 * c4, o1 = base1 + (long)p * g + 4 * c4;
     f32x4 tc;
@@ -1805,11 +1818,9 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
         s16[2 * k + 1] += dpre[k][e] * ga[e] * ha;
         s16[8 + 2 * k] += dpre[k][e] * gb[e];
         s16[8 + 2 * k + 1] += dpre[k][e] * gb[e] * hb;
-        if (dgam_ih) {
-          atomicAdd(&chan[(2 + k) * Cq + 4 * c4 + e], dpre[k][e] * ha);
-          atomicAdd(&chan[(6 + k) * Cq + 4 * c4 + e], dpre[k][e]);
-          atomicAdd(&chan[(10 + k) * Cq + 4 * c4 + e], dpre[k][e] * hb);
-        }
+        acc[2 + k][e] += dpre[k][e] * ha;
+        acc[6 + k][e] += dpre[k][e];
+        acc[10 + k][e] += dpre[k][e] * hb;
       }
     }
   }
@@ -1817,7 +1828,7 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
 #pragma unroll
   for (int k = 0; k < 16; ++k) s16[k] *= inv_n;
   unsigned mxa = 0, mxb = 0;
-  for (int i = tid; i < nq; i += 256) {  // pass 3: the two convs' output gradients
+  for (int i = tid; i < nq; i += NT) {  // pass 3: the two convs' output gradients
     const int p = i / Q4, c4 = i - p * Q4;
     const long o4 = base4 + (long)p * row4 + 4 * c4;
 #pragma unroll
@@ -1845,20 +1856,31 @@ __global__ __launch_bounds__(256) void norm_lstm_cell_bwd_kernel(
     __syncthreads();
     amax_commit_block(mxb, amax_hh);
   }
-  __syncthreads();
-  if (dgam_c)
-    for (int i = tid; i < Cq; i += 256) {
-      atomicAdd(dgam_c + q * Cq + i, chan[i]);
-      atomicAdd(dbet_c + q * Cq + i, chan[Cq + i]);
+  if (dgam_ih) {
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 14; ++v) chan4[v * NT + tid] = acc[v];
+    __syncthreads();
+    const int rpq = NT / Q4;  // threads per channel quad: tid = r * Q4 + c4
+    for (int i = tid; i < 14 * Q4; i += NT) {
+      const int v = i / Q4, c4 = i - v * Q4;
+      f32x4 t = chan4[v * NT + c4];
+      for (int r = 1; r < rpq; ++r) t += chan4[v * NT + r * Q4 + c4];
+      float* dst;
+      if (v == 0) dst = dgam_c + q * Cq;
+      else if (v == 1) dst = dbet_c + q * Cq;
+      else if (v < 6) dst = dgam_ih + (v - 2) * g + q * Cq;
+      else if (v < 10) dst = dbet_ih + (v - 6) * g + q * Cq;
+      else dst = dgam_hh + (v - 10) * g + q * Cq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(dst + 4 * c4 + e, t[e]);
+      if (v >= 6 && v < 10) {  // (dbeta of both gate norms is the same sum of the pre-activation gradients)
+        float* d2 = dbet_hh + (v - 6) * g + q * Cq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomicAdd(d2 + 4 * c4 + e, t[e]);
+      }
     }
-  if (dgam_ih)
-    for (int i = tid; i < 4 * Cq; i += 256) {
-      const int k = i / Cq, cc = i - k * Cq, ch = k * g + q * Cq + cc;
-      atomicAdd(dgam_ih + ch, chan[(2 + k) * Cq + cc]);
-      atomicAdd(dbet_ih + ch, chan[(6 + k) * Cq + cc]);
-      atomicAdd(dgam_hh + ch, chan[(10 + k) * Cq + cc]);
-      atomicAdd(dbet_hh + ch, chan[(6 + k) * Cq + cc]);  // (dbeta of both gate norms is the same sum of dpre)
-    }
+  }
 }
 
 __global__ void groupnorm_bwd_kernel(const float* dy, const float* x, const float* gamma, const float* mean_i,
@@ -1963,6 +1985,14 @@ int rac_groupnorm_fwd(const float* x, const float* gamma, const float* beta, flo
   return check_launch("rac_groupnorm_fwd");
 }
 
+// threads per (image, quarter) workgroup of the fused NormConvLSTMCell kernels: 512 while the launch has fewer workgroups
+// than two per CU (a training batch: 64) -- the passes are bound by what one workgroup keeps in flight -- else 256
+static int norm_cell_threads(int B, int g) {
+  static const int forced = [] { const char* e = getenv("RAC_NORM_CELL_THREADS"); return e ? atoi(e) : 0; }();
+  if (forced == 256 || forced == 512) return forced;
+  return (4 * B < 512 && g / 16 <= 256) ? 512 : 256;
+}
+
 int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_prev, const float* gamma_ih,
                            const float* beta_ih, const float* gamma_hh, const float* beta_hh, const float* gamma_c,
                            const float* beta_c, float* h, float* c, float* act, float* c_raw, float* stat_ih, float* stat_hh,
@@ -1980,7 +2010,7 @@ int rac_norm_lstm_cell_fwd(const float* g_ih, const float* g_hh, const float* c_
   RAC_REQUIRE(aligned16(g_ih) && aligned16(g_hh) && aligned16(c_prev) && aligned16(h) && aligned16(c) && aligned16(gamma_ih) &&
                   aligned16(beta_ih) && aligned16(gamma_hh) && aligned16(beta_hh) && aligned16(gamma_c) && aligned16(beta_c),
               "rac_norm_lstm_cell_fwd: 16-byte aligned operands");
-  hipLaunchKernelGGL(norm_lstm_cell_fwd_kernel, dim3(4, B), dim3(256), 0, ST(stream), g_ih, g_hh, c_prev, gamma_ih, beta_ih,
+  hipLaunchKernelGGL(norm_lstm_cell_fwd_kernel, dim3(4, B), dim3(norm_cell_threads(B, g)), 0, ST(stream), g_ih, g_hh, c_prev, gamma_ih, beta_ih,
                      gamma_hh, beta_hh, gamma_c, beta_c, h, c, act, c_raw, stat_ih, stat_hh, stat_c, HW, g, eps);
   return check_launch("rac_norm_lstm_cell_fwd");
 }
@@ -2005,9 +2035,16 @@ int rac_norm_lstm_cell_bwd(const float* dh, const float* dc, const float* act, c
                   aligned16(c_prev) && aligned16(g_ih) && aligned16(g_hh) && aligned16(dg_ih) && aligned16(dg_hh) &&
                   aligned16(dc_prev) && aligned16(gamma_ih) && aligned16(gamma_hh) && aligned16(gamma_c),
               "rac_norm_lstm_cell_bwd: 16-byte aligned operands");
-  const size_t lds = (size_t)18 * (g / 4) * sizeof(float);
-  RAC_REQUIRE(lds <= 48 * 1024, "rac_norm_lstm_cell_bwd: g too wide for the per-channel accumulators");
-  hipLaunchKernelGGL(norm_lstm_cell_bwd_kernel, dim3(4, B), dim3(256), lds, ST(stream), dh, dc, act, c, c_raw, c_prev, g_ih,
+  const int nt = norm_cell_threads(B, g);
+  const size_t lds = aff ? (size_t)14 * nt * 16 : 0;  // (57 / 115 KB: the one meeting of the per-thread affine sums)
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(norm_lstm_cell_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 14 * 512 * 16);
+    RAC_REQUIRE(e == hipSuccess, "rac_norm_lstm_cell_bwd: %s", hipGetErrorString(e));
+    attr = true;
+  }
+  hipLaunchKernelGGL(norm_lstm_cell_bwd_kernel, dim3(4, B), dim3(nt), lds, ST(stream), dh, dc, act, c, c_raw, c_prev, g_ih,
                      g_hh, stat_ih, stat_hh, stat_c, gamma_ih, gamma_hh, gamma_c, dg_ih, dg_hh, dc_prev, dgamma_ih, dbeta_ih,
                      dgamma_hh, dbeta_hh, dgamma_c, dbeta_c, dg_ih_amax, dg_hh_amax, HW, g);
   return check_launch("rac_norm_lstm_cell_bwd");

@@ -5,7 +5,7 @@ tag=$1; w=$2; shift 2
 out=gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done
-rocprofv3 --kernel-trace --stats -d $out -o run --output-format csv -- python3 bench.py --workload $w --steps 5 --warmup 2 --cem-iters 1 --cem-warmup 1 --no-cpu-baseline --no-exact --no-side --no-cem-ra --cem-opt-iter 1 > $out/bench.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats -d $out -o run --output-format csv -- python3 bench.py --workload $w --steps 5 --warmup 2 --cem-iters 1 --cem-warmup 1 --no-cpu-baseline --no-exact --no-side --no-cem-ra --cem-opt-iter 1 $BENCH_FLAGS > $out/bench.json 2> $out/bench.err
 f=$(find $out -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
