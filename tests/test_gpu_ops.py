@@ -620,7 +620,9 @@ def test_per_image_scales_make_a_conv_batch_invariant(dev, B, H, W, C0, C1, Cout
 def test_weight_parts_refreshed_in_one_launch(dev):
     """After an optimiser step (ops.PARAM_EPOCH) every registered weight is refreshed by one rac_absmax_multi + one
     rac_weight_frag_split_multi launch: same parts and maxima as the single-tensor calls."""
+    import gc
     from robot_aware_control_amd import ops
+    gc.collect()  # (models of earlier tests that only a reference cycle keeps alive: their weights are registered too)
     shapes = [(64, 96, 3, True), (128, 64, 5, False), (32, 64, 3, True), (256, 512, 5, True), (96, 32, 3, False)]
     ws = [cl_weight(rnd(30 + i, co, ci, k, k) * 0.02).to(dev) for i, (co, ci, k, _) in enumerate(shapes)]
     for w, (_, _, _, both) in zip(ws, shapes):  # registration: the single-tensor path
@@ -638,7 +640,8 @@ def test_weight_parts_refreshed_in_one_launch(dev):
                for w, (_, _, _, both) in zip(ws, shapes)]
     finally:
         ops.call = real
-    assert calls == ["rac_absmax_multi", "rac_weight_frag_split_multi"], calls
+    # (zero-padded copies of other live models' weights, if any, are rebuilt first: not what this test counts)
+    assert [c for c in calls if c != "rac_pad_rows"] == ["rac_absmax_multi", "rac_weight_frag_split_multi"], calls
     for w, ((parts, slot), tr) in zip(ws, got):
         h1, h2, _ = split_f16x2(w.cpu())
         assert int(slot.cpu()) == int(w.abs().max().cpu().view(torch.int32))
