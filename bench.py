@@ -216,6 +216,7 @@ def pmc_tail(workload):
     out = {r["kernel"]: {"bytes": r["hbm_side_bytes_per_launch"], "avg_ms": r["avg_us"] / 1e3, "gbps": r["gbps"],
                          "frac_of_8TBps": r["frac_of_8TBps"]} for r in rows}
     out["source"] = os.path.relpath(files[-1], ROOT)
+    out["note"] = "from the committed profile of this build's kernels (PMC passes + kernel trace), not measured by this run"
     return out
 
 

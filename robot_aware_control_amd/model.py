@@ -197,8 +197,11 @@ class _NormLstmCell(nn.Module):
         if frozen and x.is_cuda and ops.norm_cell_frozen_ok(x.shape[3]):
             # no tape: everything behind the two gate convs is one launch (rac_norm_lstm_cell_fwd)
             n_ih, n_hh, n_c = self.ih_gates[1], self.hh_gates[1], self.c_norm
-            h, c = ops.norm_cell_frozen(ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, True),
-                                        ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, True), c_prev,
+            if ops.is_zero(h_prev):  # a rollout's first step: the conv of an all-zero map is its bias, to the bit
+                g_hh = ch.bias.detach().view(1, 1, 1, -1).expand(tuple(x.shape[:3]) + (ch.bias.numel(),)).contiguous()
+            else:
+                g_hh = ops.ConvBias.apply(h_prev, None, ch.weight, ch.bias, ACT_NONE, True)
+            h, c = ops.norm_cell_frozen(ops.ConvBias.apply(x, None, ci.weight, ci.bias, ACT_NONE, True), g_hh, c_prev,
                                         (n_ih.weight, n_ih.bias), (n_hh.weight, n_hh.bias), (n_c.weight, n_c.bias))
             return ops.tag_amax(h, ops.amax_one(h.device, h.shape[0])), c  # |h| = |o * tanh(c)| < 1
         if not frozen and ops.norm_cell_node_ok(x, ci.weight, ch.weight):

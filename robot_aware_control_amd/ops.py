@@ -2557,7 +2557,10 @@ class NormLstmCell(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, h_prev, c_prev, w_ih, b_ih, gam_ih, bet_ih, w_hh, b_hh, gam_hh, bet_hh, gam_c, bet_c):
         g_ih = conv_forward_split(x, None, w_ih, b_ih)
-        g_hh = conv_forward_split(h_prev, None, w_hh, b_hh)
+        if is_zero(h_prev):  # a window's first step: the conv of the all-zero state is its bias, to the bit
+            g_hh = b_hh.detach().view(1, 1, 1, -1).expand(tuple(x.shape[:3]) + (b_hh.numel(),)).contiguous()
+        else:
+            g_hh = conv_forward_split(h_prev, None, w_hh, b_hh)
         h, c, act, c_raw, stats, g_ih, g_hh, c_prev_c = _norm_cell_launch(g_ih, g_hh, c_prev, (gam_ih, bet_ih), (gam_hh, bet_hh),
                                                                            (gam_c, bet_c), True)
         ctx.save_for_backward(x, h_prev, c_prev_c, w_ih, b_ih, gam_ih, bet_ih, w_hh, b_hh, gam_hh, bet_hh, gam_c, bet_c,

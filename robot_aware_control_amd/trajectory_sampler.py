@@ -25,6 +25,9 @@ from .losses import RobotWorldCost
 from .state import DemoGoalState, State
 
 
+CEM_STREAMS = int(os.environ.get("RAC_CEM_STREAMS", "1"))  # parts of a candidate pass on their own streams (cfg.cem_streams)
+
+
 def shard_bounds(n: int, world: int, rank: int):
     """Contiguous, near-equal candidate slices; the tail ranks get the remainder-free part."""
     base, rem = divmod(n, world)
@@ -59,6 +62,7 @@ class TrajectorySampler(object):
         self.high = torch.tensor([[0.55, 0.3, 0.4, 1, 1]], dtype=torch.float32)
         self.robot_model = robot_model
         self._refining = False  # inside the exact re-roll of the elites (no sharding, no nested refinement)
+        self._streams = []      # extra HIP streams of a pass cut into `cem_streams` parts (generate_model_rollouts)
         self._robot_ctor = (cam_ext, franka_ik, wx250s_bot, push_height, default_pitch, default_roll)
         if os.environ.get("RAC_GC_FREEZE", "0") == "1":  # opt-in, see PredictionTrainer.__init__
             import gc
@@ -205,44 +209,90 @@ class TrajectorySampler(object):
                    and not getattr(cfg, "model_use_heatmap", False)
                    and (shared_mask0 or not (cfg.model_use_mask or dontcare_in)))
 
+        # Candidates are independent and the frozen model's arithmetic does not depend on the batch (one operand scale per
+        # image, K never split: DESIGN 3.1), so a pass may be cut into `cem_streams` parts that run on their own HIP streams
+        # in lock-step -- the same bits, with one part's memory-bound kernels (first layer, output head, step tail) and launch
+        # tails under the other's matrix-pipe kernels.  The first call of a sampler runs in one stream (it builds the cached
+        # weight operands every stream reads afterwards).
+        n_streams = int(getattr(cfg, "cem_streams", CEM_STREAMS))
+        if (n_streams < 2 or ret_obs or ret_step_cost or not getattr(self, "_warm", False)
+                or 64 * (T + 1) * max(per, 1) > ops._AMAX_SLOTS):
+            n_streams = 1
+        self._warm = True
+        main = torch.cuda.current_stream()
+        side = []
+        if n_streams > 1:
+            ops._amax_reserve(dev, 64 * (T + 1) * min(per, max(n_local, 1)))  # (no fresh arena inside the forked region)
+            if len(self._streams) < n_streams - 1:
+                self._streams += [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1 - len(self._streams))]
+            side = self._streams[:n_streams - 1]
+        lstms = (model.frame_predictor, model.posterior, model.prior)
+
         for b in range(nb if n_local > 0 else 0):
             s = lo + b * per
             e = lo + (b + 1) * per if b < nb - 1 else hi
-            n = e - s
-            ls, le = s - lo, e - lo  # shard-local rows of states / masks / sum_cost_dev
-            model.init_hidden(batch_size=n)
-            curr = start_img.expand(n, -1, -1, -1).contiguous()
-            if dontcare_in:
-                curr = ops.ZeroRegion.apply(curr, masks[0, ls:le].contiguous())
+            parts = []
+            k_parts = n_streams if (e - s) >= 32 * n_streams else 1
+            for k in range(k_parts):
+                ps, pe = s + (e - s) * k // k_parts, s + (e - s) * (k + 1) // k_parts
+                model.init_hidden(batch_size=pe - ps)  # (zero states: made on the main stream, before the fork)
+                curr = start_img.expand(pe - ps, -1, -1, -1).contiguous()
+                if dontcare_in:
+                    curr = ops.ZeroRegion.apply(curr, masks[0, ps - lo:pe - lo].contiguous())
+                # (`first`: what the main stream allocated for a part that runs elsewhere stays referenced until the join --
+                # the caching allocator hands a freed block back to its OWN stream at once)
+                parts.append({"s": ps, "e": pe, "curr": curr, "hidden": [m.hidden for m in lstms],
+                              "stream": main if k == 0 else side[k - 1], "first": (curr, [m.hidden for m in lstms])})
+            if k_parts > 1:
+                fork = torch.cuda.Event()
+                fork.record(main)
+                for part in parts[1:]:
+                    part["stream"].wait_event(fork)
             for t in range(T):
-                ac = actions_dev[s:e, t].contiguous()
-                mask = masks[t, ls:le] if cfg.model_use_mask else None
-                state = states[t, ls:le] if cfg.model_use_robot_state else None
-                if cfg.model_use_future_mask:
-                    mask = torch.cat([mask, masks[t + 1, ls:le]], 1)
-                if cfg.model_use_future_robot_state:
-                    state = (state, states[t + 1, ls:le])
-                shared = t == 0 and shared0
-                x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean,
-                                        shared_frame=shared)[0]
-                gi = t if t < len(goal_imgs) else -1
-                add = (not cfg.sparse_cost) or t == T - 1
-                nxt = torch.empty_like(curr)
-                before = sum_cost_dev[ls:le].clone() if ret_step_cost else None
-                # locals: the (possibly copied) operands must outlive the raw-pointer launch
-                next_mask = masks[t + 1, ls:le].contiguous() if (dontcare_in or dontcare_cost) else None
-                goal_mask = goal_masks[gi].contiguous() if (dontcare_cost and goal_masks is not None) else None
-                goal_img = goal_imgs[gi].contiguous()
-                _lib.call(
-                    "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(), _lib.ptr(next_mask) if dontcare_in else None,
-                    goal_img.data_ptr(), _lib.ptr(next_mask) if dontcare_cost else None, _lib.ptr(goal_mask),
-                    kind, w_world, 1 if (add and w_world != 0) else 0, nxt.data_ptr(),
-                    sum_cost_dev[ls:le].data_ptr(), n, H * W, _lib.stream_ptr())
-                if ret_obs:
-                    all_obs[s:e, t] = nxt.cpu()
-                if ret_step_cost:
-                    step_cost[s:e, t] = (sum_cost_dev[ls:le] - before).cpu().numpy()
-                curr = nxt
+                for part in parts:
+                    with torch.cuda.stream(part["stream"]):
+                        s_, e_ = part["s"], part["e"]
+                        n = e_ - s_
+                        ls, le = s_ - lo, e_ - lo  # shard-local rows of states / masks / sum_cost_dev
+                        for m, hid in zip(lstms, part["hidden"]):
+                            m.hidden = hid
+                        curr = part["curr"]
+                        ac = actions_dev[s_:e_, t].contiguous()
+                        mask = masks[t, ls:le] if cfg.model_use_mask else None
+                        state = states[t, ls:le] if cfg.model_use_robot_state else None
+                        if cfg.model_use_future_mask:
+                            mask = torch.cat([mask, masks[t + 1, ls:le]], 1)
+                        if cfg.model_use_future_robot_state:
+                            state = (state, states[t + 1, ls:le])
+                        shared = t == 0 and shared0
+                        x4 = model.forward_maps(curr, mask, state, None, ac, False, sample_mean=cfg.sample_mean,
+                                                shared_frame=shared)[0]
+                        gi = t if t < len(goal_imgs) else -1
+                        add = (not cfg.sparse_cost) or t == T - 1
+                        nxt = torch.empty_like(curr)
+                        before = sum_cost_dev[ls:le].clone() if ret_step_cost else None
+                        # locals: the (possibly copied) operands must outlive the raw-pointer launch
+                        next_mask = masks[t + 1, ls:le].contiguous() if (dontcare_in or dontcare_cost) else None
+                        goal_mask = goal_masks[gi].contiguous() if (dontcare_cost and goal_masks is not None) else None
+                        goal_img = goal_imgs[gi].contiguous()
+                        _lib.call(
+                            "rac_cem_step_tail", x4.data_ptr(), curr.data_ptr(), _lib.ptr(next_mask) if dontcare_in else None,
+                            goal_img.data_ptr(), _lib.ptr(next_mask) if dontcare_cost else None, _lib.ptr(goal_mask),
+                            kind, w_world, 1 if (add and w_world != 0) else 0, nxt.data_ptr(),
+                            sum_cost_dev[ls:le].data_ptr(), n, H * W, _lib.stream_ptr())
+                        if ret_obs:
+                            all_obs[s_:e_, t] = nxt.cpu()
+                        if ret_step_cost:
+                            step_cost[s_:e_, t] = (sum_cost_dev[ls:le] - before).cpu().numpy()
+                        part["curr"] = nxt
+                        part["hidden"] = [m.hidden for m in lstms]
+                        part["keep"] = (x4, curr, next_mask, goal_mask, goal_img, ac, mask, state)
+            if k_parts > 1:  # join: the main stream goes on only behind every part (and the parts' tensors live until then)
+                for part in parts[1:]:
+                    done = torch.cuda.Event()
+                    done.record(part["stream"])
+                    main.wait_event(done)
+            parts = None
 
         # ---- gather the per-candidate costs: the only collective of a CEM iteration ----
         if getattr(self, "time_gather", False):  # bench.py: time the collective alone (drain the rollouts first)

@@ -325,3 +325,35 @@ def test_cem_elite_indices_cfg3_full_size(dev, ra):
     # and through the policy's own selection (cem.py:96-97): torch.topk over the full cost vector
     import torch as _t
     assert list(_t.from_numpy(got).topk(K)[1].numpy()) == list(order[:K])
+
+
+@pytest.mark.parametrize("ra", [False, True])
+def test_cem_pass_in_stream_parts_is_the_same_bits(dev, ra):
+    """`cfg.cem_streams = 2 / 3`: a candidate pass cut into parts that run on their own HIP streams in lock-step (one part's
+    memory-bound kernels under the other's matrix-pipe kernels) gives the SAME BITS as the one-stream pass -- candidates are
+    independent and the frozen model's arithmetic does not depend on the batch.  g 512 / z 64, 1000 candidates, 4 steps; also
+    a ragged split (batches of 437) and a second call on the same sampler (stream reuse)."""
+    from robot_aware_control_amd.state import DemoGoalState, State
+    from robot_aware_control_amd.trajectory_sampler import TrajectorySampler
+    flags = FLAGSETS["ra"] if ra else FLAGSETS["vanilla"]
+    N, T = 1000, 4
+    cfg = orc.Cfg(g_dim=512, z_dim=64, batch_size=2, candidates_batch_size=N, sample_mean=True,
+                  reward_type="dontcare" if ra else "dense", topk=5, **flags)
+    sd = orc.make_weights(cfg, seed=9, action_gain=200.0)
+    prob = syn.synth_cem_problem(seed=6, N=N, T=T, with_robot=ra, goal_blend=0.15)
+    model = build_model(cfg, sd, dev)
+    start = State(img=prob["start_img"], state=np.zeros(5, np.float32), qpos=np.zeros(5, np.float32))
+    goal = DemoGoalState(imgs=prob["goal_imgs"], masks=prob["goal_masks"])
+
+    def sampler(streams, per):
+        rm = FakeRobotModel(prob["states"], prob["masks"]) if ra else None
+        return TrajectorySampler(ns_for(cfg, dev, candidates_batch_size=per, cem_streams=streams), model, robot_model=rm)
+    ref = sampler(1, N).generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+    assert np.all(np.isfinite(ref)) and np.unique(ref).size > 900
+    for streams, per in ((2, N), (3, N), (2, 437)):
+        smp = sampler(streams, per)
+        smp.generate_model_rollouts(prob["actions"][:64].clone(), start, goal)  # (a sampler's first call: one stream)
+        for rep in range(2):
+            got = smp.generate_model_rollouts(prob["actions"].clone(), start, goal)["sum_cost"]
+            assert np.array_equal(got, ref), (streams, per, rep, float(np.abs(got - ref).max()))
+        assert len(smp._streams) == streams - 1

@@ -31,12 +31,13 @@ def short(name):
 
 # the HBM-bound tail of both workloads (bench.py's roofline.tail): bytes from the PMC passes, durations from the kernel stats
 TAIL = {"train": ("adam_frag_multi_kernel", "adam_ranges_kernel", "bn_bwd_reduce_rows_kernel", "bn_bwd_apply_rows_kernel",
-                  "affine_act_kernel4", "slab_reduce_stats_rows_kernel", "lstm_cell_bwd_srcs_kernel", "lstm_cell_fwd_kernel",
+                  "bn_apply_act_rows_kernel", "slab_reduce_stats_rows_kernel", "lstm_cell_bwd_srcs_kernel", "lstm_cell_fwd_kernel",
                   "head_dgrad_kernel"),
         "cem": ("first16_kernel", "head16_kernel", "cem_step_tail_kernel")}
 
 
-def counters(d, kernels=KERNELS):
+def counters(d, kernels=KERNELS, with_counts=False):
+    """{(kernel, workgroups): {counter: mean over that shape's launches}}; `with_counts`: also {"_n": launches of the shape}."""
     agg = defaultdict(lambda: defaultdict(list))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -44,7 +45,11 @@ def counters(d, kernels=KERNELS):
             if k.startswith(kernels):
                 wg = int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"]))
                 agg[(k, wg)][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in agg.items()}
+    if with_counts:
+        for k, cs in agg.items():
+            out[k]["_n"] = max(len(v) for v in cs.values())
+    return out
 
 
 def main(src, tag):
@@ -85,15 +90,17 @@ def main(src, tag):
         if os.path.exists(stats):
             for r in csv.DictReader(open(stats)):
                 dur[short(r["Name"])] = (float(r["AverageNs"]), int(r["Calls"]))
-        f = counters(os.path.join(src, f"pmc_FETCH_SIZE_{wl}"), names)
+        f = counters(os.path.join(src, f"pmc_FETCH_SIZE_{wl}"), names, with_counts=True)
         w = counters(os.path.join(src, f"pmc_WRITE_SIZE_{wl}"), names)
         for name in names:
             fk = [(k, c) for k, c in f.items() if k[0].startswith(name)]
             if not fk:
                 continue
-            # launches of different grid sizes: average over the launches (the counters() entries are per (kernel, grid) means)
-            fetch = sum(c.get("FETCH_SIZE", 0.0) for _, c in fk) / len(fk)
-            write = sum(w.get(k, {}).get("WRITE_SIZE", 0.0) for k, _ in fk) / len(fk)
+            # a kernel name launched at several grid sizes: the mean over its LAUNCHES -- every shape's mean weighted by its
+            # launch count -- which is what the kernel-stats average duration below is the mean over
+            n_all = sum(c["_n"] for _, c in fk)
+            fetch = sum(c.get("FETCH_SIZE", 0.0) * c["_n"] for _, c in fk) / n_all
+            write = sum(w.get(k, {}).get("WRITE_SIZE", 0.0) * c["_n"] for k, c in fk) / n_all
             d = next((v for k, v in dur.items() if k.startswith(name)), None)
             if d is None:
                 continue
