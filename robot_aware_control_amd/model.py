@@ -559,11 +559,14 @@ class SVGConvModel(nn.Module):
         return x4, mus, logvars, mu_ps, logvar_ps
 
     def _recurrent_core(self, T, B, h_all, prior_all, post_all, robots, actions):
-        """The T-step recurrence as ONE hand-scheduled autograd node (ops.RecurrentCore) where its kernels apply; None
-        otherwise (GroupNorm cells, narrow models, frozen parameters: the per-step autograd path below)."""
+        """The T-step recurrence as ONE hand-scheduled autograd node (ops.RecurrentCore; ops.NormRecurrentCore for
+        `--lstm_group_norm True`) where its kernels apply; None otherwise (narrow models, frozen parameters: the per-step
+        autograd path below)."""
         cf = self._config
         lstms = {"prior": self.prior, "post": self.posterior, "fp": self.frame_predictor}
-        if any(not isinstance(c, _LstmCell) for m in lstms.values() for c in m.lstm):
+        all_cells = [c for m in lstms.values() for c in m.lstm]
+        norm = all(isinstance(c, _NormLstmCell) for c in all_cells)  # --lstm_group_norm True: ops.NormRecurrentCore
+        if not norm and any(not isinstance(c, _LstmCell) for c in all_cells):
             return None
         g, z = cf.g_dim, cf.z_dim
         vs = []
@@ -577,8 +580,9 @@ class SVGConvModel(nn.Module):
                 vs.append([a])
         nv = sum(v.shape[1] for v in vs[0])
         head = self.posterior._head
-        cells = [c for m in lstms.values() for c in m.lstm]
-        if not ops.recurrent_core_ok(h_all, g, z, nv, cells, head, self.frame_pred_input_conv):
+        cells = all_cells
+        ok = ops.norm_recurrent_core_ok if norm else ops.recurrent_core_ok
+        if not ok(h_all, g, z, nv, cells, head, self.frame_pred_input_conv):
             return None
         for t in head:  # the merged views follow the parameters they alias
             if t.requires_grad != self.posterior.mu_net.weight.requires_grad:
@@ -586,8 +590,13 @@ class SVGConvModel(nn.Module):
         plan = dict(T=T, B=B, g=g, z=z, nv=nv, vs=vs, cells={k: tuple(m.lstm) for k, m in lstms.items()}, head=head,
                     frame_conv=self.frame_pred_input_conv, init_state={k: m.hidden for k, m in lstms.items()},
                     eps_fn=self._eps, draw_prior_noise=True)
-        params = [c.gates.weight for c in cells] + [head[0], self.frame_pred_input_conv.weight]
-        out = ops.RecurrentCore.apply(plan, h_all, prior_all, post_all, *params)
+        if norm:
+            params = ([c.ih_gates[0].weight for c in cells] + [c.hh_gates[0].weight for c in cells]
+                      + [head[0], self.frame_pred_input_conv.weight])
+            out = ops.NormRecurrentCore.apply(plan, h_all, prior_all, post_all, *params)
+        else:
+            params = [c.gates.weight for c in cells] + [head[0], self.frame_pred_input_conv.weight]
+            out = ops.RecurrentCore.apply(plan, h_all, prior_all, post_all, *params)
         for k, m in lstms.items():
             m.hidden = plan["final_state"][k]
         return out

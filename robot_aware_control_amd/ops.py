@@ -2513,14 +2513,14 @@ def norm_cell_frozen(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c):
     return _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, False)[:2]
 
 
-def _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, training):
+def _norm_cell_launch(g_ih, g_hh, c_prev, gn_ih, gn_hh, gn_c, training, h_out=None):
     B, H, W, g4 = g_ih.shape
     g = g4 // 4
     g_ih = g_ih if g_ih.is_contiguous() else g_ih.contiguous()
     g_hh = g_hh if g_hh.is_contiguous() else g_hh.contiguous()
     c_prev = c_prev if c_prev.is_contiguous() else c_prev.contiguous()
     dev = g_ih.device
-    h = torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
+    h = h_out if h_out is not None else torch.empty((B, H, W, g), device=dev, dtype=torch.float32)
     c = torch.empty_like(h)
     act = c_raw = stats = None
     if training:
@@ -2626,6 +2626,244 @@ class NormLstmCell(torch.autograd.Function):
                 conv_wgrad_split_acc(dg_hh, h_prev, None, w_hh, defer=True)
             bias_grad_acc(dg_hh, b_hh)
         return (dx, dh_prev, dc_prev) + (None,) * 10
+
+
+# --------------------------------------------------------------------------- #
+# the recurrent core for NormConvLSTMCell models (--lstm_group_norm True)
+# --------------------------------------------------------------------------- #
+# The same idea as RecurrentCore -- the T-step recurrence of a teacher-forced window as ONE autograd node, layer-major,
+# gradient maps handed over as sources -- for the cell of the deployed checkpoints (lstm.py:151-198).  Its two gate convs
+# are separate (each is normalised on its own), and only conv_hh reads the recurrence: in layer-major order the INPUT half
+# of a layer's gate convs runs ONCE over all T steps (M = T B H W rows instead of T launches of B H W: 3 840 instead of 768
+# at the deployed model's size, where the per-step GEMMs ran at 0.12-0.31 of the pipe), and so do its data gradient and its
+# weight gradient (one record of the batched operands).  Per step: conv_hh, rac_norm_lstm_cell_fwd / _bwd, conv_hh's data
+# gradient.
+NORM_RECURRENT_CORE = os.environ.get("RAC_NORM_RECURRENT_CORE", "1") == "1"
+
+
+def norm_recurrent_core_ok(h_all, g: int, z: int, nv: int, cells, head, frame_conv) -> bool:
+    if not (NORM_RECURRENT_CORE and RECURRENT_CORE and SPLIT_GEMM and h_all.is_cuda and torch.is_grad_enabled()):
+        return False
+    _, H, W, gg = h_all.shape
+    if gg != g or g % 32 or z % 4 or head is None or not gauss_head_ok((1, H, W, g), head[0]):
+        return False
+    ct = nv + g + z
+    cpad = ct + (-ct) % 32
+    if not (ct >= 128 and split_supported(H, W, 3, cpad, 128, 0)):
+        return False
+    if not split_supported(H, W, frame_conv.weight.shape[2], cpad, frame_conv.weight.shape[0], 0):
+        return False
+    x_like = h_all[:1]
+    for cell in cells:
+        ci, ch = cell.ih_gates[0], cell.hh_gates[0]
+        if not norm_cell_node_ok(x_like, ci.weight, ch.weight) or not NORM_CELL_BWD_FUSED:
+            return False
+        if not all(p.requires_grad for p in cell.parameters()):
+            return False
+    return frame_conv.weight.requires_grad and head[0].requires_grad
+
+
+def _plain_map(src, g):
+    """The tensor behind a gradient source that is one plain [M][g] map (no slabs, no column window), else None."""
+    t, n, _, row, col = src
+    return t if (n == 1 and row == g and col == 0 and t.is_contiguous()) else None
+
+
+class NormRecurrentCore(torch.autograd.Function):
+    """h_pred (T*B), mu, logvar (posterior, T*B), h_prior (T*B) = the T-step recurrence over the encoder's latents for a
+    model of NormConvLSTMCells (same contract as RecurrentCore; parameter gradients accumulate in place)."""
+
+    @staticmethod
+    def forward(ctx, plan, h_all, prior_all, post_all, *params):
+        T, B, g, z = plan["T"], plan["B"], plan["g"], plan["z"]
+        dev = h_all.device
+        _, H, W, _ = h_all.shape
+        M = B * H * W
+        step = lambda t_: t_.view((T, B) + tuple(t_.shape[1:]))
+        one = amax_one(dev)
+        cells = plan["cells"]
+        head_w, head_b = plan["head"]
+        fconv = plan["frame_conv"]
+        nv = plan["nv"]
+        ct = nv + g + z
+        pad = (-ct) % 32
+        param_wait()
+        fw_pad = padded_weight(fconv.weight, ct + pad)
+        mu_all = torch.empty((T * B, H, W, z), device=dev, dtype=torch.float32)
+        lv_all = torch.empty_like(mu_all)
+        eps_all = []
+        for t in range(T):  # the noise of every step in the reference's order (the prior's draw, dropped, first)
+            if plan["draw_prior_noise"]:
+                plan["eps_fn"](step(mu_all)[t])
+            eps_all.append(plan["eps_fn"](step(mu_all)[t]))
+        for L in ("prior", "post", "fp"):
+            for cell in cells[L]:
+                weight_parts(cell.ih_gates[0].weight), weight_parts(cell.hh_gates[0].weight)
+        weight_parts(head_w), weight_parts(fw_pad)
+        state = {L: list(plan["init_state"][L]) for L in ("prior", "post", "fp")}
+        tape = {}
+
+        def run_layer(L, l, x_all):
+            """All T steps of one layer: the input half of its gate convs once over the window, then step by step."""
+            cell = cells[L][l]
+            ci, ch = cell.ih_gates[0], cell.hh_gates[0]
+            gn = [(m.weight, m.bias) for m in (cell.ih_gates[1], cell.hh_gates[1], cell.c_norm)]
+            g_ih_all = conv_forward_split(x_all, None, ci.weight, ci.bias)
+            h_all_l = torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32)
+            h_s, gi_s = step(h_all_l), step(g_ih_all)
+            h_prev, c_prev = state[L][l]
+            recs = []
+            for t in range(T):
+                if is_zero(h_prev):  # the conv of the all-zero initial state is its bias, to the bit
+                    g_hh = ch.bias.detach().view(1, 1, 1, -1).expand(B, H, W, 4 * g).contiguous()
+                else:
+                    g_hh = conv_forward_split(h_prev, None, ch.weight, ch.bias)
+                h, c, act, c_raw, stats, _, g_hh, c_prev_c = _norm_cell_launch(gi_s[t], g_hh, c_prev, gn[0], gn[1], gn[2], True,
+                                                                               h_out=h_s[t])
+                tag_amax(h, one)  # |h| = |o * tanh(c)| < 1
+                recs.append({"h_prev": h_prev, "c_prev": c_prev_c, "g_hh": g_hh, "act": act, "c_raw": c_raw, "c": c,
+                             "stats": stats})
+                h_prev, c_prev = h, c
+            state[L][l] = (h_prev, c_prev)
+            tape[(L, l)] = {"x_all": x_all, "g_ih_all": g_ih_all, "h_all": h_all_l, "steps": recs}
+            return tag_amax(h_all_l, one)
+
+        h_prior_all = run_layer("prior", 1, run_layer("prior", 0, prior_all))
+        h_post_all = run_layer("post", 1, run_layer("post", 0, post_all))
+        # posterior head + reparameterisation, then the frame predictor's input conv, once over all steps
+        sp = stream_ptr()
+        slabs, split, stride = conv_forward_split(h_post_all, None, head_w, want_slabs=True)
+        call("rac_slab_reduce2", ptr(slabs), split, stride, ptr(head_b), ptr(mu_all), ptr(lv_all), T * M, 2 * z, z, None, None, sp)
+        eps_stack = torch.stack(eps_all)
+        zs = torch.empty_like(mu_all)
+        call("rac_reparam_fwd", ptr(mu_all), ptr(lv_all), ptr(eps_stack), ptr(zs), zs.numel(), sp)
+        vs = plan["vs"]
+        v3 = [torch.cat([vs[t][k] for t in range(T)]) if k < len(vs[0]) else None for k in range(3)]
+        cat = torch.empty((T * B, H, W, ct + pad), device=dev, dtype=torch.float32)
+        slot = amax_slot(dev)
+        call("rac_tilecat_fwd", ptr(v3[0]), v3[0].shape[1] if v3[0] is not None else 0, ptr(v3[1]),
+             v3[1].shape[1] if v3[1] is not None else 0, ptr(v3[2]), v3[2].shape[1] if v3[2] is not None else 0,
+             ptr(h_all), g, ptr(zs), z, pad, ptr(cat), T * B, H * W, ptr(slot), 0, sp)
+        tag_amax(cat, slot)
+        xf_all = conv_forward_split(cat, None, fw_pad, fconv.bias)
+        h_pred_all = run_layer("fp", 1, run_layer("fp", 0, xf_all))
+        ctx.plan = {k: plan[k] for k in ("g", "z", "nv", "cells", "head", "frame_conv")}
+        ctx.tape = tape
+        ctx.thin = {"h_post": h_post_all, "eps": eps_stack, "cat": cat}
+        ctx.lv_all = lv_all
+        ctx.shape = (T, B, H, W)
+        plan["final_state"] = state
+        return h_pred_all, mu_all, lv_all, h_prior_all
+
+    @staticmethod
+    def backward(ctx, d_hpred, d_mu, d_lv, d_hprior):
+        plan, tape, thin = ctx.plan, ctx.tape, ctx.thin
+        T, B, H, W = ctx.shape
+        g, z, nv = plan["g"], plan["z"], plan["nv"]
+        M, HW = B * H * W, H * W
+        dev = ctx.lv_all.device
+        cells, fconv = plan["cells"], plan["frame_conv"]
+        head_w, head_b = plan["head"]
+        ct = nv + g + z
+        cpad = ct + (-ct) % 32
+        fw_pad = padded_weight(fconv.weight, cpad)
+        cont = lambda t_: None if t_ is None else t_.contiguous()
+        d_hpred, d_mu, d_lv, d_hprior = cont(d_hpred), cont(d_mu), cont(d_lv), cont(d_hprior)
+        for L in ("prior", "post", "fp"):
+            for cell in cells[L]:
+                weight_parts(cell.ih_gates[0].weight, transposed=True), weight_parts(cell.hh_gates[0].weight, transposed=True)
+        weight_parts(head_w, transposed=True), weight_parts(fw_pad, transposed=True)
+        sp = stream_ptr()
+
+        def window(slabs, n, cin, t, col=0):  # rows of step t of batched slabs [n][T M][cin] as a gradient source
+            rows = slabs.view(n, T, M, cin)[0, t]
+            return (rows, n, slabs.numel() // n if n > 1 else 0, cin, col)
+
+        def layer_bwd(L, l, ext):
+            """Backward of all T steps of one layer; `ext(t)` = the sources of dh[t] from outside the layer's own recurrence.
+            Returns the batched slabs of the gradient w.r.t. the layer's input (n_slabs given) for whoever produced it."""
+            cell = cells[L][l]
+            ci, ch = cell.ih_gates[0], cell.hh_gates[0]
+            n_ih, n_hh, n_c = cell.ih_gates[1], cell.hh_gates[1], cell.c_norm
+            rec = tape[(L, l)]
+            dg_ih_all = torch.empty_like(rec["g_ih_all"])
+            dgi_s, gi_s = dg_ih_all.view((T, B) + tuple(dg_ih_all.shape[1:])), rec["g_ih_all"].view((T, B) + tuple(dg_ih_all.shape[1:]))
+            slot_ih = amax_slot(dev)  # (every step folds its maximum in: the batched tensor's)
+            want = n_ih.weight.requires_grad
+            gb = lambda p_: ptr(grad_buffer(p_)) if want else None
+            dc_next, dh_src = None, None
+            for t in range(T - 1, -1, -1):
+                r = rec["steps"][t]
+                srcs = list(ext(t)) + ([dh_src] if dh_src is not None else [])
+                dh = None
+                if len(srcs) == 1 and _plain_map(srcs[0], g) is not None:
+                    dh = _plain_map(srcs[0], g)
+                elif srcs:
+                    dh = grad_sum(srcs, torch.empty((B, H, W, g), device=dev, dtype=torch.float32), g)
+                dg_hh = torch.empty_like(r["act"])
+                dc_prev = torch.empty_like(r["c"])
+                slot_hh = amax_slot(dev)
+                st = r["stats"]
+                call("rac_norm_lstm_cell_bwd", ptr(dh), ptr(dc_next), ptr(r["act"]), ptr(r["c"]), ptr(r["c_raw"]),
+                     ptr(r["c_prev"]), ptr(gi_s[t]), ptr(r["g_hh"]), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(n_ih.weight),
+                     ptr(n_hh.weight), ptr(n_c.weight), ptr(dgi_s[t]), ptr(dg_hh), ptr(dc_prev), gb(n_ih.weight), gb(n_ih.bias),
+                     gb(n_hh.weight), gb(n_hh.bias), gb(n_c.weight), gb(n_c.bias), ptr(slot_ih), ptr(slot_hh), B, HW, g, sp)
+                tag_amax(dg_hh, slot_hh)
+                first = is_zero(r["h_prev"])  # nothing flows into the (all-zero, constant) initial state
+                if not first:
+                    slabs, n = conv_dgrad_slabs(dg_hh, ch.weight, g)
+                    dh_src = _src(slabs, n, g, 0)
+                    conv_wgrad_split_acc(dg_hh, r["h_prev"], None, ch.weight, defer=True)
+                else:
+                    dh_src = None
+                bias_grad_acc(dg_hh, ch.bias)
+                dc_next = None if first else dc_prev
+            tag_amax(dg_ih_all, slot_ih)
+            dx_slabs, n_x = conv_dgrad_slabs(dg_ih_all, ci.weight, g)  # the input half's data gradient: once over the window
+            conv_wgrad_split_acc(dg_ih_all, rec["x_all"], None, ci.weight, defer=True)
+            bias_grad_acc(dg_ih_all, ci.bias)
+            return dx_slabs, n_x
+
+        def chain_ws(L, extra):
+            return [c_.ih_gates[0].weight for c_ in cells[L]] + [c_.hh_gates[0].weight for c_ in cells[L]] + extra
+
+        # ---- frame predictor
+        hp_s = None if d_hpred is None else d_hpred.view((T, B) + tuple(d_hpred.shape[1:]))
+        top, n_top = layer_bwd("fp", 1, lambda t: [_src(hp_s[t], 1, g)] if hp_s is not None else [])
+        low, n_low = layer_bwd("fp", 0, lambda t: [window(top, n_top, g, t)])
+        dy_f_all = torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32)
+        slot_f = amax_slot(dev)
+        tag_amax(grad_sum([_src(low, n_low, g, 0)], dy_f_all, g, slot_f), slot_f)
+        dcat, n_c = conv_dgrad_slabs(dy_f_all, fw_pad, cpad)
+        conv_wgrad_split_acc(dy_f_all, thin["cat"], None, fconv.weight, defer=True)  # un-pads into weight.grad
+        bias_grad_acc(dy_f_all, fconv.bias)
+        d_h_all = grad_sum([_src(dcat, n_c, cpad, nv)], torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32), g)
+        flush_deferred_wgrads_early(chain_ws("fp", [fconv.weight]))
+        # ---- posterior: reparameterisation + KL gradients -> merged head -> the two layers
+        dy_h = torch.empty((T * B, H, W, 2 * z), device=dev, dtype=torch.float32)
+        slot = amax_slot(dev)
+        call("rac_reparam_head_bwd", _pack_srcs([_src(dcat, n_c, cpad, nv + g)]), 1, ptr(ctx.lv_all), ptr(thin["eps"]),
+             ptr(d_mu), ptr(d_lv), ptr(dy_h), T * M, z, ptr(slot), sp)
+        tag_amax(dy_h, slot)
+        dhead, n_h = conv_dgrad_slabs(dy_h, head_w, g)
+        conv_wgrad_split_acc(dy_h, tag_amax(thin["h_post"], amax_one(dev)), None, head_w, defer=True)
+        bias_grad_acc(dy_h, head_b)
+        top, n_top = layer_bwd("post", 1, lambda t: [window(dhead, n_h, g, t)])
+        low, n_low = layer_bwd("post", 0, lambda t: [window(top, n_top, g, t)])
+        slot_post = amax_slot(dev)
+        d_post_all = tag_amax(grad_sum([_src(low, n_low, g, 0)], torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32),
+                                       g, slot_post), slot_post)
+        flush_deferred_wgrads_early(chain_ws("post", [head_w]))
+        # ---- prior (its z is not used on this path: only its hidden state feeds the batched mu_p / logvar_p heads)
+        hq_s = None if d_hprior is None else d_hprior.view((T, B) + tuple(d_hprior.shape[1:]))
+        top, n_top = layer_bwd("prior", 1, lambda t: [_src(hq_s[t], 1, g)] if hq_s is not None else [])
+        low, n_low = layer_bwd("prior", 0, lambda t: [window(top, n_top, g, t)])
+        slot_prior = amax_slot(dev)
+        d_prior_all = tag_amax(grad_sum([_src(low, n_low, g, 0)], torch.empty((T * B, H, W, g), device=dev, dtype=torch.float32),
+                                        g, slot_prior), slot_prior)
+        flush_deferred_wgrads_early(None)
+        ctx.tape = ctx.plan = ctx.thin = None
+        return (None, d_h_all, d_prior_all, d_post_all) + (None,) * (len(ctx.needs_input_grad) - 4)
 
 
 class GroupNorm(torch.autograd.Function):

@@ -958,3 +958,30 @@ def test_train_step_is_bit_reproducible(dev):
     for step, ((fa, ga), (fb, gb)) in enumerate(zip(a, b)):
         assert torch.equal(ga, gb), (step, "gradients")
         assert torch.equal(fa, fb), (step, "parameters")
+
+
+def test_norm_recurrent_core_matches_the_autograd_path(dev, monkeypatch):
+    """ops.NormRecurrentCore -- `--lstm_group_norm True` models' recurrence as one hand-scheduled node, layer-major, the input
+    half of every layer's gate convs (and its data / weight gradient) once over the window's steps -- against the per-step
+    autograd path (one ops.NormLstmCell node per cell and step): the same kernels on the same values, other associations of
+    the sums.  Losses to 1e-6, every parameter's gradient to 2e-5 norm-wise; and the core really ran."""
+    from robot_aware_control_amd import ops
+    cfg = orc.Cfg(g_dim=128, z_dim=16, batch_size=4, n_past=1, n_future=4, lr=1e-4, lstm_group_norm=True, **FLAGSETS["ra"])
+    sd = orc.make_weights(cfg, seed=3, randomize_bn_stats=False)
+    data = syn.synth_video(seed=9, T=5, B=4)
+    eps = syn.synth_eps(seed=10, steps=4, B=4, z=16, h=8, w=8)
+    out = {}
+    for core in (True, False):
+        monkeypatch.setattr(ops, "NORM_RECURRENT_CORE", core)
+        tr = make_trainer(cfg, sd, dev)
+        queue = [e for pair in eps for e in pair]
+        tr.model.eps_source = lambda shape: queue.pop(0)
+        tr.optimizer.step = lambda: None
+        losses = tr._train_step(data)
+        assert not queue and tr.model.used_recurrent_core == core
+        out[core] = (losses, {k: p.grad.detach().double().cpu().clone() for k, p in tr.model.named_parameters()})
+    for k, v in out[False][0].items():
+        assert abs(out[True][0][k] - v) <= 1e-6 * abs(v) + 1e-9, k
+    for k, b in out[False][1].items():
+        a = out[True][1][k]
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-5, k
