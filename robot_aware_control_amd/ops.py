@@ -1116,9 +1116,11 @@ def _amax_reserve(device, n: int) -> None:
             _AMAX["used"] = 0
 
 
-def flush_deferred_wgrads_early(weights=None) -> None:
+def flush_deferred_wgrads_early(weights=None, final=True) -> None:
     """Launch the recorded (deferred) weight gradients of `weights` (None: all recorded so far), and the bias column sums
-    recorded so far, NOW on the side stream.  Called where their last operand was produced (RecurrentCore.backward)."""
+    recorded so far, NOW on the side stream.  Called where their last operand was produced (RecurrentCore.backward).
+    `final`: nothing more will be recorded for these weights -- `on_ready` (the data-parallel reduction of a weight's
+    gradient slice) may start behind the launch; a weight that records again afterwards raises."""
     if _DEFERRED is None or not WGRAD_STREAM or (weights is not None and not WGRAD_CHAIN_FLUSH):
         return
     if weights is None:  # everything recorded so far (each record's operands exist: they were produced in program order)
@@ -1141,7 +1143,8 @@ def flush_deferred_wgrads_early(weights=None) -> None:
     with torch.cuda.stream(side):
         for weight, its in sorted(items, key=lambda wi: (-wi[0].numel(), wi[0].data_ptr())):
             _wgrad_split_batch(its, weight)
-            if _SIDE["on_ready"] is not None:
+            if _SIDE["on_ready"] is not None and final:
+                _READY_DONE.add(id(weight))
                 _SIDE["on_ready"](weight)  # (a collective started here orders itself behind the side stream)
         _flush_bias_grads()
         done = torch.cuda.Event()
@@ -1181,6 +1184,7 @@ def wgrad_on_side_stream(launch, operands, need_amax=True) -> None:
 
 _FLUSH_AFTER = None  # deferred_wgrad(flush_after=n | (n1, n2, ..)): a weight's records are launched (side stream) whenever
 _FLUSH_SEEN = {}     # the number of steps recorded for it so far (counted here) reaches one of these
+_READY_DONE = set()  # weights whose gradient slice was handed to `on_ready` (its reduction may be running): no more records
 _VGG_STEPS = False   # ... and the vgg layers' weight gradients are recorded per step too (the encoder / decoder ran per step)
 VGG_WGRAD_BATCH = os.environ.get("RAC_VGG_WGRAD_BATCH", "1") == "1"
 
@@ -1211,6 +1215,7 @@ def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     else:
         _FLUSH_AFTER = None
     _FLUSH_SEEN.clear()
+    _READY_DONE.clear()
     _VGG_STEPS = bool(vgg_steps) and _FLUSH_AFTER is not None and VGG_WGRAD_BATCH
     _SIDE["on_ready"] = on_ready
     try:
@@ -1230,6 +1235,7 @@ def deferred_wgrad(on_ready=None, flush_after=None, vgg_steps=False):
     finally:
         _DEFERRED = None
         _FLUSH_AFTER = None
+        _READY_DONE.clear()
         _VGG_STEPS = False
         _DEFERRED_BIAS.clear()
         if _SIDE["done"] is not None:  # (also on an exception: nothing may outlive the side stream's reads)
@@ -1243,6 +1249,9 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
     """weight.grad += dW on the split-precision pipe.
     `defer`: inside `deferred_wgrad()` only record the operands (the caller must not modify them afterwards)."""
     if defer and _DEFERRED is not None:
+        if id(weight) in _READY_DONE:
+            raise _lib.RacError("a weight gradient was recorded after the weight's data-parallel reduction had started "
+                                "(more steps than deferred_wgrad's flush_after counted on)")
         rec = _DEFERRED.setdefault(id(weight), (weight, []))[1]
         rec.append((dy, x0, x1))
         seen = _FLUSH_SEEN[id(weight)] = _FLUSH_SEEN.get(id(weight), 0) + 1
@@ -1254,7 +1263,8 @@ def conv_wgrad_split_acc(dy, x0, x1, weight, defer=False):
                 for t_ in (dy_, x0_, x1_):
                     if t_ is not None:
                         amax_for(t_)
-            flush_deferred_wgrads_early([weight])
+            # (only the last flush point may start the weight's reduction: earlier ones leave steps to come)
+            flush_deferred_wgrads_early([weight], final=seen == max(_FLUSH_AFTER))
         return
     _wgrad_split_batch([(dy, x0, x1)], weight)
 

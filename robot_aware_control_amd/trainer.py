@@ -26,6 +26,7 @@ from .optim import FusedAdam, ShardedAdam
 
 # teacher-forced windows run the encoder / decoder once over all time steps (RAC_SEQUENCE_PATH=0: step by step)
 SEQUENCE_PATH = os.environ.get("RAC_SEQUENCE_PATH", "1") == "1"
+STEP_HIGH_PRIORITY = os.environ.get("RAC_STEP_HIGH_PRIORITY", "0") == "1"
 
 
 def _dist_on() -> bool:
@@ -266,6 +267,20 @@ class PredictionTrainer(object):
     def _train_step(self, data, use_truth=None):
         """Forward and backward pass + optimiser step (trainer.py:326-465).  Returns the loss dict.
         `use_truth[i]` overrides the scheduled-sampling coin at time index i (parity tests)."""
+        if STEP_HIGH_PRIORITY:
+            # (experiment) the whole step on a HIGH-priority stream: when the side stream's weight-gradient workgroups retire,
+            # the step's own small kernels get the freed slots first
+            if getattr(self, "_hp_stream", None) is None:
+                self._hp_stream = torch.cuda.Stream(device=self._device, priority=-1)
+            cur = torch.cuda.current_stream()
+            self._hp_stream.wait_stream(cur)
+            with torch.cuda.stream(self._hp_stream):
+                out = self._train_step_body(data, use_truth)
+            cur.wait_stream(self._hp_stream)
+            return out
+        return self._train_step_body(data, use_truth)
+
+    def _train_step_body(self, data, use_truth=None):
         cf = self._config
         dev = self._device
         f32 = torch.float32

@@ -153,6 +153,21 @@ def _worker(rank, world, port, q):
         tr._train_step(data)
         got = tr.model.flat_parameters()[1].clone()
         out["ddp_err"] = float((got - mean).norm() / mean.norm())
+        # ... and of a window that feeds its predicted frame back (the per-step path: every weight's time-batched gradient
+        # launch -- and, behind it, the slice's all-reduce -- starts when its last step is recorded)
+        feedback = [True, True, False]
+        trainer_mod._dist_on = lambda: False
+        tr.model.load_state_dict({k: v.clone() for k, v in orc.make_weights(cfg, seed=1, randomize_bn_stats=False).items()})
+        tr._train_step(data, use_truth=feedback)
+        local = tr.model.flat_parameters()[1].clone()
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local)
+        mean = sum(parts) / world
+        trainer_mod._dist_on = real
+        tr.model.load_state_dict({k: v.clone() for k, v in orc.make_weights(cfg, seed=1, randomize_bn_stats=False).items()})
+        tr._train_step(data, use_truth=feedback)
+        got = tr.model.flat_parameters()[1].clone()
+        out["ddp_err_fed_back"] = float((got - mean).norm() / mean.norm())
 
         q.put(out)
         dist.destroy_process_group()
@@ -184,6 +199,7 @@ def test_ranks_sharing_one_gpu(world):
     assert all(r["action"] == res[0]["action"] for r in res)
     # identical inputs exclude slope flips; what is left is the all-reduce's summation order
     assert all(r["ddp_err"] < 1e-5 for r in res), res
+    assert all(r["ddp_err_fed_back"] < 1e-5 for r in res), res
 
 
 def test_bench_two_ranks_rehearsal():
