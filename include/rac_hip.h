@@ -244,6 +244,19 @@ int rac_bn_apply_act(const double* stats, int64_t count, const float* gamma, con
                      float* running_var, float momentum, float eps, int32_t n_updates, const float* x, int32_t act, float* y,
                      float* scale, float* shift, float* mean, float* invstd, int64_t M, int32_t C, int32_t groups,
                      uint32_t* y_amax, void* stream);
+/* Small train-mode layers (ONE statistics group, rac_bn_small_ok(M, C): a few MB -- the 8x8 / 16x16 vgg layers of one time
+ * step): a workgroup owns a slice of channels and all rows, so the per-channel sums need no atomics and no second launch.
+ * rac_bn_small_fwd = split-K combine (raw = sum of the slabs) + batch statistics + running-stat updates + affine +
+ * activation (what rac_slab_reduce_stats + rac_bn_apply_act do, vgg_64.py:8-18 in training mode); rac_bn_small_bwd =
+ * rac_bn_bwd_reduce + rac_bn_bwd_apply.  The same arithmetic per element; the sums in a fixed order. */
+int rac_bn_small_ok(int64_t M, int32_t C);
+int rac_bn_small_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* raw, float* y, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t n_updates,
+                     float* scale, float* shift, float* mean, float* invstd, int64_t M, int32_t C, int32_t act, uint32_t* y_amax,
+                     void* stream);
+int rac_bn_small_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, uint32_t* dx_amax,
+                     void* stream);
 /* sums = fp64 [2][C]: sum dz, sum dz*xhat  with z = x*scale+shift, dz = dy*(z>0?1:0.2), xhat=(x-mean)*invstd.
  * `sums` must be zero on entry. */
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,

@@ -95,6 +95,9 @@ _SIGS = {
     "rac_bn_finalize": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i32, i32, vp],
     "rac_affine_act": [vp, vp, vp, i32, vp, i64, i32, i32, vp, vp],
     "rac_bn_apply_act": [vp, i64, vp, vp, vp, vp, f32, f32, i32, vp, i32, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
+    "rac_bn_small_ok": [i64, i32],
+    "rac_bn_small_fwd": [vp, i32, i64, vp, vp, vp, vp, vp, vp, f32, f32, i32, vp, vp, vp, vp, i64, i32, i32, vp, vp],
+    "rac_bn_small_bwd": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, vp, vp],
     "rac_bn_bwd_reduce": [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp],
     "rac_bn_bwd_apply": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, vp, vp],
     "rac_maxpool2_fwd": [vp, vp, i32, i32, i32, i32, vp],

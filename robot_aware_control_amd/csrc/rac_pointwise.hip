@@ -167,6 +167,136 @@ __global__ __launch_bounds__(256) void bn_apply_act_rows_kernel(const double* st
   if (amax) amax_commit_block(mx, amax);
 }
 
+// ---- small train-mode BatchNorm layers (one statistics group, a few MB: the 8x8 / 16x16 vgg layers of ONE time step) ----
+// The two-launch forms (combine + statistics, then finalize + apply; reduce, then apply) cost 10-22 us per launch on these
+// tensors -- ramp, a cold first touch, the atomics' tail -- whatever the bytes: a window that feeds its frames back runs them
+// 95 times each (profiles/r06_sched_shapes.md).  Here a workgroup owns a SLICE of channels and ALL rows: the per-channel
+// sums never leave it (no atomics, no second launch, a fixed summation order), and the second pass re-reads from the caches
+// what the first one streamed.  grid = C / (4 QS) slices; block = QS channel quads x (256 / QS) row lanes.
+template <int QS>
+__device__ __forceinline__ void slice_totals(f32x4 a1, f32x4 a2, double (&t1)[4], double (&t2)[4], f32x4* sh) {
+  // sum of the 256 / QS row lanes' partials of this thread's quad, in fp64, in lane order; every thread gets the totals
+  const int tid = threadIdx.x, cl = tid & (QS - 1), nrl = 256 / QS;
+  sh[tid] = a1;
+  sh[256 + tid] = a2;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) t1[e] = 0.0, t2[e] = 0.0;
+  for (int r = 0; r < nrl; ++r) {
+    const f32x4 p1 = sh[r * QS + cl], p2 = sh[256 + r * QS + cl];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t1[e] += (double)p1[e], t2[e] += (double)p2[e];
+  }
+  __syncthreads();
+}
+
+template <int QS>
+__global__ __launch_bounds__(256) void bn_small_fwd_kernel(const f32x4* slabs, int n_slabs, long slab_stride4, f32x4* raw,
+                                                           f32x4* y, const float* gamma, const float* beta, float* rmean,
+                                                           float* rvar, float momentum, float eps, int n_updates,
+                                                           float* scale_o, float* shift_o, float* mean_o, float* invstd_o,
+                                                           long M, int C4, int act, unsigned* amax) {
+  __shared__ f32x4 sh[512];
+  const int tid = threadIdx.x, cl = tid & (QS - 1), rl = tid / QS, nrl = 256 / QS;
+  const int c4 = blockIdx.x * QS + cl;
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  for (long r = rl; r < M; r += nrl) {
+    const long i = r * C4 + c4;
+    f32x4 v = slabs[i];
+    for (int sidx = 1; sidx < n_slabs; ++sidx) v += slabs[sidx * slab_stride4 + i];
+    raw[i] = v;
+    a1 += v;
+    a2 += v * v;
+  }
+  double t1[4], t2[4];
+  slice_totals<QS>(a1, a2, t1, t2, sh);
+  f32x4 sc, shf;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {  // (bn_finalize_kernel's arithmetic)
+    const int c = 4 * c4 + e;
+    const double mean = t1[e] / (double)M;
+    double var = t2[e] / (double)M - mean * mean;
+    if (var < 0) var = 0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    sc[e] = gamma[c] * invstd;
+    shf[e] = beta[c] - meanf * sc[e];
+    if (rl == 0) {
+      scale_o[c] = sc[e], shift_o[c] = shf[e], mean_o[c] = meanf, invstd_o[c] = invstd;
+      if (rmean) {
+        const float unbiased = (float)(M > 1 ? var * (double)M / (double)(M - 1) : var);
+        float rm = rmean[c], rv = rvar[c];
+        for (int k = 0; k < n_updates; ++k) {
+          rm = (1.f - momentum) * rm + momentum * meanf;
+          rv = (1.f - momentum) * rv + momentum * unbiased;
+        }
+        rmean[c] = rm, rvar[c] = rv;
+      }
+    }
+  }
+  unsigned mx = 0;
+  for (long r = rl; r < M; r += nrl) {
+    const long i = r * C4 + c4;
+    const f32x4 v = raw[i];  // (this thread wrote it)
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = act_apply(v[e] * sc[e] + shf[e], act);
+      mx = max(mx, absbits(o[e]));
+    }
+    y[i] = o;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
+template <int QS>
+__global__ __launch_bounds__(256) void bn_small_bwd_kernel(const f32x4* dy, const f32x4* x, const f32x4* scale, const f32x4* shift,
+                                                           const f32x4* mean, const f32x4* invstd, f32x4* dx, float* dgamma,
+                                                           float* dbeta, long M, int C4, unsigned* amax) {
+  __shared__ f32x4 sh[512];
+  const int tid = threadIdx.x, cl = tid & (QS - 1), rl = tid / QS, nrl = 256 / QS;
+  const int c4 = blockIdx.x * QS + cl;
+  const f32x4 sc = scale[c4], shf = shift[c4], mu = mean[c4], is = invstd[c4];
+  f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+  for (long r = rl; r < M; r += nrl) {
+    const f32x4 xv = x[r * C4 + c4], dv = dy[r * C4 + c4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = xv[e] * sc[e] + shf[e];
+      const float dz = dv[e] * (z > 0.f ? 1.f : 0.2f);
+      a1[e] += dz;
+      a2[e] += dz * ((xv[e] - mu[e]) * is[e]);
+    }
+  }
+  double t1[4], t2[4];
+  slice_totals<QS>(a1, a2, t1, t2, sh);
+  f32x4 m1, m2;
+  const double invM = 1.0 / (double)M;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    m1[e] = (float)(t1[e] * invM), m2[e] = (float)(t2[e] * invM);
+    if (rl == 0 && dgamma) {  // (one workgroup per channel: plain adds)
+      dgamma[4 * c4 + e] += (float)t2[e];
+      dbeta[4 * c4 + e] += (float)t1[e];
+    }
+  }
+  unsigned mx = 0;
+  for (long r = rl; r < M; r += nrl) {
+    const f32x4 xv = x[r * C4 + c4], dv = dy[r * C4 + c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {  // (bn_bwd_apply_kernel's arithmetic, element by element)
+      const float z = xv[e] * sc[e] + shf[e];
+      const float dz = dv[e] * (z > 0.f ? 1.f : 0.2f);
+      const float xh = (xv[e] - mu[e]) * is[e];
+      o[e] = sc[e] * (dz - m1[e] - xh * m2[e]);
+      mx = max(mx, absbits(o[e]));
+    }
+    dx[r * C4 + c4] = o;
+  }
+  if (amax) amax_commit_block(mx, amax);
+}
+
 // Per-channel reductions over M rows.  grid = (row blocks, 64-channel groups), block = 4 row lanes x 64 channel
 // lanes; partials combined through LDS, then one fp64 atomic per (block, channel).
 // grid.x = G groups x `bpg` row blocks; `Mg` rows per group; sums [G][2][C], scale.. [G][C]
@@ -1083,6 +1213,63 @@ int rac_bn_apply_act(const double* stats, int64_t count, const float* gamma, con
                      running_mean, running_var, momentum, eps, n_updates, (const f32x4*)x, (f32x4*)y, scale, shift, mean,
                      invstd, (long)(M / groups), C / 4, groups, act, rpb, bpg, y_amax);
   return check_launch("rac_bn_apply_act");
+}
+
+// channel quads per slice of the small-layer kernels: as wide as leaves >= 32 workgroups (1, 2 or 4 quads)
+static int small_bn_qs(int C) {
+  const int C4 = C / 4;
+  if (C4 % 4 == 0 && C4 / 4 >= 32) return 4;
+  if (C4 % 2 == 0 && C4 / 2 >= 32) return 2;
+  return 1;
+}
+
+int rac_bn_small_ok(int64_t M, int32_t C) {
+  static const bool off = getenv("RAC_BN_SMALL") && getenv("RAC_BN_SMALL")[0] == '0';
+  static const long max_bytes = [] { const char* e = getenv("RAC_BN_SMALL_BYTES"); return e ? atol(e) : (4L << 20); }();
+  return !off && M > 0 && C >= 32 && C % 4 == 0 && C <= 4096 && (long)M * C * 4 <= max_bytes;
+}
+
+int rac_bn_small_fwd(const float* slabs, int32_t n_slabs, int64_t slab_stride, float* raw, float* y, const float* gamma,
+                     const float* beta, float* running_mean, float* running_var, float momentum, float eps, int32_t n_updates,
+                     float* scale, float* shift, float* mean, float* invstd, int64_t M, int32_t C, int32_t act, uint32_t* y_amax,
+                     void* stream) {
+  RAC_REQUIRE(slabs && raw && y && gamma && beta && scale && shift && mean && invstd && n_slabs >= 1 && M > 0 && C > 0 &&
+                  C % 4 == 0 && slab_stride % 4 == 0 && (running_mean == nullptr) == (running_var == nullptr),
+              "rac_bn_small_fwd: bad args");
+  RAC_REQUIRE(aligned16(slabs) && aligned16(raw) && aligned16(y), "rac_bn_small_fwd: 16-byte aligned maps");
+  const int qs = small_bn_qs(C), C4 = C / 4;
+  const dim3 grid(C4 / qs);
+#define RAC_SMALL_FWD(Q)                                                                                                  \
+  hipLaunchKernelGGL(bn_small_fwd_kernel<Q>, grid, dim3(256), 0, ST(stream), (const f32x4*)slabs, n_slabs,                  \
+                     (long)(slab_stride / 4), (f32x4*)raw, (f32x4*)y, gamma, beta, running_mean, running_var, momentum, eps, \
+                     n_updates, scale, shift, mean, invstd, (long)M, C4, act, y_amax)
+  if (qs == 4) RAC_SMALL_FWD(4);
+  else if (qs == 2) RAC_SMALL_FWD(2);
+  else RAC_SMALL_FWD(1);
+#undef RAC_SMALL_FWD
+  return check_launch("rac_bn_small_fwd");
+}
+
+int rac_bn_small_bwd(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,
+                     const float* invstd, float* dx, float* dgamma, float* dbeta, int64_t M, int32_t C, uint32_t* dx_amax,
+                     void* stream) {
+  RAC_REQUIRE(dy && x && scale && shift && mean && invstd && dx && M > 0 && C > 0 && C % 4 == 0 &&
+                  (dgamma == nullptr) == (dbeta == nullptr),
+              "rac_bn_small_bwd: bad args");
+  RAC_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(scale) && aligned16(shift) && aligned16(mean) &&
+                  aligned16(invstd),
+              "rac_bn_small_bwd: 16-byte aligned operands");
+  const int qs = small_bn_qs(C), C4 = C / 4;
+  const dim3 grid(C4 / qs);
+#define RAC_SMALL_BWD(Q)                                                                                              \
+  hipLaunchKernelGGL(bn_small_bwd_kernel<Q>, grid, dim3(256), 0, ST(stream), (const f32x4*)dy, (const f32x4*)x,        \
+                     (const f32x4*)scale, (const f32x4*)shift, (const f32x4*)mean, (const f32x4*)invstd, (f32x4*)dx, dgamma, \
+                     dbeta, (long)M, C4, dx_amax)
+  if (qs == 4) RAC_SMALL_BWD(4);
+  else if (qs == 2) RAC_SMALL_BWD(2);
+  else RAC_SMALL_BWD(1);
+#undef RAC_SMALL_BWD
+  return check_launch("rac_bn_small_bwd");
 }
 
 int rac_bn_bwd_reduce(const float* dy, const float* x, const float* scale, const float* shift, const float* mean,

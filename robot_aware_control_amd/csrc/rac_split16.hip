@@ -3308,7 +3308,11 @@ extern "C" int rac_conv2d_wgrad_split(const rac_wgrad_args* a, void* stream) {
                               (fn_t)wgrad16_kernel<5, 2, true>,  (fn_t)wgrad16_kernel<5, 1, true>};
   const int fi = p.presplit * 4 + (a->ksize == 5) * 2 + co64;
   const fn_t fn = fns[fi];
-  const int lds = 2 * 16384 + (a->ksize + 1) * 8192;
+  // (experiment, RAC_WGRAD_LDS_MIN=<bytes>: a dynamic-LDS request of at least that size -- above 80 KB only ONE workgroup
+  // fits a CU, which leaves half of every SIMD's slots to the kernels of another stream)
+  static const int lds_min = [] { const char* e = getenv("RAC_WGRAD_LDS_MIN"); return e ? atoi(e) : 0; }();
+  const int lds_need = 2 * 16384 + (a->ksize + 1) * 8192;
+  const int lds = lds_need > lds_min ? lds_need : lds_min;
   static bool attr_done[8] = {false, false, false, false, false, false, false, false};
   if (!attr_done[fi]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);

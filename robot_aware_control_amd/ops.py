@@ -1626,6 +1626,7 @@ class ConvTHead(torch.autograd.Function):
         return dx, None, None, None
 
 
+BN_SMALL = os.environ.get("RAC_BN_SMALL", "1") == "1"  # one time step's small vgg layers: BatchNorm in one launch each way
 BN_FUSED_APPLY = os.environ.get("RAC_BN_FUSED_APPLY", "1") == "1"  # BatchNorm finalize + affine + LeakyReLU in one launch
 
 
@@ -1681,6 +1682,23 @@ class VggLayer(torch.autograd.Function):
         c0 = x0.shape[3]
         ctx.split = (SPLIT_GEMM and Cout >= SPLIT_MIN_COUT_TRAIN
                      and split_supported(x0.shape[1], x0.shape[2], 3, weight.shape[1], Cout, c0 if x1 is not None else 0))
+        Mx = x0.shape[0] * x0.shape[1] * x0.shape[2]
+        ctx.small = bool(ctx.split and G == 1 and BN_SMALL and _lib.load().rac_bn_small_ok(Mx, Cout))
+        if ctx.small:
+            # one time step's small layer (a window that feeds its frames back): split-K combine + statistics + affine +
+            # LeakyReLU in ONE launch whose workgroups each own a slice of channels (rac_bn_small_fwd)
+            slabs, n_slabs, stride = conv_forward_split(x0, x1, weight, want_slabs=True)
+            raw = slabs[0] if n_slabs == 1 else torch.empty(tuple(slabs.shape[1:]), device=dev, dtype=torch.float32)
+            aff = torch.empty((4, 1, Cout), device=dev, dtype=torch.float32)
+            y = torch.empty_like(raw)
+            slot = amax_slot(dev)
+            call("rac_bn_small_fwd", ptr(slabs), n_slabs, stride, ptr(raw), ptr(y), ptr(gamma), ptr(beta), ptr(rmean),
+                 ptr(rvar), BN_MOMENTUM, BN_EPS, n_updates, ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), Mx, Cout,
+                 ACT_LEAKY, ptr(slot), stream_ptr())
+            tag_amax(y, slot)
+            ctx.save_for_backward(x0, x1, wfull, gamma, beta, raw, aff)
+            ctx.amax = (amax_tag(x0), amax_tag(x1))
+            return y
         if ctx.split:
             raw = conv_forward_split(x0, x1, weight, None, stats=stats, groups=G)
         else:
@@ -1700,15 +1718,20 @@ class VggLayer(torch.autograd.Function):
         Cout = weight.shape[0]
         M = raw.numel() // Cout
         G = ctx.groups
-        sums = zeros64((G, 2, Cout), dy.device)
-        call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M,
-             Cout, G, stream_ptr())
         draw = torch.empty_like(raw)
         want_affine = gamma.requires_grad
-        call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums),
-             ptr(draw), ptr(grad_buffer(gamma)) if want_affine else None,
-             ptr(grad_buffer(beta)) if want_affine else None, M, Cout, G, ptr(tag_amax(draw, amax_slot(dy.device))._rac_amax),
-             stream_ptr())
+        if ctx.small:  # (reduce + apply in one launch: rac_bn_small_bwd)
+            call("rac_bn_small_bwd", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(draw),
+                 ptr(grad_buffer(gamma)) if want_affine else None, ptr(grad_buffer(beta)) if want_affine else None, M, Cout,
+                 ptr(tag_amax(draw, amax_slot(dy.device))._rac_amax), stream_ptr())
+        else:
+            sums = zeros64((G, 2, Cout), dy.device)
+            call("rac_bn_bwd_reduce", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums), M,
+                 Cout, G, stream_ptr())
+            call("rac_bn_bwd_apply", ptr(dy), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(aff[2]), ptr(aff[3]), ptr(sums),
+                 ptr(draw), ptr(grad_buffer(gamma)) if want_affine else None,
+                 ptr(grad_buffer(beta)) if want_affine else None, M, Cout, G,
+                 ptr(tag_amax(draw, amax_slot(dy.device))._rac_amax), stream_ptr())
         C0 = x0.shape[3]
         C1 = x1.shape[3] if x1 is not None else 0
         dx0 = dx1 = None

@@ -1180,3 +1180,35 @@ def test_norm_lstm_cell_one_node_matches_seven(dev, monkeypatch, B, H, W, g):
     for key in ((True, True), (True, False)):
         for i, (a, b) in enumerate(zip(out[key], out[(False, False)])):
             assert relerr(a, b) < 5e-6, (key, i)
+
+
+@pytest.mark.parametrize("shape", [(16, 8, 8, 256, 0, 512), (16, 16, 16, 128, 128, 256), (16, 6, 8, 256, 0, 512), (4, 16, 16, 64, 0, 128)])
+def test_small_bn_layer_one_launch_each_way(dev, monkeypatch, shape):
+    """rac_bn_small_fwd / rac_bn_small_bwd (one time step's small train-mode vgg layer: split-K combine + statistics + apply,
+    and reduce + apply, in ONE launch each -- a workgroup owns a slice of channels and all rows) against the multi-launch
+    forms: the activated map, the running statistics, every gradient to 2e-6 (the sums run in another order), and the
+    single-launch forms twice in a row to the bit."""
+    from robot_aware_control_amd import ops
+    B, H, W, C0, C1, Cout = shape
+    Cin = C0 + C1
+    x = rnd(1, B, Cin, H, W)
+    w = rnd(2, Cout, Cin, 3, 3) * (1.4 / np.sqrt(Cin * 9))
+    gy = rnd(7, B, Cout, H, W)
+    out = {}
+    for key, small in (("small", True), ("again", True), ("multi", False)):
+        monkeypatch.setattr(ops, "BN_SMALL", small)
+        x0 = to_map(x[:, :C0], dev).requires_grad_(True)
+        x1 = to_map(x[:, C0:], dev).requires_grad_(True) if C1 else None
+        wd = cl_weight(w.clone()).to(dev).requires_grad_(True)
+        gd, bd = (1 + rnd(3, Cout, scale=0.1)).to(dev).requires_grad_(True), rnd(4, Cout, scale=0.1).to(dev).requires_grad_(True)
+        rm, rv = rnd(5, Cout, scale=0.1).to(dev), (1 + rnd(6, Cout, scale=0.1).abs()).to(dev)
+        y = ops.VggLayer.apply(x0, x1, wd, gd, bd, rm, rv, True, 2, None)
+        y.backward(to_map(gy, dev))
+        torch.cuda.synchronize()
+        out[key] = [y.detach(), rm, rv, x0.grad, wd.grad, gd.grad, bd.grad] + ([x1.grad] if C1 else []) + [ops.amax_tag(y)]
+    assert bool(ops._lib.load().rac_bn_small_ok(B * H * W, Cout))
+    for i, (a, b) in enumerate(zip(out["small"], out["again"])):
+        assert torch.equal(a, b), i
+    for i, (a, b) in enumerate(zip(out["small"][:-1], out["multi"][:-1])):
+        assert relerr(a, b) < 2e-6, i
+    assert int(out["small"][-1].item()) == int(out["small"][0].abs().max().view(torch.int32).item())
