@@ -1626,7 +1626,12 @@ class ConvTHead(torch.autograd.Function):
         return dx, None, None, None
 
 
-BN_SMALL = os.environ.get("RAC_BN_SMALL", "1") == "1"  # one time step's small vgg layers: BatchNorm in one launch each way
+# One time step's small vgg layers with BatchNorm in ONE launch each way (rac_bn_small_fwd / _bwd: a workgroup owns a slice of
+# channels and all rows -- no atomics, no second launch).  Built, tested (the same numbers to 2e-6) and measured SLOWER: with
+# every frame fed back 38.0 ms per step against 33.2 (4 MB layers; 34.6 with 2 MB, 42-53 with 8-16 MB), the deployed model's
+# stepped window 28.0 against 25.4 -- 32-64 workgroups walking 1 024+ rows of 8 slabs each are bound by what ONE workgroup
+# keeps in flight, and lose more than the two launches and their atomics cost.  Off; RAC_BN_SMALL=1 turns it on.
+BN_SMALL = os.environ.get("RAC_BN_SMALL", "0") == "1"
 BN_FUSED_APPLY = os.environ.get("RAC_BN_FUSED_APPLY", "1") == "1"  # BatchNorm finalize + affine + LeakyReLU in one launch
 
 
