@@ -851,15 +851,25 @@ def weight_parts(weight: torch.Tensor, transposed: bool = False):
     return ent.parts[transposed], ent.slot
 
 
+_CONV_ARGS = {}  # shape key -> the ConvArgs struct re-pointed per launch (_split_launch)
+
+
 def _split_launch(x0, x1, a0, a1, pw, wslot, out, *, B, H, W, k, Cin, Cout, C0, act=ACT_NONE, bias=None, scale=None,
                   shift=None, stats=None, split_k=1, slab_stride=0, stats_rows=0, out_amax=None, w_cin=0, a0_up=0,
                   per_image=False, pool=None):
     """`pool`: None, a [B, H/2, W/2, Cout] tensor the same launch fills with the 2 x 2 max pool of its output, or "query"
     (nothing launched: can this conv pool in its epilogue?  -> bool)."""
-    args = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k, accumulate=0,
-                    a_split=C0, o_split=0, slab_stride=slab_stride, a0=ptr(x0), a1=ptr(x1), w=ptr(pw), out0=ptr(out),
-                    out1=None if isinstance(pool, str) else ptr(pool), bias=ptr(bias), scale=ptr(scale), shift=ptr(shift),
-                    stats=ptr(stats), stats_rows=stats_rows, a0_up=a0_up, amax_per_image=1 if per_image else 0)
+    # (the argument struct of a shape is built once and re-pointed: the library reads it during the call only; building a
+    # 25-field ctypes structure from keywords costs more host time than the launch itself)
+    key = (B, H, W, k, Cin, Cout, act, split_k, C0, slab_stride, stats_rows, a0_up, per_image)
+    args = _CONV_ARGS.get(key)
+    if args is None:
+        args = _CONV_ARGS[key] = ConvArgs(mode=FWD, B=B, H=H, W=W, ksize=k, Cin=Cin, Cout=Cout, act=act, split_k=split_k,
+                                          accumulate=0, a_split=C0, o_split=0, slab_stride=slab_stride, stats_rows=stats_rows,
+                                          a0_up=a0_up, amax_per_image=1 if per_image else 0)
+    args.a0, args.a1, args.w, args.out0 = ptr(x0), ptr(x1), ptr(pw), ptr(out)
+    args.out1 = None if isinstance(pool, str) else ptr(pool)
+    args.bias, args.scale, args.shift, args.stats = ptr(bias), ptr(scale), ptr(shift), ptr(stats)
     if isinstance(pool, str):
         return bool(_lib.load().rac_conv2d_fwd_split_pool_ok(C.byref(args), w_cin))
     prof = PROFILE
