@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r06p; mkdir -p $out; : > $out/log.txt
+out=gpurun_out/exp_$(basename $0 .sh); mkdir -p $out; : > $out/log.txt
 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "stream_parts" > $out/test.log 2>&1; echo "rc $?" >> $out/test.log
 for n in 1 2 3 4; do
   echo "== RAC_CEM_STREAMS=$n" >> $out/log.txt

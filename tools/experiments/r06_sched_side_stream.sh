@@ -1,6 +1,6 @@
 #!/bin/bash
 # sched-sampling step: where the time-batched weight gradients start x the side stream's priority / CU mask
-out=gpurun_out/r06h; mkdir -p $out; : > $out/log.txt
+out=gpurun_out/exp_$(basename $0 .sh); mkdir -p $out; : > $out/log.txt
 B="python bench.py --workload train --no-exact --no-cpu-baseline --no-side --steps 10 --warmup 3 --sched all"
 run() { echo "== $*" >> $out/log.txt; env "$@" $B 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],2), d['time_breakdown_ms'])" >> $out/log.txt; }
 run X=0
