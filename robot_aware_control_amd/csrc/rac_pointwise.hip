@@ -1207,7 +1207,9 @@ int rac_bn_apply_act(const double* stats, int64_t count, const float* gamma, con
                   M > 0 && M % groups == 0 && (running_mean == nullptr) == (running_var == nullptr),
               "rac_bn_apply_act: bad args");
   int bpg, rpb;
-  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, y_amax ? 512 : 2048, &bpg, &rpb) && aligned16(x) && aligned16(y),
+  static const int max_blocks_env = [] { const char* e = getenv("RAC_BN_APPLY_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int max_blocks = max_blocks_env > 0 ? max_blocks_env : (y_amax ? 512 : 2048);
+  RAC_REQUIRE(bn_rows_form(C, M / groups, groups, max_blocks, &bpg, &rpb) && aligned16(x) && aligned16(y),
               "rac_bn_apply_act: C must be 4 * 2^k <= 1024 and the maps 16-byte aligned (use rac_bn_finalize + rac_affine_act)");
   hipLaunchKernelGGL(bn_apply_act_rows_kernel, dim3(bpg * groups), dim3(256), 0, ST(stream), stats, (long)count, gamma, beta,
                      running_mean, running_var, momentum, eps, n_updates, (const f32x4*)x, (f32x4*)y, scale, shift, mean,
